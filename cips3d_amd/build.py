@@ -1,0 +1,53 @@
+"""Build libcips3d_hip.so (gfx950) in-tree with hipcc.  `python -m cips3d_amd.build`.
+
+hipcc cross-compiles without a GPU.  The shared object is git-ignored but travels to the GPU
+box with the gpurun snapshot."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib", "libcips3d_hip.so")
+SOURCES = ["gemm_f32.hip", "siren.hip", "render.hip", "modfc.hip", "disc_ops.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
+    objdir = os.path.join(HERE, "lib", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "cips3d_hip.h")]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    if force or procs or _stale(OUT, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

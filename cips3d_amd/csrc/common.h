@@ -1,0 +1,75 @@
+// common.h — shared device helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CIPS_CHECK_LAUNCH() (int)hipGetLastError()
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Row (within a 32x32 MFMA C/D tile) held by accumulator register r of a lane
+// whose upper-half flag is hf = lane >> 5.  Column = lane & 31.
+// (cdna_hip_programming.md §3: row=(reg&3)+8*(reg>>2)+4*(lane>>5))
+__device__ __forceinline__ constexpr int mfma_row(int r, int hf) {
+  return (r & 3) + 8 * (r >> 2) + 4 * hf;
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+// sin / cos with explicit 2-term Cody-Waite range reduction, then the hardware
+// v_sin_f32 / v_cos_f32 (argument in revolutions).  FiLM gains are ~30, so
+// arguments reach tens of radians; reduce in fp32 first.
+#define CIPS_INV_2PI 0.15915494309189535f
+#define CIPS_2PI_HI 6.2831854820251465f
+#define CIPS_2PI_LO (-1.7484555314695172e-7f)
+
+__device__ __forceinline__ float reduce_2pi(float x) {
+  float k = rintf(x * CIPS_INV_2PI);
+  float r = fmaf(-k, CIPS_2PI_HI, x);
+  r = fmaf(-k, CIPS_2PI_LO, r);
+  return r;  // in [-pi, pi] (+- rounding)
+}
+
+// Polynomial sin/cos on the reduced argument r in [-pi, pi]: fold to
+// [-pi/4, pi/4] by quadrant and evaluate the classic Cephes sinf/cosf minimax
+// polynomials (abs error ~1e-7).
+__device__ __forceinline__ void sincos_reduced(float r, float* s, float* c) {
+  float q = rintf(r * 0.6366197723675814f);  // 2/pi
+  float t = fmaf(-q, 1.5707963705062866f, r);
+  t = fmaf(-q, -4.371138828673793e-8f, t);
+  int qi = (int)q;
+  float z = t * t;
+  float sp = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  sp = fmaf(sp, z, -1.6666654611e-1f);
+  float st = fmaf(sp * z, t, t);
+  float cp = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  cp = fmaf(cp, z, 4.166664568298827e-2f);
+  float ct = fmaf(cp, z * z, fmaf(-0.5f, z, 1.0f));
+  float ss, cc;
+  if (qi & 1) { ss = ct; cc = -st; } else { ss = st; cc = ct; }
+  if (qi & 2) { ss = -ss; cc = -cc; }
+  *s = ss; *c = cc;
+}
+
+template <bool HW>
+__device__ __forceinline__ float film_sin(float x) {
+  float r = reduce_2pi(x);
+  if (HW) return __builtin_amdgcn_sinf(r * CIPS_INV_2PI);
+  float s, c; sincos_reduced(r, &s, &c); return s;
+}
+template <bool HW>
+__device__ __forceinline__ void film_sincos(float x, float* s, float* c) {
+  float r = reduce_2pi(x);
+  if (HW) {
+    float rv = r * CIPS_INV_2PI;
+    *s = __builtin_amdgcn_sinf(rv);
+    *c = __builtin_amdgcn_cosf(rv);
+  } else {
+    sincos_reduced(r, s, c);
+  }
+}

@@ -1,0 +1,180 @@
+// disc_ops.hip — the discriminator's native ops for gfx950 (H5): the two ops the reference
+// ships as CUDA extensions, with identical contracts, plus the im2col / col2im pair that
+// feeds EqualConv2d to the fp32 MFMA GEMM.  All HBM-bandwidth bound streaming kernels.
+#include "common.h"
+#include "../../include/cips3d_hip.h"
+
+namespace {
+
+// exp/comm/op/fused_bias_act_kernel.cu:18-49
+__global__ __launch_bounds__(256) void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                                                             const float* __restrict__ ref, float* __restrict__ y,
+                                                             long long n, int size_b, int step_b, int mode,
+                                                             float alpha, float scale) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v = x[i];
+    if (b) v += b[(i / step_b) % size_b];
+    const float r = ref ? ref[i] : 0.f;
+    float o;
+    switch (mode) {
+      default:
+      case 10: o = v; break;
+      case 11: o = v; break;
+      case 12: o = 0.f; break;
+      case 30: o = (v > 0.f) ? v : v * alpha; break;
+      case 31: o = (r > 0.f) ? v : v * alpha; break;
+      case 32: o = 0.f; break;
+    }
+    y[i] = o * scale;
+  }
+}
+
+__device__ __forceinline__ int floor_div(int a, int b) {
+  int c = a / b;
+  if (c * b > a) c--;
+  return c;
+}
+
+// exp/comm/op/upfirdn2d_kernel.cu:52-137 — same arithmetic (polyphase, flipped kernel), one
+// thread per output element; the <= kh*kw input taps come from L1/L2 (each input element is
+// reused by kh*kw/(down^2) outputs of neighbouring lanes), so HBM sees input once + output once.
+struct UpfirArgs {
+  const float *in, *k;
+  float* out;
+  int major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w;
+};
+
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirArgs a) {
+  __shared__ float sk[64];
+  for (int t = threadIdx.x; t < a.kh * a.kw; t += 256) {
+    int ky = t / a.kw, kx = t % a.kw;
+    sk[t] = a.k[(a.kh - 1 - ky) * a.kw + (a.kw - 1 - kx)];
+  }
+  __syncthreads();
+  const long long total = (long long)a.major * a.out_h * a.out_w * a.minor;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int mi = (int)(idx % a.minor);
+    long long t = idx / a.minor;
+    const int ox = (int)(t % a.out_w); t /= a.out_w;
+    const int oy = (int)(t % a.out_h);
+    const long long mj = t / a.out_h;
+    const int mid_x = ox * a.down_x + a.up_x - 1 - a.pad_x0;
+    const int mid_y = oy * a.down_y + a.up_y - 1 - a.pad_y0;
+    const int in_x0 = floor_div(mid_x, a.up_x), in_y0 = floor_div(mid_y, a.up_y);
+    const int kx0 = (in_x0 + 1) * a.up_x - mid_x - 1, ky0 = (in_y0 + 1) * a.up_y - mid_y - 1;
+    float v = 0.f;
+    for (int yy = 0, ky = ky0; ky < a.kh; ++yy, ky += a.up_y) {
+      const int iy = in_y0 + yy;
+      if (iy < 0 || iy >= a.in_h) continue;
+      for (int xx = 0, kx = kx0; kx < a.kw; ++xx, kx += a.up_x) {
+        const int ix = in_x0 + xx;
+        if (ix < 0 || ix >= a.in_w) continue;
+        v += a.in[((mj * a.in_h + iy) * a.in_w + ix) * a.minor + mi] * sk[ky * a.kw + kx];
+      }
+    }
+    a.out[idx] = v;
+  }
+}
+
+// colT[b][(c,ky,kx)][(oy,ox)] = x[b][c][oy*s+ky-p][ox*s+kx-p]   (zero outside)
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int C,
+                                                     int H, int W, int kh, int kw, int stride, int pad, int Ho, int Wo) {
+  const long long total = (long long)B * C * kh * kw * Ho * Wo;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    long long t = idx;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho); t /= Ho;
+    const int kx = (int)(t % kw); t /= kw;
+    const int ky = (int)(t % kh); t /= kh;
+    const int c = (int)(t % C);
+    const long long b = t / C;
+    const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((b * C + c) * H + iy) * W + ix];
+    col[idx] = v;
+  }
+}
+
+// dx[b][c][iy][ix] = sum over (ky,kx,oy,ox) hitting (iy,ix) of colT  (gather form: deterministic)
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ col, float* __restrict__ dx, int B, int C,
+                                                     int H, int W, int kh, int kw, int stride, int pad, int Ho, int Wo) {
+  const long long total = (long long)B * C * H * W;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    long long t = idx;
+    const int ix = (int)(t % W); t /= W;
+    const int iy = (int)(t % H); t /= H;
+    const int c = (int)(t % C);
+    const long long b = t / C;
+    float v = 0.f;
+    for (int ky = 0; ky < kh; ++ky) {
+      const int ny = iy + pad - ky;
+      if (ny < 0 || (ny % stride) != 0) continue;
+      const int oy = ny / stride;
+      if (oy >= Ho) continue;
+      for (int kx = 0; kx < kw; ++kx) {
+        const int nx = ix + pad - kx;
+        if (nx < 0 || (nx % stride) != 0) continue;
+        const int ox = nx / stride;
+        if (ox >= Wo) continue;
+        v += col[((((b * C + c) * kh + ky) * kw + kx) * Ho + oy) * Wo + ox];
+      }
+    }
+    dx[idx] = v;
+  }
+}
+
+inline unsigned grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 32768 ? 32768 : b));
+}
+
+}  // namespace
+
+extern "C" int cips_version(void) { return 1; }
+extern "C" const char* cips_arch(void) { return "gfx950"; }
+
+extern "C" int cips_fused_bias_act(const float* x, const float* bias, const float* refer, float* y,
+                                   long long numel, int size_b, int step_b, int act, int grad, float alpha,
+                                   float scale, cips_stream_t stream) {
+  if (numel <= 0) return 0;
+  if (bias && (size_b <= 0 || step_b <= 0)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(fused_bias_act_kernel, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, x, bias,
+                     refer, y, numel, size_b, step_b, act * 10 + grad, alpha, scale);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h,
+                              int in_w, int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x,
+                              int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream) {
+  if (kernel_h * kernel_w > 64 || up_x < 1 || up_y < 1 || down_x < 1 || down_y < 1) return (int)hipErrorInvalidValue;
+  UpfirArgs a;
+  a.in = input; a.k = kernel; a.out = out; a.major = major; a.in_h = in_h; a.in_w = in_w; a.minor = minor;
+  a.kh = kernel_h; a.kw = kernel_w; a.up_x = up_x; a.up_y = up_y; a.down_x = down_x; a.down_y = down_y;
+  a.pad_x0 = pad_x0; a.pad_y0 = pad_y0;
+  a.out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h) / down_y + 1;
+  a.out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w) / down_x + 1;
+  long long total = (long long)major * a.out_h * a.out_w * minor;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(upfirdn2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_im2col(const float* x, float* col, int B, int C, int H, int W, int kh, int kw, int stride,
+                           int pad, cips_stream_t stream) {
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  long long total = (long long)B * C * kh * kw * Ho * Wo;
+  if (total <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, col, B, C, H, W,
+                     kh, kw, stride, pad, Ho, Wo);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_col2im(const float* col, float* dx, int B, int C, int H, int W, int kh, int kw, int stride,
+                           int pad, cips_stream_t stream) {
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  long long total = (long long)B * C * H * W;
+  if (total <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, col, dx, B, C, H, W,
+                     kh, kw, stride, pad, Ho, Wo);
+  return CIPS_CHECK_LAUNCH();
+}

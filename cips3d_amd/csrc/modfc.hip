@@ -1,0 +1,292 @@
+// modfc.hip — helpers around the CIPS INR head's modulated FC layers (H4) for gfx950.
+//
+// The reference (exp/comm/models/mod_conv_fc.py:470-489, SinStyleMod.forward_bmm) builds a
+// per-image weight  Wb = W * (s+1)[:,None] * rsqrt(sum_in (W*(s+1))^2 + eps)[None,:]  and runs
+// torch.bmm(x, Wb).  Here `cips_modfc_prep` produces Wb (and its transpose for the dX GEMM)
+// once per layer — B x 1 MB, L2/MALL resident — and the bmm itself is cips_gemm_f32 with the
+// LeakyReLU / skip epilogue fused.  ToRGB (generator.py:983-1006) is a 512 -> 3 projection:
+// pure HBM streaming, one wave per pixel row.
+#include "common.h"
+#include "../../include/cips3d_hip.h"
+
+namespace {
+
+// ---- prep: demod[b][n] and wb / wbt ------------------------------------------------
+// grid (out/32, B), 256 threads = 32 columns x 8 k-groups
+__global__ __launch_bounds__(256) void modfc_prep_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                         float* __restrict__ wb, float* __restrict__ wbt,
+                                                         float* __restrict__ demod, int in_dim, int out_dim, float eps) {
+  __shared__ float red[8][33];
+  __shared__ float dsh[32];
+  const int b = blockIdx.y;
+  const int c = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  const float* sb = s + (long long)b * in_dim;
+  float q = 0.f;
+  if (n < out_dim)
+    for (int k = kg; k < in_dim; k += 8) {
+      float u = W[(long long)k * out_dim + n] * (sb[k] + 1.f);
+      q = fmaf(u, u, q);
+    }
+  red[kg][c] = q;
+  __syncthreads();
+  if (kg == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][c];
+    float d = rsqrtf(t + eps);
+    dsh[c] = d;
+    if (n < out_dim) demod[(long long)b * out_dim + n] = d;
+  }
+  __syncthreads();
+  float* wbb = wb + (long long)b * in_dim * out_dim;
+  float* wtb = wbt + (long long)b * in_dim * out_dim;
+  if (n < out_dim) {
+    const float d = dsh[c];
+    for (int k = kg; k < in_dim; k += 8)
+      wbb[(long long)k * out_dim + n] = W[(long long)k * out_dim + n] * (sb[k] + 1.f) * d;
+  }
+  // transposed copy: consecutive threads walk k (contiguous in wbt)
+  for (int idx = threadIdx.x; idx < 32 * in_dim; idx += 256) {
+    const int k = idx % in_dim, cc = idx / in_dim;
+    const int nn = blockIdx.x * 32 + cc;
+    if (nn < out_dim)
+      wtb[(long long)nn * in_dim + k] = W[(long long)k * out_dim + nn] * (sb[k] + 1.f) * dsh[cc];
+  }
+}
+
+// ---- prep backward -------------------------------------------------------------------
+// u = W*(s+1), q_n = sum_k u^2 + eps, d = q^-1/2, Wb = u*d.  With G = dL/dWb:
+//   c_n  = sum_k G_kn u_kn
+//   du   = d_n * (G_kn - d_n^2 u_kn c_n)
+//   dW_kn = sum_b (s_bk+1) du_bkn ;  ds_bk = sum_n W_kn du_bkn
+__global__ __launch_bounds__(256) void modfc_prep_bwd_c_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                               const float* __restrict__ G, float* __restrict__ cbuf,
+                                                               int in_dim, int out_dim) {
+  __shared__ float red[8][33];
+  const int b = blockIdx.y;
+  const int c = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  const float* sb = s + (long long)b * in_dim;
+  const float* Gb = G + (long long)b * in_dim * out_dim;
+  float q = 0.f;
+  if (n < out_dim)
+    for (int k = kg; k < in_dim; k += 8)
+      q = fmaf(Gb[(long long)k * out_dim + n], W[(long long)k * out_dim + n] * (sb[k] + 1.f), q);
+  red[kg][c] = q;
+  __syncthreads();
+  if (kg == 0 && n < out_dim) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][c];
+    cbuf[(long long)b * out_dim + n] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void modfc_prep_bwd_w_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                               const float* __restrict__ demod, const float* __restrict__ G,
+                                                               const float* __restrict__ cbuf, float* __restrict__ dW,
+                                                               int B, int in_dim, int out_dim) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)in_dim * out_dim) return;
+  const int k = (int)(idx / out_dim), n = (int)(idx % out_dim);
+  const float w = W[idx];
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {   // fixed order: deterministic
+    const float m = s[(long long)b * in_dim + k] + 1.f;
+    const float d = demod[(long long)b * out_dim + n];
+    const float g = G[((long long)b * in_dim + k) * out_dim + n];
+    const float du = d * (g - d * d * (w * m) * cbuf[(long long)b * out_dim + n]);
+    acc = fmaf(m, du, acc);
+  }
+  dW[idx] = acc;
+}
+
+// one wave per (b, k): lanes stride over n
+__global__ __launch_bounds__(256) void modfc_prep_bwd_s_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                               const float* __restrict__ demod, const float* __restrict__ G,
+                                                               const float* __restrict__ cbuf, float* __restrict__ ds,
+                                                               int B, int in_dim, int out_dim) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)B * in_dim) return;
+  const int b = (int)(row / in_dim), k = (int)(row % in_dim);
+  const float m = s[row] + 1.f;
+  float acc = 0.f;
+  for (int n = lane; n < out_dim; n += 64) {
+    const float w = W[(long long)k * out_dim + n];
+    const float d = demod[(long long)b * out_dim + n];
+    const float g = G[row * out_dim + n];
+    const float du = d * (g - d * d * (w * m) * cbuf[(long long)b * out_dim + n]);
+    acc = fmaf(w, du, acc);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) ds[row] = acc;
+}
+
+// ---- ToRGB --------------------------------------------------------------------------
+// rgb[m][c] (+)= sum_k x[m][k] w[c][k] + bias[c];  one wave per row, float4 lanes
+__global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ rgb,
+                                                        long long M, int K, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long m = wave0; m < M; m += nwaves) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const float* xr = x + m * K;
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + k);
+      const float4 w0 = *reinterpret_cast<const float4*>(w + k);
+      const float4 w1 = *reinterpret_cast<const float4*>(w + K + k);
+      const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * K + k);
+      a0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
+      a1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
+      a2 += v.x * w2.x + v.y * w2.y + v.z * w2.z + v.w * w2.w;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off);
+    }
+    if (lane < 3) {
+      float v = (lane == 0) ? a0 : (lane == 1 ? a1 : a2);
+      v += bias ? bias[lane] : 0.f;
+      float* o = rgb + m * 3 + lane;
+      *o = accumulate ? (*o + v) : v;
+    }
+  }
+}
+
+constexpr int TORGB_ROWS = 512;  // rows per partial chunk
+
+// partial[chunk][c][k] = sum_{m in chunk} drgb[m][c] x[m][k] ; partial[chunk][3][0..2] = sum drgb
+__global__ __launch_bounds__(256) void torgb_bwd_w_partial_kernel(const float* __restrict__ x, const float* __restrict__ drgb,
+                                                                  float* __restrict__ partial, long long M, int K) {
+  const long long m0 = (long long)blockIdx.x * TORGB_ROWS;
+  const long long m1 = (m0 + TORGB_ROWS < M) ? m0 + TORGB_ROWS : M;
+  float* out = partial + (long long)blockIdx.x * 4 * K;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (long long m = m0; m < m1; ++m) {
+      const float v = x[m * K + k];
+      a0 = fmaf(drgb[m * 3 + 0], v, a0);
+      a1 = fmaf(drgb[m * 3 + 1], v, a1);
+      a2 = fmaf(drgb[m * 3 + 2], v, a2);
+    }
+    out[k] = a0; out[K + k] = a1; out[2 * K + k] = a2;
+  }
+  if (threadIdx.x < 3) {
+    float sacc = 0.f;
+    for (long long m = m0; m < m1; ++m) sacc += drgb[m * 3 + threadIdx.x];
+    out[3 * K + threadIdx.x] = sacc;
+  }
+}
+
+__global__ __launch_bounds__(256) void torgb_bwd_w_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                 float* __restrict__ dbias, int chunks, int K) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < 3 * K) {
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) acc += partial[(long long)c * 4 * K + idx];
+    dw[idx] = acc;
+  } else if (idx < 3 * K + 3) {
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) acc += partial[(long long)c * 4 * K + idx];
+    dbias[idx - 3 * K] = acc;
+  }
+}
+
+// dx[m][k] = sum_c drgb[m][c] w[c][k] (+ add[m][k]); optional unmasked copy; masked by (mask>0 ? 1 : slope)
+__global__ __launch_bounds__(256) void torgb_bwd_x_kernel(const float* __restrict__ drgb, const float* __restrict__ w,
+                                                          const float* __restrict__ add, const float* __restrict__ mask,
+                                                          float slope, float* __restrict__ out_unmasked,
+                                                          float* __restrict__ out, long long M, int K) {
+  const long long total4 = M * K / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const long long e = i * 4;
+    const long long m = e / K;
+    const int k = (int)(e % K);
+    const float g0 = drgb[m * 3 + 0], g1 = drgb[m * 3 + 1], g2 = drgb[m * 3 + 2];
+    const float4 w0 = *reinterpret_cast<const float4*>(w + k);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + K + k);
+    const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * K + k);
+    float4 v;
+    v.x = fmaf(g0, w0.x, fmaf(g1, w1.x, g2 * w2.x));
+    v.y = fmaf(g0, w0.y, fmaf(g1, w1.y, g2 * w2.y));
+    v.z = fmaf(g0, w0.z, fmaf(g1, w1.z, g2 * w2.z));
+    v.w = fmaf(g0, w0.w, fmaf(g1, w1.w, g2 * w2.w));
+    if (add) {
+      const float4 a = *reinterpret_cast<const float4*>(add + e);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (out_unmasked) *reinterpret_cast<float4*>(out_unmasked + e) = v;
+    if (mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(mask + e);
+      v.x *= mk.x > 0.f ? 1.f : slope; v.y *= mk.y > 0.f ? 1.f : slope;
+      v.z *= mk.z > 0.f ? 1.f : slope; v.w *= mk.w > 0.f ? 1.f : slope;
+    }
+    *reinterpret_cast<float4*>(out + e) = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int cips_modfc_prep(const float* weight, const float* s, float* wb, float* wbt, float* demod,
+                               int B, int in_dim, int out_dim, float eps, cips_stream_t stream) {
+  if (B <= 0 || in_dim <= 0 || out_dim <= 0) return (int)hipErrorInvalidValue;
+  dim3 grid((out_dim + 31) / 32, B);
+  hipLaunchKernelGGL(modfc_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, weight, s, wb, wbt, demod,
+                     in_dim, out_dim, eps);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_modfc_prep_bwd(const float* weight, const float* s, const float* demod, const float* gwb,
+                                   float* cbuf, float* dweight, float* ds, int B, int in_dim, int out_dim,
+                                   cips_stream_t stream) {
+  if (B <= 0 || in_dim <= 0 || out_dim <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(modfc_prep_bwd_c_kernel, dim3((out_dim + 31) / 32, B), dim3(256), 0, st, weight, s, gwb,
+                     cbuf, in_dim, out_dim);
+  long long nw = (long long)in_dim * out_dim;
+  hipLaunchKernelGGL(modfc_prep_bwd_w_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, weight, s,
+                     demod, gwb, cbuf, dweight, B, in_dim, out_dim);
+  long long rows = (long long)B * in_dim;
+  hipLaunchKernelGGL(modfc_prep_bwd_s_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, weight, s,
+                     demod, gwb, cbuf, ds, B, in_dim, out_dim);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_torgb_fwd(const float* x, const float* w, const float* bias, float* rgb, long long M,
+                              int K, int accumulate, cips_stream_t stream) {
+  if (M <= 0 || K <= 0 || (K & 3)) return (int)hipErrorInvalidValue;
+  long long blocks = (M + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(torgb_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                     rgb, M, K, accumulate);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_torgb_bwd_partials(long long M) { return (int)((M + TORGB_ROWS - 1) / TORGB_ROWS); }
+
+extern "C" int cips_torgb_bwd_w(const float* x, const float* drgb, float* partials, float* dw, float* dbias,
+                                long long M, int K, cips_stream_t stream) {
+  if (M <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+  int chunks = cips_torgb_bwd_partials(M);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(torgb_bwd_w_partial_kernel, dim3(chunks), dim3(256), 0, st, x, drgb, partials, M, K);
+  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 255) / 256), dim3(256), 0, st, partials, dw,
+                     dbias, chunks, K);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_torgb_bwd_x(const float* drgb, const float* w, const float* add, const float* mask,
+                                float slope, float* out_unmasked, float* out, long long M, int K,
+                                cips_stream_t stream) {
+  if (M <= 0 || K <= 0 || (K & 3)) return (int)hipErrorInvalidValue;
+  long long blocks = (M * K / 4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(torgb_bwd_x_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, drgb, w, add,
+                     mask, slope, out_unmasked, out, M, K);
+  return CIPS_CHECK_LAUNCH();
+}

@@ -1,0 +1,233 @@
+/*
+ * cips3d_hip.h — C-ABI of libcips3d_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the CIPS-3D generator / discriminator hot path
+ * (SURVEY.md §8b).  Every entry point takes raw DEVICE pointers (fp32,
+ * row-major contiguous unless a leading dimension is given), sizes, scalar
+ * parameters and a hipStream_t (passed as void*), returns a hipError_t as int
+ * (0 = success), allocates nothing, keeps no state and is thread-safe.
+ * The Python host (cips3d_amd/ops.py) binds these through ctypes; the reference
+ * binds its two CUDA ops through pybind11 (exp/comm/op/fused_bias_act.cpp:11-21,
+ * exp/comm/op/upfirdn2d.cpp:12-23) and everything else through ATen.
+ *
+ * Each declaration cites the reference code it replaces (paths relative to the
+ * reference repo root).
+ */
+#ifndef CIPS3D_HIP_H
+#define CIPS3D_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cips_stream_t; /* hipStream_t */
+
+/* ------------------------------------------------------------------ */
+/* library info                                                        */
+/* ------------------------------------------------------------------ */
+int cips_version(void);          /* ABI version, bumped on signature change */
+const char* cips_arch(void);     /* "gfx950" */
+
+/* ------------------------------------------------------------------ */
+/* H1  ray set-up                                                      */
+/* replaces exp/comm/comm_utils.py:365-412 (get_initial_rays_trig),    */
+/*          :416-438 (perturb_points), :584-679 (transform_sampled_points, */
+/*          the three bmm's).  Camera sampling / cam2world (O(batch))  */
+/*          stay on the host.                                          */
+/* ------------------------------------------------------------------ */
+/* xg[W], yg[H], zg[S]: torch.linspace grids built by the host (bit-exact
+ * with the reference).  zc = -1/tan(fov/2).  cam2world (B,4,4).  jitter U
+ * (B,n,S) in [0,1) or NULL (no perturbation).
+ * out: points (B,n,S,3) world space, z (B,n,S), dirs (B,n,3) world space. */
+int cips_rays_fwd(const float* xg, const float* yg, const float* zg, float zc,
+                  const float* cam2world, const float* jitter,
+                  float* points, float* z, float* dirs,
+                  int B, int H, int W, int S, cips_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* H2  fused FiLM-SIREN NeRF MLP (3 -> 128 -> 128 -> {sigma, 64 -> 32}) */
+/* replaces exp/cips3d/models/generator.py:260-317                     */
+/*   (NeRFNetwork.forward_with_frequencies_phase_shifts),              */
+/*   exp/comm/models/film_layer.py:78-107 (FiLMLayer.forward),         */
+/*   exp/comm/models/nerf_network.py:39-45 (UniformBoxWarp).           */
+/* ------------------------------------------------------------------ */
+typedef struct cips_siren_weights {
+  const float* w0;  /* (128,3)   siren.network.0.linear.weight */
+  const float* b0;  /* (128)                                  */
+  const float* w1;  /* (128,128) siren.network.1.linear.weight */
+  const float* b1;  /* (128)                                  */
+  const float* ws;  /* (1,128)   siren.final_layer.weight      */
+  const float* bs;  /* (1)                                    */
+  const float* wc;  /* (64,128)  siren.color_layer_sine.linear.weight */
+  const float* bc;  /* (64)                                   */
+  const float* wf;  /* (32,64)   siren.color_layer_linear.0.weight */
+  const float* bf;  /* (32)                                   */
+  /* per-image FiLM vectors: gain = 15*gain_fc(style)+30, bias = bias_fc(style) */
+  const float* g0;  /* (B,128) */
+  const float* p0;  /* (B,128) */
+  const float* g1;  /* (B,128) */
+  const float* p1;  /* (B,128) */
+  const float* gc;  /* (B,64)  */
+  const float* pc;  /* (B,64)  */
+  float box_scale;  /* 2/0.24 (UniformBoxWarp) */
+  int trig_mode;    /* 0: Cody-Waite + minimax polynomial sin/cos (default); 1: v_sin_f32/v_cos_f32 */
+} cips_siren_weights;
+
+/* points (B,P,3) -> feat (B,P,32), sigma (B,P). */
+int cips_siren_fwd(const cips_siren_weights* w, const float* points,
+                   float* feat, float* sigma, int B, int P, cips_stream_t stream);
+
+/* Backward, stage 1 ("data" pass; recomputes the forward in-kernel, saves no
+ * forward activations).  In: upstream grads dfeat (B,P,32), dsigma (B,P).
+ * Out (HBM staging for the weight-gradient GEMMs, all [B*P][F] row-major):
+ *   h1 (B*P,128), h2 (B*P,128), hc (B*P,64)       recomputed activations
+ *   da2 (B*P,128), dac (B*P,64)                    d loss / d sine-argument of layer 1 / colour layer
+ * Out (per-partial-row reductions, partial rows = cips_siren_bwd_rows(B,P),
+ *      each row belongs to one image: image = row / (rows/B)):
+ *   red (rows, 832): [0,128) sum_p da1 | [128,512) sum_p da1*x_c (c=0..2, 128 each)
+ *                    | [512,640) sum_p da2 | [640,704) sum_p dac
+ *                    | [704,832) sum_p dsigma*h2
+ */
+int cips_siren_bwd_rows(int B, int P);
+int cips_siren_bwd_data(const cips_siren_weights* w, const float* points,
+                        const float* dfeat, const float* dsigma,
+                        float* h1, float* h2, float* hc, float* da2, float* dac,
+                        float* red, int B, int P, cips_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* H3  hierarchical resampling + merge + alpha-composite               */
+/* ------------------------------------------------------------------ */
+/* Coarse weights + inverse-CDF resampling.
+ * replaces exp/dev/nerf_inr/models/generator_nerf_inr.py:537-598
+ *   (get_fine_points_and_direction), exp/pigan/pigan_utils.py:164-209
+ *   (sample_pdf) and the weights part of :212-273 (fancy_integration).
+ * sigma (R,S), z (R,S), noise (R,S) or NULL (noise already scaled by
+ * noise_std is NOT assumed: kernel applies sigma + noise*noise_std),
+ * u (R,S) uniforms, origins (B,3), dirs (R,3) with R = B*n rays.
+ * out: fine_z (R,S), fine_pts (R,S,3); optional debug outs (may be NULL):
+ * weights (R,S), cdf (R,S-1), inds (R,S) int64 (searchsorted result).
+ * clamp_mode: 0 = relu, 1 = softplus. */
+int cips_resample_fwd(const float* sigma, const float* z, const float* noise, float noise_std,
+                      const float* u, const float* origins, const float* dirs,
+                      float* fine_z, float* fine_pts,
+                      float* weights_out, float* cdf_out, long long* inds_out,
+                      int B, int n, int S, int clamp_mode, cips_stream_t stream);
+
+/* Merge (coarse + fine, ascending z) and alpha-composite.
+ * replaces exp/cips3d/models/generator.py:1733-1752 (cat/sort/gather) and
+ *   exp/pigan/pigan_utils.py:212-273 (fancy_integration).
+ * feat_c (R,S,32), sig_c (R,S), z_c (R,S); fine set same shapes or NULL
+ * (then E = S, no merge).  noise (R,E) in SORTED order or NULL.
+ * out: fea (R,32), depth (R), weights (R,E) sorted order, order (R,E) int32
+ * (index into [fine(0..S-1), coarse(S..2S-1)] like torch.cat([fine, coarse]);
+ * for the non-hierarchical case the identity), zsorted (R,E) (may be NULL).
+ * flags: bit0 last_back, bit1 white_back. */
+int cips_composite_fwd(const float* feat_c, const float* sig_c, const float* z_c,
+                       const float* feat_f, const float* sig_f, const float* z_f,
+                       const float* noise, float noise_std,
+                       float* fea, float* depth, float* weights, int* order, float* zsorted,
+                       int R, int S, int clamp_mode, int flags, cips_stream_t stream);
+
+/* Backward of the above w.r.t. feat/sigma of both sample sets (z has no grad:
+ * fine z is detach()ed, generator_nerf_inr.py:575-579; coarse z is an input).
+ * dfea (R,32) upstream.  Re-reads the forward inputs (no saved activations
+ * besides `order`). */
+int cips_composite_bwd(const float* feat_c, const float* sig_c, const float* z_c,
+                       const float* feat_f, const float* sig_f, const float* z_f,
+                       const float* noise, float noise_std, const int* order,
+                       const float* dfea,
+                       float* dfeat_c, float* dsig_c, float* dfeat_f, float* dsig_f,
+                       int R, int S, int clamp_mode, int flags, cips_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* generic batched fp32 GEMM on v_mfma_f32_32x32x2_f32 with fused epilogues */
+/* the workhorse under H4 (bmm in exp/comm/models/mod_conv_fc.py:489),  */
+/* the SIREN weight gradients, and H5 convolutions (im2col GEMM).       */
+/* ------------------------------------------------------------------ */
+typedef struct cips_gemm_desc {
+  /* C[b] (M,N) = epilogue( A[b] (M,K) @ B[b] (K,N) ) ; B always k-major (row-major K x N). */
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  long long strideA, strideB, strideC; /* elements between batches */
+  int batch;
+  int a_kmajor;          /* 0: A stored (M,K) row-major; 1: A stored (K,M) row-major ("TN") */
+  /* ---- epilogue (all optional; every aux matrix uses ldc / strideC addressing) ---- */
+  float alpha;           /* acc *= alpha (0 is treated as 1) */
+  const float* bias;     /* (N) added after alpha */
+  int act;               /* 0 none; 1 leaky_relu(slope) ; 2 leaky_relu(slope)*act_gain */
+  float slope; float act_gain;
+  const float* resid;    /* after act: C2 = act(..) + resid */
+  float* C2;             /* second output (written only if non-NULL) */
+  const float* add;      /* before mask: s = acc + add */
+  const float* rgb_g;    /* (batch*M,3) with row stride 3: s += rgb_g[m,:] @ rgb_w[:, n] */
+  const float* rgb_w;    /* (3,N) row-major */
+  float* C_unmasked;     /* if non-NULL, s stored here before masking */
+  const float* mask;     /* C = s * (mask > 0 ? 1 : slope) * (act==2? act_gain:1) */
+} cips_gemm_desc;
+
+int cips_gemm_f32(const cips_gemm_desc* d, cips_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* H4  CIPS INR head helpers (modulated FC, demodulated)                */
+/* replaces exp/comm/models/mod_conv_fc.py:470-489 (SinStyleMod.forward_bmm) */
+/* ------------------------------------------------------------------ */
+/* weight (in,out) [= SinStyleMod.weight[0]], style s (B,in) [= modulation(style)].
+ * out: wb (B,in,out) = W*(s+1)*demod, wbt (B,out,in) its transpose,
+ * demod (B,out) = rsqrt(sum_in (W*(s+1))^2 + eps). */
+int cips_modfc_prep(const float* weight, const float* s, float* wb, float* wbt, float* demod,
+                    int B, int in_dim, int out_dim, float eps, cips_stream_t stream);
+/* backward of prep: gwb (B,in,out) = dL/d wb  ->  dweight (in,out), ds (B,in).
+ * cbuf: caller-provided scratch of B*out floats. */
+int cips_modfc_prep_bwd(const float* weight, const float* s, const float* demod, const float* gwb,
+                        float* cbuf, float* dweight, float* ds, int B, int in_dim, int out_dim,
+                        cips_stream_t stream);
+
+/* ToRGB (generator.py:983-1006): rgb (M,3) (+)= x (M,K) @ w^T (3,K) + bias.
+ * accumulate != 0: rgb += ...  */
+int cips_torgb_fwd(const float* x, const float* w, const float* bias, float* rgb,
+                   long long M, int K, int accumulate, cips_stream_t stream);
+/* dw (3,K) = drgb^T @ x, dbias(3) = sum drgb.  Uses `partials` scratch of
+ * cips_torgb_bwd_partials(M) * 4 * K floats, reduced deterministically. */
+int cips_torgb_bwd_partials(long long M);
+int cips_torgb_bwd_w(const float* x, const float* drgb, float* partials, float* dw, float* dbias,
+                     long long M, int K, cips_stream_t stream);
+/* dx (M,K) = drgb (M,3) @ w (3,K) [+ add]; optional copy before masking; out = dx * (mask>0 ? 1 : slope)
+ * (the LeakyReLU gate of the layer below, fused).  mask / add / out_unmasked may be NULL. */
+int cips_torgb_bwd_x(const float* drgb, const float* w, const float* add, const float* mask, float slope,
+                     float* out_unmasked, float* out, long long M, int K, cips_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* H5  discriminator native ops                                        */
+/* ------------------------------------------------------------------ */
+/* Same contract as the reference's pybind op
+ *   fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ * (exp/comm/op/fused_bias_act.cpp:11-21, kernel fused_bias_act_kernel.cu:18-49):
+ * y = f(x + b[(i/step_b) % size_b]) * scale, act*10+grad switch:
+ * 10 linear, 11/12 linear grads, 30 lrelu, 31 lrelu grad gated by sign(refer),
+ * 32 second-order (=0).  bias / refer may be NULL ("empty tensor"). */
+int cips_fused_bias_act(const float* x, const float* bias, const float* refer, float* y,
+                        long long numel, int size_b, int step_b,
+                        int act, int grad, float alpha, float scale, cips_stream_t stream);
+
+/* Same contract as upfirdn2d_op.upfirdn2d(input[N,H,W,minor], kernel[kh,kw],
+ * up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+ * (exp/comm/op/upfirdn2d.cpp:12-23, kernel upfirdn2d_kernel.cu:52-137). */
+int cips_upfirdn2d(const float* input, const float* kernel, float* out,
+                   int major, int in_h, int in_w, int minor, int kernel_h, int kernel_w,
+                   int up_x, int up_y, int down_x, int down_y,
+                   int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream);
+
+/* im2col for the EqualConv2d GEMM path (exp/cips3d/models/discriminator.py:40-48).
+ * x (B,C,H,W) NCHW -> col (B, C*kh*kw, Ho*Wo) row-major ("colT": k-major B operand, so that
+ * out[b] (O, Ho*Wo) = W (O, C*kh*kw) @ col[b] lands directly in NCHW).  col2im is the adjoint
+ * (gather form, deterministic). */
+int cips_im2col(const float* x, float* col, int B, int C, int H, int W,
+                int kh, int kw, int stride, int pad, cips_stream_t stream);
+int cips_col2im(const float* col, float* dx, int B, int C, int H, int W,
+                int kh, int kw, int stride, int pad, cips_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIPS3D_HIP_H */
