@@ -1,0 +1,89 @@
+"""ctypes binding of libcips3d_hip.so — the C-ABI declared in include/cips3d_hip.h.
+
+The product path has NO CPU fallback: if the shared object is missing or a symbol is absent,
+import fails loudly (RuntimeError).  Build it with `python -m cips3d_amd.build` (hipcc,
+--offload-arch=gfx950; cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcips3d_hip.so")
+
+vp = C.c_void_p
+i32 = C.c_int
+i64 = C.c_longlong
+f32 = C.c_float
+
+
+class SirenWeights(C.Structure):
+    _fields_ = [(n, vp) for n in
+                ("w0", "b0", "w1", "b1", "ws", "bs", "wc", "bc", "wf", "bf",
+                 "g0", "p0", "g1", "p1", "gc", "pc")] + [("box_scale", f32), ("trig_mode", i32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("lda", i32), ("ldb", i32), ("ldc", i32),
+        ("strideA", i64), ("strideB", i64), ("strideC", i64),
+        ("batch", i32), ("a_kmajor", i32), ("b_nmajor", i32),
+        ("alpha", f32), ("bias", vp), ("bias_m", vp),
+        ("act", i32), ("slope", f32), ("act_gain", f32),
+        ("resid", vp), ("C2", vp), ("add", vp),
+        ("rgb_g", vp), ("rgb_w", vp), ("C_unmasked", vp), ("mask", vp),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/cips3d_hip.h
+SIGNATURES = {
+    "cips_version": (i32, []),
+    "cips_arch": (C.c_char_p, []),
+    "cips_rays_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "cips_siren_fwd": (i32, [C.POINTER(SirenWeights), vp, vp, vp, i32, i32, vp]),
+    "cips_siren_bwd_rows": (i32, [i32, i32]),
+    "cips_siren_bwd_data": (i32, [C.POINTER(SirenWeights), vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "cips_resample_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "cips_composite_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "cips_composite_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "cips_gemm_f32": (i32, [C.POINTER(GemmDesc), vp]),
+    "cips_modfc_prep": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "cips_modfc_prep_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "cips_torgb_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
+    "cips_torgb_bwd_partials": (i32, [i64]),
+    "cips_torgb_bwd_w": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
+    "cips_torgb_bwd_x": (i32, [vp, vp, vp, vp, f32, vp, vp, i64, i32, vp]),
+    "cips_fused_bias_act": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, vp]),
+    "cips_upfirdn2d": (i32, [vp, vp, vp] + [i32] * 14 + [vp]),
+    "cips_im2col": (i32, [vp, vp] + [i32] * 8 + [vp]),
+    "cips_col2im": (i32, [vp, vp] + [i32] * 8 + [vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"cips3d_amd: HIP extension not built ({LIB_PATH} missing). "
+            "Run `python -m cips3d_amd.build` (needs hipcc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"cips3d_amd: symbol {name} missing from {LIB_PATH}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(err, what):
+    if err != 0:
+        raise RuntimeError(f"cips3d_amd: {what} failed with hipError {err}")

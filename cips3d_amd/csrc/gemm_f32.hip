@@ -26,14 +26,15 @@ constexpr int LDA_M = BK + 1;   // A row-major image  [BM][33]
 constexpr int LDA_K = BM;       // A k-major image    [BK][128]
 constexpr int LDB = BN;         // B image            [BK][128]
 constexpr int SMEM_A = BM * LDA_M;  // >= BK*LDA_K
-constexpr int SMEM_B = BK * LDB;
+constexpr int LDB_N = BK + 1;      // B n-major image    [BN][33]
+constexpr int SMEM_B = BN * LDB_N;  // >= BK*LDB
 
 struct Args {
   cips_gemm_desc d;
   int tiles_m, tiles_n, total;
 };
 
-template <bool A_KMAJOR>
+template <bool A_KMAJOR, bool B_NMAJOR>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Args g) {
   __shared__ __attribute__((aligned(16))) float smem[SMEM_A + SMEM_B];
   float* As = smem;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Args g) {
         ra[i] = v;
       }
     }
-    {
+    if (!B_NMAJOR) {
       const int c4 = (tid & 31) * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -106,6 +107,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Args g) {
         int gk = k0 + kr, gn = n0 + c4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gk < K && gn < N) v = *reinterpret_cast<const float4*>(B + (long long)gk * d.ldb + gn);
+        rb[i] = v;
+      }
+    } else {
+      // B (N,K) row-major: thread -> rows n = tid/8 + 32*i, 4 consecutive k at (tid%8)*4
+      const int c4 = (tid & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = (tid >> 3) + 32 * i;
+        int gn = n0 + row, gk = k0 + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gn < N && gk < K) v = *reinterpret_cast<const float4*>(B + (long long)gn * d.ldb + gk);
         rb[i] = v;
       }
     }
@@ -128,12 +140,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Args g) {
         *reinterpret_cast<float4*>(As + kr * LDA_K + c4) = ra[i];
       }
     }
-    {
+    if (!B_NMAJOR) {
       const int c4 = (tid & 31) * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int kr = (tid >> 5) + 8 * i;
         *reinterpret_cast<float4*>(Bs + kr * LDB + c4) = rb[i];
+      }
+    } else {
+      const int c4 = (tid & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = (tid >> 3) + 32 * i;
+        float* p = Bs + row * LDB_N + c4;
+        p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w;
       }
     }
   };
@@ -154,7 +174,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Args g) {
         a[i] = A_KMAJOR ? As[(kk * 2 + hf) * LDA_K + m] : As[m * LDA_M + kk * 2 + hf];
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[(kk * 2 + hf) * LDB + wn * 64 + j * 32 + l31];
+      for (int j = 0; j < 2; ++j) {
+        int n = wn * 64 + j * 32 + l31;
+        b[j] = B_NMAJOR ? Bs[n * LDB_N + kk * 2 + hf] : Bs[(kk * 2 + hf) * LDB + n];
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -186,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Args g) {
         if (row >= M) continue;
         const long long off = cbase + (long long)row * d.ldc + col;
         float v = acc[i][j][r] * alpha + bias;
+        if (d.bias_m) v += d.bias_m[row];
         if (d.add) v += d.add[off];
         if (d.rgb_g) {
           const float* gp = d.rgb_g + ((long long)bz * M + row) * 3;
@@ -205,9 +229,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Args g) {
 
 extern "C" int cips_gemm_f32(const cips_gemm_desc* d, cips_stream_t stream) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
-  // vector (16 B) global loads: leading dims / K-or-M extents must be multiples of 4 floats
-  if ((d->lda & 3) || (d->ldb & 3) || (d->N & 3)) return (int)hipErrorInvalidValue;
+  // vector (16 B) global loads: leading dims and the contiguous extents must be multiples of 4 floats
+  if ((d->lda & 3) || (d->ldb & 3)) return (int)hipErrorInvalidValue;
   if (d->a_kmajor ? (d->M & 3) : (d->K & 3)) return (int)hipErrorInvalidValue;
+  if (d->b_nmajor ? (d->K & 3) : (d->N & 3)) return (int)hipErrorInvalidValue;
   if ((d->strideA & 3) || (d->strideB & 3)) return (int)hipErrorInvalidValue;
   Args g;
   g.d = *d;
@@ -217,9 +242,12 @@ extern "C" int cips_gemm_f32(const cips_gemm_desc* d, cips_stream_t stream) {
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
   hipStream_t s = (hipStream_t)stream;
-  if (d->a_kmajor)
-    hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(g.total), dim3(256), 0, s, g);
-  else
-    hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(g.total), dim3(256), 0, s, g);
+  const int variant = (d->a_kmajor ? 1 : 0) | (d->b_nmajor ? 2 : 0);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(g.total), dim3(256), 0, s, g); break;
+    case 1: hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(g.total), dim3(256), 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(g.total), dim3(256), 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(g.total), dim3(256), 0, s, g); break;
+  }
   return CIPS_CHECK_LAUNCH();
 }

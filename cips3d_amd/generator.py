@@ -1,0 +1,601 @@
+"""MI355X-native drop-in for the reference generator API (exp/cips3d/models/generator.py).
+
+Same constructor / forward signatures, attribute names and state_dict layout as
+`GeneratorNerfINR` (generator.py:1159-1951) and `GeneratorNerfINR_freeze_NeRF` (:1955-2083), so
+checkpoints and `exp/cips3d` scripts work unchanged; the arithmetic runs in the hand-written
+HIP kernels of libcips3d_hip.so (see ops.py / include/cips3d_hip.h).  Modules here only HOLD
+parameters (same names, shapes and initialisers, created in the reference's order so that the
+same torch seed yields the same initial weights) and orchestrate kernel launches.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------
+# initialisers (film_layer.py:11-18, inr_network.py:20-27, tl2 init_func.kaiming_leaky_init)
+# ------------------------------------------------------------------------------------------
+def frequency_init(freq):
+    def init(m):
+        with torch.no_grad():
+            if isinstance(m, nn.Linear):
+                num_input = m.weight.size(-1)
+                m.weight.uniform_(-np.sqrt(6 / num_input) / freq, np.sqrt(6 / num_input) / freq)
+    return init
+
+
+def kaiming_leaky_init(m):
+    if m.__class__.__name__.find('Linear') != -1:
+        torch.nn.init.kaiming_normal_(m.weight, a=0.2, mode='fan_in', nonlinearity='leaky_relu')
+
+
+# ------------------------------------------------------------------------------------------
+# parameter holders
+# ------------------------------------------------------------------------------------------
+class PixelNorm(nn.Module):
+    """multi_head_mapping.py:13-19"""
+
+    def forward(self, input):
+        assert input.dim() == 2
+        return input * torch.rsqrt(torch.mean(input ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+class MultiHeadMappingNetwork(nn.Module):
+    """z -> style MLP (multi_head_mapping.py:28-153).  Tiny (b x 512) GEMMs: stays on
+    torch/rocBLAS; must remain differentiable and state-dict compatible."""
+
+    def __init__(self, z_dim, hidden_dim, base_layers, head_layers, head_dim_dict,
+                 add_norm=False, norm_out=False, **kwargs):
+        super().__init__()
+        self.z_dim = z_dim
+        self.head_dim_dict = head_dim_dict
+        out_dim = z_dim
+        self.module_name_list = []
+        self.norm = PixelNorm()
+        base_net = []
+        for i in range(base_layers):
+            in_dim = out_dim
+            out_dim = hidden_dim
+            layer = nn.Linear(in_features=in_dim, out_features=out_dim)
+            layer.apply(kaiming_leaky_init)
+            base_net.append(layer)
+            if head_layers > 0 or i != base_layers - 1:
+                if add_norm:
+                    base_net.append(nn.LayerNorm(out_dim))
+                base_net.append(nn.LeakyReLU(0.2, inplace=True))
+        if len(base_net) > 0:
+            if norm_out and head_layers <= 0:
+                base_net.append(nn.LayerNorm(out_dim))
+            self.base_net = nn.Sequential(*base_net)
+            self.num_z = 1
+            self.module_name_list.append('base_net')
+        else:
+            self.base_net = None
+            self.num_z = len(head_dim_dict)
+        head_in_dim = out_dim
+        for name, head_dim in head_dim_dict.items():
+            if head_layers > 0:
+                head_net = []
+                out_dim = head_in_dim
+                for i in range(head_layers):
+                    in_dim = out_dim
+                    out_dim = head_dim if i == head_layers - 1 else hidden_dim
+                    hl = nn.Linear(in_features=in_dim, out_features=out_dim)
+                    hl.apply(kaiming_leaky_init)
+                    head_net.append(hl)
+                    if i != head_layers - 1:
+                        head_net.append(nn.LeakyReLU(0.2, inplace=True))
+                    elif norm_out:
+                        head_net.append(nn.LayerNorm(out_dim))
+                head_net = nn.Sequential(*head_net)
+                self.module_name_list.append(name)
+            else:
+                head_net = nn.Identity()
+            self.add_module(name, head_net)
+
+    def forward(self, z):
+        if self.base_net is not None:
+            z = self.norm(z)
+            base_fea = self.base_net(z)
+            head_inputs = {name: base_fea for name in self.head_dim_dict.keys()}
+        else:
+            head_inputs = {name: self.norm(z[idx]) for idx, name in enumerate(self.head_dim_dict.keys())}
+        return {name: getattr(self, name)(head_inputs[name]) for name in self.head_dim_dict.keys()}
+
+
+class FiLMLayer(nn.Module):
+    """Parameters of film_layer.FiLMLayer (film_layer.py:41-107); the sine layer itself is
+    evaluated inside the fused SIREN kernel."""
+
+    def __init__(self, in_dim, out_dim, style_dim, use_style_fc=True, **kwargs):
+        super().__init__()
+        assert use_style_fc
+        self.in_dim, self.out_dim, self.style_dim, self.use_style_fc = in_dim, out_dim, style_dim, use_style_fc
+        self.linear = nn.Linear(in_dim, out_dim)
+        self.linear.apply(frequency_init(25))
+        self.gain_fc = nn.Linear(style_dim, out_dim)
+        self.bias_fc = nn.Linear(style_dim, out_dim)
+        self.gain_fc.weight.data.mul_(0.25)
+        self.bias_fc.weight.data.mul_(0.25)
+
+    def film(self, style):
+        """gain = 15 * gain_fc(style) + 30 (LinearScale, film_layer.py:21-32, :59), bias = bias_fc(style)."""
+        return self.gain_fc(style) * 15 + 30, self.bias_fc(style)
+
+
+class NeRFNetwork(nn.Module):
+    """generator.py:151-340.  forward() keeps the reference op boundary ((b,P,3) -> (b,P,33));
+    the generator uses `evaluate()` which returns feat / sigma separately (no 33-wide cat)."""
+
+    def __init__(self, in_dim=3, hidden_dim=256, hidden_layers=2, style_dim=512, rgb_dim=3, device=None,
+                 name_prefix='nerf', **kwargs):
+        super().__init__()
+        if not (in_dim == 3 and hidden_dim == 128 and hidden_layers == 2 and rgb_dim == 32):
+            raise NotImplementedError(
+                "the fused SIREN kernel is specialised for the shipped configs "
+                "(in 3, hidden 128, 2 layers, rgb_dim 32; ffhq_exp.yaml:51-58)")
+        self.device = device
+        self.in_dim, self.hidden_dim, self.rgb_dim = in_dim, hidden_dim, rgb_dim
+        self.style_dim, self.hidden_layers, self.name_prefix = style_dim, hidden_layers, name_prefix
+        self.module_name_list = []
+        self.style_dim_dict = {}
+        self.network = nn.ModuleList()
+        self.module_name_list.append('network')
+        _out = in_dim
+        for idx in range(hidden_layers):
+            _in, _out = _out, hidden_dim
+            layer = FiLMLayer(in_dim=_in, out_dim=_out, style_dim=style_dim, use_style_fc=True)
+            self.network.append(layer)
+            self.style_dim_dict[f'{name_prefix}_w{idx}'] = layer.style_dim
+        self.final_layer = nn.Linear(hidden_dim, 1)
+        self.module_name_list.append('final_layer')
+        self.color_layer_sine = FiLMLayer(in_dim=hidden_dim, out_dim=hidden_dim // 2, style_dim=style_dim,
+                                          use_style_fc=True)
+        self.style_dim_dict[f'{name_prefix}_rgb'] = self.color_layer_sine.style_dim
+        self.module_name_list.append('color_layer_sine')
+        self.color_layer_linear = nn.Sequential(nn.Linear(hidden_dim // 2, rgb_dim))
+        self.color_layer_linear.apply(kaiming_leaky_init)
+        self.module_name_list.append('color_layer_linear')
+        self.dim_styles = sum(self.style_dim_dict.values())
+
+    def evaluate(self, points, style_dict):
+        """points (b,P,3) -> feat (b,P,32), sigma (b,P) via the fused HIP kernel."""
+        p = self.name_prefix
+        g0, p0 = self.network[0].film(style_dict[f'{p}_w0'])
+        g1, p1 = self.network[1].film(style_dict[f'{p}_w1'])
+        gc, pc = self.color_layer_sine.film(style_dict[f'{p}_rgb'])
+        return ops.SirenFunction.apply(
+            points, g0, p0, g1, p1, gc, pc,
+            self.network[0].linear.weight, self.network[0].linear.bias,
+            self.network[1].linear.weight, self.network[1].linear.bias,
+            self.final_layer.weight, self.final_layer.bias,
+            self.color_layer_sine.linear.weight, self.color_layer_sine.linear.bias,
+            self.color_layer_linear[0].weight, self.color_layer_linear[0].bias)
+
+    def forward(self, input, style_dict, ray_directions=None, **kwargs):
+        feat, sigma = self.evaluate(input, style_dict)
+        return torch.cat([feat, sigma.unsqueeze(-1)], dim=-1)
+
+    forward_with_frequencies_phase_shifts = forward
+
+
+class SinStyleMod(nn.Module):
+    """Parameters of mod_conv_fc.SinStyleMod (mod_conv_fc.py:392-450).  `norm` exists in the
+    reference state_dict but is never used in forward (:444-445)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size=1, style_dim=None, use_style_fc=False,
+                 demodulate=True, eps=1e-8, **kwargs):
+        super().__init__()
+        assert kernel_size == 1 and use_style_fc and demodulate
+        self.eps, self.in_channel, self.out_channel, self.style_dim = eps, in_channel, out_channel, style_dim
+        self.weight = nn.Parameter(torch.randn(1, in_channel, out_channel))
+        torch.nn.init.kaiming_normal_(self.weight[0], a=0.2, mode='fan_in', nonlinearity='leaky_relu')
+        self.modulation = nn.Linear(style_dim, in_channel)
+        self.modulation.apply(kaiming_leaky_init)
+        self.norm = nn.LayerNorm(in_channel)
+
+
+class SinBlock(nn.Module):
+    """generator.py:893-980 (two modulated FCs + LeakyReLU(0.2), optional skip)."""
+
+    def __init__(self, in_dim, out_dim, style_dim, name_prefix):
+        super().__init__()
+        self.in_dim, self.out_dim, self.style_dim, self.name_prefix = in_dim, out_dim, style_dim, name_prefix
+        self.style_dim_dict = {}
+        self.mod1 = SinStyleMod(in_channel=in_dim, out_channel=out_dim, style_dim=style_dim, use_style_fc=True)
+        self.style_dim_dict[f'{name_prefix}_0'] = self.mod1.style_dim
+        self.mod2 = SinStyleMod(in_channel=out_dim, out_channel=out_dim, style_dim=style_dim, use_style_fc=True)
+        self.style_dim_dict[f'{name_prefix}_1'] = self.mod2.style_dim
+
+
+class ToRGB(nn.Module):
+    """generator.py:983-1006"""
+
+    def __init__(self, in_dim, dim_rgb=3, use_equal_fc=False):
+        super().__init__()
+        assert not use_equal_fc
+        self.in_dim, self.dim_rgb = in_dim, dim_rgb
+        self.linear = nn.Linear(in_dim, dim_rgb)
+
+
+class CIPSNet(nn.Module):
+    """generator.py:1009-1154.  NOTE (reference behaviour): `points_forward` calls
+    `self.inr_net(pixels_fea, style_dict)` WITHOUT img_size (generator.py:1754), so the default
+    img_size=1024 applies and ALL nine blocks "4".."1024" run at every resolution."""
+
+    def __init__(self, input_dim, style_dim, hidden_dim=256, pre_rgb_dim=32, device=None, name_prefix='inr',
+                 **kwargs):
+        super().__init__()
+        if pre_rgb_dim != 3:
+            raise NotImplementedError("shipped configs use pre_rgb_dim 3 (ffhq_exp.yaml:72)")
+        self.device, self.pre_rgb_dim, self.name_prefix = device, pre_rgb_dim, name_prefix
+        self.channels = {str(2 ** i): hidden_dim for i in range(2, 11)}
+        self.module_name_list = []
+        self.style_dim_dict = {}
+        _out = input_dim
+        network, to_rgbs = OrderedDict(), OrderedDict()
+        for name, channel in self.channels.items():
+            _in, _out = _out, channel
+            blk = SinBlock(in_dim=_in, out_dim=_out, style_dim=style_dim, name_prefix=f'{name_prefix}_w{name}')
+            self.style_dim_dict.update(blk.style_dim_dict)
+            network[name] = blk
+            to_rgbs[name] = ToRGB(in_dim=_out, dim_rgb=pre_rgb_dim, use_equal_fc=False)
+        self.network = nn.ModuleDict(network)
+        self.to_rgbs = nn.ModuleDict(to_rgbs)
+        self.to_rgbs.apply(frequency_init(100))
+        self.module_name_list += ['network', 'to_rgbs']
+        self.tanh = nn.Sequential(nn.Tanh())
+        self.module_name_list.append('tanh')
+
+    def forward(self, input, style_dict, img_size=1024, **kwargs):
+        img_size = str(2 ** int(np.log2(img_size)))
+        names = []
+        for name in self.network.keys():
+            names.append(name)
+            if name == img_size:
+                break
+        params = []
+        for name in names:
+            blk = self.network[name]
+            s1 = blk.mod1.modulation(style_dict[f'{blk.name_prefix}_0'])
+            s2 = blk.mod2.modulation(style_dict[f'{blk.name_prefix}_1'])
+            params += [blk.mod1.weight[0], s1, blk.mod2.weight[0], s2]
+        for idx, name in enumerate(names):
+            if idx >= 3:
+                params += [self.to_rgbs[name].linear.weight, self.to_rgbs[name].linear.bias]
+        rgb = ops.InrHeadFunction.apply(len(names), input, *params)
+        return self.tanh(rgb)
+
+
+class _ToRGBFunction(torch.autograd.Function):
+    """y (M,3) = x (M,K) @ w^T + b on the HIP ToRGB kernels (used for the aux 32->3 head)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.detach().contiguous().view(-1, x.shape[-1])
+        w, b = w.detach().contiguous(), b.detach().contiguous()
+        y = torch.empty(x2.shape[0], 3, device=x.device)
+        ops.torgb_fwd(x2, w, b, y, accumulate=False)
+        ctx.save_for_backward(x2, w)
+        ctx.shape = x.shape
+        return y.view(*x.shape[:-1], 3)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, 3)
+        dw, db = ops.torgb_bwd_w(x2, dy2)
+        dx = torch.empty_like(x2)
+        ops.torgb_bwd_x(dy2, w, None, None, None, dx)
+        return dx.view(ctx.shape), dw, db
+
+
+# ------------------------------------------------------------------------------------------
+# camera helpers (O(batch) host-side math; comm_utils.py:451-581)
+# ------------------------------------------------------------------------------------------
+def _normalize(v):
+    return v / torch.norm(v, dim=-1, keepdim=True)
+
+
+def camera_origin_from_angles(theta, phi, r=1.0):
+    """comm_utils.py:527-535 (phi already drawn; clamp + spherical -> cartesian)."""
+    phi = torch.clamp(phi, 1e-5, math.pi - 1e-5)
+    out = torch.zeros((theta.shape[0], 3), device=theta.device)
+    out[:, 0:1] = r * torch.sin(phi) * torch.cos(theta)
+    out[:, 2:3] = r * torch.sin(phi) * torch.sin(theta)
+    out[:, 1:2] = r * torch.cos(phi)
+    return out, phi
+
+
+def create_cam2world_matrix(forward_vector, origin, up_vector=None):
+    """comm_utils.py:538-581"""
+    device = origin.device
+    forward_vector = _normalize(forward_vector)
+    if up_vector is None:
+        up_vector = torch.tensor([0, 1, 0], dtype=torch.float, device=device).expand_as(forward_vector)
+    left_vector = _normalize(torch.cross(up_vector, forward_vector, dim=-1))
+    up_vector = _normalize(torch.cross(forward_vector, left_vector, dim=-1))
+    rot = torch.eye(4, device=device).unsqueeze(0).repeat(forward_vector.shape[0], 1, 1)
+    rot[:, :3, :3] = torch.stack((-left_vector, up_vector, -forward_vector), axis=-1)
+    trans = torch.eye(4, device=device).unsqueeze(0).repeat(forward_vector.shape[0], 1, 1)
+    trans[:, :3, 3] = origin
+    return trans @ rot
+
+
+# ------------------------------------------------------------------------------------------
+# generator
+# ------------------------------------------------------------------------------------------
+class GeneratorNerfINR(nn.Module):
+    """Drop-in for exp.cips3d.models.generator.GeneratorNerfINR."""
+
+    def __init__(self, z_dim, nerf_cfg, mapping_nerf_cfg, inr_cfg, mapping_inr_cfg, device='cuda', **kwargs):
+        super().__init__()
+        self.epoch = 0
+        self.step = 0
+        self.z_dim = z_dim
+        self.device = device
+        self.module_name_list = []
+        self.siren = NeRFNetwork(**nerf_cfg)
+        self.module_name_list.append('siren')
+        self.mapping_network_nerf = MultiHeadMappingNetwork(
+            **{**mapping_nerf_cfg, 'head_dim_dict': self.siren.style_dim_dict})
+        self.module_name_list.append('mapping_network_nerf')
+        self.inr_net = CIPSNet(**{**inr_cfg, "input_dim": self.siren.rgb_dim})
+        self.module_name_list.append('inr_net')
+        self.mapping_network_inr = MultiHeadMappingNetwork(
+            **{**mapping_inr_cfg, 'head_dim_dict': self.inr_net.style_dim_dict})
+        self.module_name_list.append('mapping_network_inr')
+        self.aux_to_rbg = nn.Sequential(nn.Linear(self.siren.rgb_dim, 3), nn.Tanh())
+        self.aux_to_rbg.apply(frequency_init(25))
+        self.module_name_list.append('aux_to_rbg')
+        self.filters = nn.Identity()
+
+    # ---- latent / style plumbing (generator.py:1764-1826) ----
+    def z_sampler(self, shape, device, dist='gaussian'):
+        if dist == 'gaussian':
+            return torch.randn(shape, device=device)
+        return torch.rand(shape, device=device) * 2 - 1
+
+    def get_zs(self, b, batch_split=1):
+        z_nerf = self.z_sampler(shape=(b, self.mapping_network_nerf.z_dim), device=self.device)
+        z_inr = self.z_sampler(shape=(b, self.mapping_network_inr.z_dim), device=self.device)
+        if batch_split > 1:
+            return [{'z_nerf': a, 'z_inr': c} for a, c in
+                    zip(z_nerf.split(b // batch_split), z_inr.split(b // batch_split))]
+        return {'z_nerf': z_nerf, 'z_inr': z_inr}
+
+    def mapping_network(self, z_nerf, z_inr):
+        style_dict = {}
+        style_dict.update(self.mapping_network_nerf(z_nerf))
+        style_dict.update(self.mapping_network_inr(z_inr))
+        return style_dict
+
+    def generate_avg_frequencies(self, num_samples=10000, device='cuda'):
+        zs = self.get_zs(num_samples)
+        with torch.no_grad():
+            style_dict = self.mapping_network(**zs)
+        self.avg_styles = {name: style.mean(0, keepdim=True) for name, style in style_dict.items()}
+        return self.avg_styles
+
+    def get_truncated_freq_phase(self, raw_style_dict, avg_style_dict, raw_lambda):
+        """generator_nerf_inr.py:770-782"""
+        return {name: avg_style_dict[name].lerp(raw, raw_lambda) for name, raw in raw_style_dict.items()}
+
+    def set_device(self, device):
+        pass
+
+    def staged_forward(self, *args, **kwargs):
+        raise NotImplementedError
+
+    # ---- the hot path ----
+    def _nerf_styles(self, style_dict):
+        return style_dict
+
+    def _render(self, style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean,
+                v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise, white_back, last_back,
+                return_aux_img, forward_points=None, camera_pos=None, camera_lookup=None, up_vector=None,
+                nerf_grad=True, rand_override=None):
+        """whole_grad_forward + points_forward (generator.py:1378-1534, 1659-1762) on the HIP path.
+
+        Random tensors are drawn with the reference's calls, shapes and order
+        so that a same-device, same-seed run consumes the generator identically; `rand_override`
+        (dict with any of jitter/theta/phi/noise_c/u/noise_f) injects fixed draws for parity tests.
+        With `forward_points` the reference evaluates image by image in chunks under no_grad; the
+        fused kernels need no chunking, so only the per-image/per-chunk draw order is reproduced."""
+        ro = rand_override or {}
+        device = next(self.parameters()).device
+        b = list(style_dict.values())[0].shape[0]
+        H = W = img_size
+        n = H * W
+        S = num_steps
+        E = 2 * S if hierarchical_sample else S
+        clamp = ops._CLAMP[clamp_mode]
+        flags = (1 if last_back else 0) | (2 if white_back else 0)
+        staged = forward_points is not None
+
+        # ---------------- random draws in reference order ----------------
+        def draw(kind, fn, shape):
+            t = fn(shape, device=device)
+            return ro[kind].to(device).reshape(shape).float() if kind in ro else t
+
+        need_cam = camera_pos is None or camera_lookup is None
+        mode = sample_dist
+        if need_cam and mode not in ('gaussian', 'normal', 'uniform', 'mean', None):
+            raise NotImplementedError(f"camera sample_dist {mode!r}")
+
+        def draw_cam(bs):
+            if mode == 'uniform':
+                th = (draw('theta', torch.rand, (bs, 1)) - 0.5) * 2 * h_stddev + h_mean
+                ph = (draw('phi', torch.rand, (bs, 1)) - 0.5) * 2 * v_stddev + v_mean
+            elif mode == 'mean':
+                th = torch.ones((bs, 1), device=device) * h_mean
+                ph = torch.ones((bs, 1), device=device) * v_mean
+            else:
+                th = draw('theta', torch.randn, (bs, 1)) * h_stddev + h_mean
+                ph = draw('phi', torch.randn, (bs, 1)) * v_stddev + v_mean
+            return th, ph
+
+        if not staged:
+            jitter = draw('jitter', torch.rand, (b, n, S, 1))
+            theta, phi = draw_cam(b) if need_cam else (None, None)
+            noise_c = draw('noise_c', torch.randn, (b, n, S, 1)) if hierarchical_sample else None
+            u = draw('u', torch.rand, (b * n, S)) if hierarchical_sample else None
+            noise_f = draw('noise_f', torch.randn, (b, n, E, 1))
+        else:
+            js, ths, phs, ncs, us, nfs = [], [], [], [], [], []
+            for _ in range(b):
+                js.append(torch.rand((1, n, S, 1), device=device))
+                if need_cam:
+                    th, ph = draw_cam(1)
+                    ths.append(th); phs.append(ph)
+                head = 0
+                while head < n:
+                    c = min(forward_points, n - head)
+                    if hierarchical_sample:
+                        ncs.append(torch.randn((1, c, S, 1), device=device))
+                        us.append(torch.rand((c, S), device=device))
+                    nfs.append(torch.randn((1, c, E, 1), device=device))
+                    head += forward_points
+            jitter = ro.get('jitter', torch.cat(js, 0))
+            theta = ro.get('theta', torch.cat(ths, 0)) if need_cam else None
+            phi = ro.get('phi', torch.cat(phs, 0)) if need_cam else None
+            noise_c = ro.get('noise_c', torch.cat(ncs, 1).view(b, n, S, 1)) if hierarchical_sample else None
+            u = ro.get('u', torch.cat(us, 0)) if hierarchical_sample else None
+            noise_f = ro.get('noise_f', torch.cat(nfs, 1).view(b, n, E, 1))
+
+        # ---------------- camera (O(b) host math) ----------------
+        with torch.no_grad():
+            if need_cam:
+                origin, pitch = camera_origin_from_angles(theta, phi)
+                yaw = theta
+                forward_vector = _normalize(-origin)
+            else:
+                origin = camera_pos
+                pitch = yaw = torch.zeros(b, 1, device=device)
+                forward_vector = _normalize(camera_lookup)
+            cam2world = create_cam2world_matrix(forward_vector, origin, up_vector=up_vector)
+            xg = torch.linspace(-1, 1, W, device=device)
+            yg = torch.linspace(1, -1, H, device=device)
+            zg = torch.linspace(ray_start, ray_end, S, device=device)
+            zc = float((-torch.ones(1) / np.tan((2 * math.pi * fov / 360) / 2)).item())
+            points, z_vals, dirs = ops.rays_fwd(xg, yg, zg, zc, cam2world, jitter.reshape(b, n, S), b, H, W, S)
+            ray_origins = cam2world[:, :3, 3].contiguous()       # every ray starts at the camera
+
+        nerf_styles = self._nerf_styles(style_dict)
+        ctx_nerf = torch.enable_grad() if nerf_grad else torch.no_grad()
+        with ctx_nerf:
+            feat_c, sig_c = self.siren.evaluate(points.view(b, n * S, 3), nerf_styles)
+            feat_c = feat_c.view(b * n, S, 32)
+            sig_c = sig_c.view(b * n, S)
+            z_c = z_vals.view(b * n, S)
+            if hierarchical_sample:
+                with torch.no_grad():
+                    fine_z, fine_pts = ops.resample_fwd(
+                        sig_c, z_c, noise_c.reshape(b * n, S) if nerf_noise != 0 else None, nerf_noise,
+                        u, ray_origins, dirs.view(b * n, 3), b, n, S, clamp)
+                feat_f, sig_f = self.siren.evaluate(fine_pts.view(b, n * S, 3), nerf_styles)
+                feat_f = feat_f.view(b * n, S, 32)
+                sig_f = sig_f.view(b * n, S)
+            else:
+                feat_f = sig_f = fine_z = None
+            pixels_fea, depth, weights, order, zsorted = ops.CompositeFunction.apply(
+                feat_c, sig_c, z_c, feat_f, sig_f, fine_z,
+                noise_f.reshape(b * n, E) if nerf_noise != 0 else None, nerf_noise, clamp, flags)
+            pixels_fea = pixels_fea.view(b, n, 32)
+            if return_aux_img:
+                aux_img = torch.tanh(_ToRGBFunction.apply(pixels_fea, self.aux_to_rbg[0].weight,
+                                                          self.aux_to_rbg[0].bias))
+            else:
+                aux_img = None
+        if not nerf_grad:
+            pixels_fea = pixels_fea.detach()
+        inr_img = self.inr_net(pixels_fea, style_dict)
+
+        inr_img = inr_img.view(b, H, W, 3).permute(0, 3, 1, 2)
+        inr_img = self.filters(inr_img)
+        pitch_yaw = torch.cat([pitch, yaw], -1)
+        if return_aux_img:
+            aux_img = aux_img.view(b, H, W, 3).permute(0, 3, 1, 2)
+            imgs = torch.cat([inr_img, aux_img])
+            pitch_yaw = torch.cat([pitch_yaw, pitch_yaw])
+        else:
+            imgs = inr_img.contiguous()
+        return imgs, pitch_yaw
+
+    def forward(self, zs, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, hierarchical_sample,
+                h_mean=math.pi * 0.5, v_mean=math.pi * 0.5, psi=1, sample_dist=None, lock_view_dependence=False,
+                clamp_mode='relu', nerf_noise=0., white_back=False, last_back=False, return_aux_img=False,
+                grad_points=None, forward_points=None, **kwargs):
+        """generator.py:1256-1370.  Returns (imgs (b or 2b,3,H,W), pitch_yaw (b or 2b,2))."""
+        style_dict = self.mapping_network(**zs)
+        if psi < 1:
+            avg_styles = self.generate_avg_frequencies(device=self.device)
+            style_dict = self.get_truncated_freq_phase(raw_style_dict=style_dict, avg_style_dict=avg_styles,
+                                                       raw_lambda=psi)
+        if grad_points is not None and grad_points < img_size ** 2:
+            raise NotImplementedError(
+                "part_grad_forward (random pixel subset with gradients, generator.py:1536-1657) is only "
+                "reachable for img_size > 256 with the shipped configs and is not built yet")
+        return self._forward_styles(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                                    h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise,
+                                    white_back, last_back, return_aux_img, forward_points,
+                                    rand_override=kwargs.get('rand_override'))
+
+    def _forward_styles(self, style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                        h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise, white_back,
+                        last_back, return_aux_img, forward_points, rand_override=None, **cam):
+        if forward_points is not None:
+            with torch.no_grad():
+                return self._render(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                                    h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise,
+                                    white_back, last_back, return_aux_img, forward_points=forward_points,
+                                    rand_override=rand_override, **cam)
+        return self._render(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean,
+                            v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise, white_back, last_back,
+                            return_aux_img, rand_override=rand_override, **cam)
+
+    def forward_camera_pos_and_lookup(self, zs, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                                      h_mean, v_mean, hierarchical_sample, camera_pos, camera_lookup, psi=1,
+                                      sample_dist=None, lock_view_dependence=False, clamp_mode='relu',
+                                      nerf_noise=0., white_back=False, last_back=False, return_aux_img=False,
+                                      grad_points=None, forward_points=None, up_vector=None, **kwargs):
+        """generator.py:1828-1951 (explicit camera; pitch/yaw are zeros)."""
+        style_dict = self.mapping_network(**zs)
+        if psi < 1:
+            avg_styles = self.generate_avg_frequencies(device=self.device)
+            style_dict = self.get_truncated_freq_phase(raw_style_dict=style_dict, avg_style_dict=avg_styles,
+                                                       raw_lambda=psi)
+        if grad_points is not None and grad_points < img_size ** 2:
+            raise NotImplementedError("part_grad_forward is not built yet")
+        return self._forward_styles(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                                    h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise,
+                                    white_back, last_back, return_aux_img, forward_points,
+                                    rand_override=kwargs.get('rand_override'),
+                                    camera_pos=camera_pos, camera_lookup=camera_lookup, up_vector=up_vector)
+
+
+class GeneratorNerfINR_freeze_NeRF(GeneratorNerfINR):
+    """generator.py:1955-2083: mapping_nerf, both SIREN passes, the composite and aux_to_rbg run
+    under no_grad; gradients flow only through the CIPS INR head and mapping_inr."""
+
+    def load_nerf_ema(self, G_ema):
+        self.siren.load_state_dict(G_ema.siren.state_dict())
+        self.mapping_network_nerf.load_state_dict(G_ema.mapping_network_nerf.state_dict())
+        self.aux_to_rbg.load_state_dict(G_ema.aux_to_rbg.state_dict())
+
+    def mapping_network(self, z_nerf, z_inr):
+        style_dict = {}
+        with torch.no_grad():
+            style_dict.update(self.mapping_network_nerf(z_nerf))
+        style_dict.update(self.mapping_network_inr(z_inr))
+        return style_dict
+
+    def _render(self, *args, **kwargs):
+        kwargs['nerf_grad'] = False
+        return super()._render(*args, **kwargs)

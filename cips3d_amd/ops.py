@@ -1,0 +1,504 @@
+"""Host-side operators over the C-ABI (include/cips3d_hip.h): thin launch wrappers plus the
+torch.autograd.Functions that give the reference's Python API its backward.
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; every arithmetic
+kernel on the hot path is a hand-written HIP kernel in libcips3d_hip.so.  There is no CPU
+fallback: tensors must live on a ROCm device and the extension must be built.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, SirenWeights, check
+
+LRELU_SLOPE = 0.2
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("cips3d_amd ops need tensors on the GPU (no CPU fallback)")
+        if t.dtype != torch.float32 and t.dtype not in (torch.int32, torch.int64):
+            raise RuntimeError(f"cips3d_amd ops are fp32 (got {t.dtype})")
+        if not t.is_contiguous():
+            raise RuntimeError("cips3d_amd ops need contiguous tensors")
+
+
+def _c(t):
+    return t.contiguous().float() if t is not None else None
+
+
+# --------------------------------------------------------------------------------------
+# H1 rays
+# --------------------------------------------------------------------------------------
+def rays_fwd(xg, yg, zg, zc, cam2world, jitter, B, H, W, S):
+    """-> points (B,n,S,3), z (B,n,S), dirs (B,n,3); see cips_rays_fwd."""
+    lib = _lib.load()
+    dev = cam2world.device
+    n = H * W
+    points = torch.empty(B, n, S, 3, device=dev)
+    z = torch.empty(B, n, S, device=dev)
+    dirs = torch.empty(B, n, 3, device=dev)
+    xg, yg, zg, cam2world, jitter = _c(xg), _c(yg), _c(zg), _c(cam2world), _c(jitter)
+    _chk(xg, yg, zg, cam2world, jitter)
+    check(lib.cips_rays_fwd(_p(xg), _p(yg), _p(zg), float(zc), _p(cam2world), _p(jitter),
+                            _p(points), _p(z), _p(dirs), B, H, W, S, _stream()), "cips_rays_fwd")
+    return points, z, dirs
+
+
+# --------------------------------------------------------------------------------------
+# generic GEMM
+# --------------------------------------------------------------------------------------
+def gemm(A, Bm, Cm, M, N, K, lda, ldb, ldc, batch=1, strideA=0, strideB=0, strideC=0,
+         a_kmajor=False, b_nmajor=False, alpha=1.0, bias=None, bias_m=None, act=0, slope=LRELU_SLOPE,
+         act_gain=1.0, resid=None, C2=None, add=None, rgb_g=None, rgb_w=None, C_unmasked=None, mask=None):
+    lib = _lib.load()
+    d = GemmDesc()
+    d.A, d.B, d.C = _p(A), _p(Bm), _p(Cm)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.strideA, d.strideB, d.strideC = strideA, strideB, strideC
+    d.batch = batch
+    d.a_kmajor = 1 if a_kmajor else 0
+    d.b_nmajor = 1 if b_nmajor else 0
+    d.alpha = alpha
+    d.bias, d.bias_m = _p(bias), _p(bias_m)
+    d.act, d.slope, d.act_gain = act, slope, act_gain
+    d.resid, d.C2, d.add = _p(resid), _p(C2), _p(add)
+    d.rgb_g, d.rgb_w = _p(rgb_g), _p(rgb_w)
+    d.C_unmasked, d.mask = _p(C_unmasked), _p(mask)
+    check(lib.cips_gemm_f32(C.byref(d), _stream()), "cips_gemm_f32")
+    return Cm
+
+
+def bmm_nn(x, w, out=None, **epi):
+    """out[b] (M,N) = x[b] (M,K) @ w[b] (K,N); x (B,M,K), w (B,K,N) contiguous."""
+    B, M, K = x.shape
+    N = w.shape[-1]
+    if out is None:
+        out = torch.empty(B, M, N, device=x.device)
+    gemm(x, w, out, M, N, K, K, N, N, batch=B, strideA=M * K, strideB=K * N, strideC=M * N, **epi)
+    return out
+
+
+def bmm_tn(a, b, out=None):
+    """out[b] (Ma,N) = a[b]^T @ b[b]; a (B,K,Ma), b (B,K,N)."""
+    B, K, Ma = a.shape
+    N = b.shape[-1]
+    if out is None:
+        out = torch.empty(B, Ma, N, device=a.device)
+    gemm(a, b, out, Ma, N, K, Ma, N, N, batch=B, strideA=K * Ma, strideB=K * N, strideC=Ma * N, a_kmajor=True)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# H2 SIREN
+# --------------------------------------------------------------------------------------
+_SIREN_NAMES = ("w0", "b0", "w1", "b1", "ws", "bs", "wc", "bc", "wf", "bf", "g0", "p0", "g1", "p1", "gc", "pc")
+BOX_SCALE = 2.0 / 0.24   # UniformBoxWarp(0.24), generator.py:249
+TRIG_MODE = 0            # 0 polynomial (default), 1 hardware v_sin/v_cos
+
+
+def _siren_struct(t):
+    s = SirenWeights()
+    for n in _SIREN_NAMES:
+        setattr(s, n, _p(t[n]))
+    s.box_scale = BOX_SCALE
+    s.trig_mode = TRIG_MODE
+    return s
+
+
+def _split_k(P, target=8):
+    """Largest split count <= target such that P/split is a multiple of 32."""
+    for s in range(target, 0, -1):
+        if P % s == 0 and (P // s) % 32 == 0:
+            return s
+    return 1
+
+
+class SirenFunction(torch.autograd.Function):
+    """feat (B,P,32), sigma (B,P) = siren(points; weights, per-image FiLM vectors).
+
+    Mirrors NeRFNetwork.forward_with_frequencies_phase_shifts (generator.py:260-317); gains g*
+    are already 15*gain_fc(style)+30 and phases p* = bias_fc(style) (film_layer.py:88-93), both
+    computed by tiny torch Linears on the host side so autograd carries them to the mapping net.
+    No gradient w.r.t. points (the reference never needs it: points come from no_grad ray math).
+    """
+
+    @staticmethod
+    def forward(ctx, points, g0, p0, g1, p1, gc, pc, w0, b0, w1, b1, ws, bs, wc, bc, wf, bf):
+        lib = _lib.load()
+        t = dict(w0=w0, b0=b0, w1=w1, b1=b1, ws=ws, bs=bs, wc=wc, bc=bc, wf=wf, bf=bf,
+                 g0=g0, p0=p0, g1=g1, p1=p1, gc=gc, pc=pc)
+        t = {k: _c(v.detach()) for k, v in t.items()}
+        points = _c(points.detach())
+        _chk(points, *t.values())
+        B, P, _ = points.shape
+        feat = torch.empty(B, P, 32, device=points.device)
+        sigma = torch.empty(B, P, device=points.device)
+        sw = _siren_struct(t)
+        check(lib.cips_siren_fwd(C.byref(sw), _p(points), _p(feat), _p(sigma), B, P, _stream()), "cips_siren_fwd")
+        ctx.save_for_backward(points, *[t[n] for n in _SIREN_NAMES])
+        return feat, sigma
+
+    @staticmethod
+    def backward(ctx, dfeat, dsigma):
+        lib = _lib.load()
+        points = ctx.saved_tensors[0]
+        t = dict(zip(_SIREN_NAMES, ctx.saved_tensors[1:]))
+        B, P, _ = points.shape
+        dev = points.device
+        dfeat = _c(dfeat) if dfeat is not None else torch.zeros(B, P, 32, device=dev)
+        dsigma = _c(dsigma) if dsigma is not None else torch.zeros(B, P, device=dev)
+        BP = B * P
+        h1 = torch.empty(BP, 128, device=dev)
+        h2 = torch.empty(BP, 128, device=dev)
+        hc = torch.empty(BP, 64, device=dev)
+        da2 = torch.empty(BP, 128, device=dev)
+        dac = torch.empty(BP, 64, device=dev)
+        rows = lib.cips_siren_bwd_rows(B, P)
+        red = torch.empty(rows, 868, device=dev)
+        sw = _siren_struct(t)
+        check(lib.cips_siren_bwd_data(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(h1), _p(h2), _p(hc),
+                                      _p(da2), _p(dac), _p(red), B, P, _stream()), "cips_siren_bwd_data")
+        R = red.view(B, rows // B, 868).sum(1)          # (B, 868) deterministic reduction of partial rows
+        # weight-gradient contractions over the points (K = P per image, split-K)
+        sp = _split_k(P)
+        Kc = P // sp
+        G1 = torch.empty(B * sp, 128, 128, device=dev)   # da2^T @ h1
+        gemm(da2, h1, G1, 128, 128, Kc, 128, 128, 128, batch=B * sp, strideA=Kc * 128, strideB=Kc * 128,
+             strideC=128 * 128, a_kmajor=True)
+        G1 = G1.view(B, sp, 128, 128).sum(1)
+        Gc = torch.empty(B * sp, 64, 128, device=dev)    # dac^T @ h2
+        gemm(dac, h2, Gc, 64, 128, Kc, 64, 128, 128, batch=B * sp, strideA=Kc * 64, strideB=Kc * 128,
+             strideC=64 * 128, a_kmajor=True)
+        Gc = Gc.view(B, sp, 64, 128).sum(1)
+        spf = _split_k(BP, 64)
+        Kf = BP // spf
+        Gf = torch.empty(spf, 32, 64, device=dev)        # dfeat^T @ hc (no per-image scale)
+        gemm(dfeat, hc, Gf, 32, 64, Kf, 32, 64, 64, batch=spf, strideA=Kf * 32, strideB=Kf * 64,
+             strideC=32 * 64, a_kmajor=True)
+        dwf = Gf.sum(0)
+        # ---- assemble parameter / FiLM gradients (tiny tensors) ----
+        g0, g1, gc = t["g0"], t["g1"], t["gc"]
+        w0, b0, w1, b1, wc, bc = t["w0"], t["b0"], t["w1"], t["b1"], t["wc"], t["bc"]
+        dp0 = R[:, 0:128]
+        S0 = R[:, 128:512].view(B, 3, 128).transpose(1, 2) * BOX_SCALE   # (B,128,3): sum_p da1 * x0_c
+        dg0 = (S0 * w0.unsqueeze(0)).sum(-1) + b0.unsqueeze(0) * dp0
+        dw0 = (g0.unsqueeze(-1) * S0).sum(0)
+        db0 = (g0 * dp0).sum(0)
+        dp1 = R[:, 512:640]
+        dg1 = (G1 * w1.unsqueeze(0)).sum(-1) + b1.unsqueeze(0) * dp1
+        dw1 = (g1.unsqueeze(-1) * G1).sum(0)
+        db1 = (g1 * dp1).sum(0)
+        dpc = R[:, 640:704]
+        dgc = (Gc * wc.unsqueeze(0)).sum(-1) + bc.unsqueeze(0) * dpc
+        dwc = (gc.unsqueeze(-1) * Gc).sum(0)
+        dbc = (gc * dpc).sum(0)
+        dws = R[:, 704:832].sum(0, keepdim=True)
+        dbf = R[:, 832:864].sum(0)
+        dbs = R[:, 864].sum().view(1)
+        return (None, dg0, dp0, dg1, dp1, dgc, dpc, dw0, db0, dw1, db1, dws, dbs, dwc, dbc, dwf, dbf)
+
+
+# --------------------------------------------------------------------------------------
+# H3 resample / composite
+# --------------------------------------------------------------------------------------
+def resample_fwd(sigma, z, noise, noise_std, u, origins, dirs, B, n, S, clamp_mode=0, debug=False):
+    """sigma/z/noise/u (B*n,S) -> fine_z (B*n,S), fine_pts (B*n,S,3) [+ weights, cdf, inds]."""
+    lib = _lib.load()
+    dev = sigma.device
+    sigma, z, noise, u, origins, dirs = _c(sigma), _c(z), _c(noise), _c(u), _c(origins), _c(dirs)
+    _chk(sigma, z, noise, u, origins, dirs)
+    R = B * n
+    fine_z = torch.empty(R, S, device=dev)
+    fine_pts = torch.empty(R, S, 3, device=dev)
+    w = cdf = inds = None
+    if debug:
+        w = torch.empty(R, S, device=dev)
+        cdf = torch.empty(R, S - 1, device=dev)
+        inds = torch.empty(R, S, device=dev, dtype=torch.int64)
+    check(lib.cips_resample_fwd(_p(sigma), _p(z), _p(noise), float(noise_std), _p(u), _p(origins), _p(dirs),
+                                _p(fine_z), _p(fine_pts), _p(w), _p(cdf), _p(inds), B, n, S, clamp_mode,
+                                _stream()), "cips_resample_fwd")
+    if debug:
+        return fine_z, fine_pts, w, cdf, inds
+    return fine_z, fine_pts
+
+
+_CLAMP = {"relu": 0, "softplus": 1}
+
+
+class CompositeFunction(torch.autograd.Function):
+    """Merge (optional) + alpha-composite; see cips_composite_fwd / _bwd.
+    Inputs are flattened over rays: feat (R,S,32), sig (R,S), z (R,S); fine set may be None."""
+
+    @staticmethod
+    def forward(ctx, feat_c, sig_c, z_c, feat_f, sig_f, z_f, noise, noise_std, clamp_mode, flags):
+        lib = _lib.load()
+        feat_c, sig_c, z_c = _c(feat_c.detach()), _c(sig_c.detach()), _c(z_c.detach())
+        hier = feat_f is not None
+        if hier:
+            feat_f, sig_f, z_f = _c(feat_f.detach()), _c(sig_f.detach()), _c(z_f.detach())
+        noise = _c(noise) if (noise is not None and noise_std != 0.0) else None
+        _chk(feat_c, sig_c, z_c, feat_f, sig_f, z_f, noise)
+        R, S, _ = feat_c.shape
+        E = 2 * S if hier else S
+        dev = feat_c.device
+        fea = torch.empty(R, 32, device=dev)
+        depth = torch.empty(R, device=dev)
+        weights = torch.empty(R, E, device=dev)
+        order = torch.empty(R, E, device=dev, dtype=torch.int32)
+        zs = torch.empty(R, E, device=dev)
+        check(lib.cips_composite_fwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
+                                     float(noise_std), _p(fea), _p(depth), _p(weights), _p(order), _p(zs),
+                                     R, S, clamp_mode, flags, _stream()), "cips_composite_fwd")
+        ctx.save_for_backward(feat_c, sig_c, z_c, feat_f, sig_f, z_f, noise, order)
+        ctx.meta = (float(noise_std), clamp_mode, flags, hier)
+        ctx.mark_non_differentiable(depth, weights, order, zs)
+        return fea, depth, weights, order, zs
+
+    @staticmethod
+    def backward(ctx, dfea, *unused):
+        lib = _lib.load()
+        feat_c, sig_c, z_c, feat_f, sig_f, z_f, noise, order = ctx.saved_tensors
+        noise_std, clamp_mode, flags, hier = ctx.meta
+        R, S, _ = feat_c.shape
+        dfea = _c(dfea)
+        dfeat_c = torch.empty_like(feat_c)
+        dsig_c = torch.empty_like(sig_c)
+        dfeat_f = torch.empty_like(feat_f) if hier else None
+        dsig_f = torch.empty_like(sig_f) if hier else None
+        check(lib.cips_composite_bwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
+                                     noise_std, _p(order), _p(dfea), _p(dfeat_c), _p(dsig_c), _p(dfeat_f),
+                                     _p(dsig_f), R, S, clamp_mode, flags, _stream()), "cips_composite_bwd")
+        return dfeat_c, dsig_c, None, dfeat_f, dsig_f, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------
+# H4 CIPS INR head (all blocks of CIPSNet.forward in one autograd node)
+# --------------------------------------------------------------------------------------
+def modfc_prep(W, s, eps=1e-8):
+    lib = _lib.load()
+    in_dim, out_dim = W.shape
+    B = s.shape[0]
+    dev = W.device
+    wb = torch.empty(B, in_dim, out_dim, device=dev)
+    wbt = torch.empty(B, out_dim, in_dim, device=dev)
+    demod = torch.empty(B, out_dim, device=dev)
+    check(lib.cips_modfc_prep(_p(W), _p(s), _p(wb), _p(wbt), _p(demod), B, in_dim, out_dim, eps, _stream()),
+          "cips_modfc_prep")
+    return wb, wbt, demod
+
+
+def modfc_prep_bwd(W, s, demod, gwb):
+    lib = _lib.load()
+    in_dim, out_dim = W.shape
+    B = s.shape[0]
+    dev = W.device
+    cbuf = torch.empty(B, out_dim, device=dev)
+    dW = torch.empty(in_dim, out_dim, device=dev)
+    ds = torch.empty(B, in_dim, device=dev)
+    check(lib.cips_modfc_prep_bwd(_p(W), _p(s), _p(demod), _p(gwb), _p(cbuf), _p(dW), _p(ds), B, in_dim, out_dim,
+                                  _stream()), "cips_modfc_prep_bwd")
+    return dW, ds
+
+
+def torgb_fwd(x2d, w, b, rgb2d, accumulate):
+    lib = _lib.load()
+    M, K = x2d.shape
+    check(lib.cips_torgb_fwd(_p(x2d), _p(w), _p(b), _p(rgb2d), M, K, 1 if accumulate else 0, _stream()),
+          "cips_torgb_fwd")
+
+
+def torgb_bwd_w(x2d, drgb2d):
+    lib = _lib.load()
+    M, K = x2d.shape
+    chunks = lib.cips_torgb_bwd_partials(M)
+    part = torch.empty(chunks, 4, K, device=x2d.device)
+    dw = torch.empty(3, K, device=x2d.device)
+    db = torch.empty(3, device=x2d.device)
+    check(lib.cips_torgb_bwd_w(_p(x2d), _p(drgb2d), _p(part), _p(dw), _p(db), M, K, _stream()), "cips_torgb_bwd_w")
+    return dw, db
+
+
+def torgb_bwd_x(drgb2d, w, add, mask, out_unmasked, out):
+    lib = _lib.load()
+    M = drgb2d.shape[0]
+    K = w.shape[1]
+    check(lib.cips_torgb_bwd_x(_p(drgb2d), _p(w), _p(add), _p(mask), LRELU_SLOPE, _p(out_unmasked), _p(out), M, K,
+                               _stream()), "cips_torgb_bwd_x")
+
+
+class InrHeadFunction(torch.autograd.Function):
+    """rgb_pre (B,n,3) = CIPSNet body (generator.py:1107-1153, before the final tanh).
+
+    args: x0 (B,n,in0); then per block k (nblocks of them): W1 (in,out), s1 (B,in), W2 (out,out),
+    s2 (B,out); then per block with a ToRGB (k >= 3): T (3,out), tau (3).
+    s* = SinStyleMod.modulation(style) (mod_conv_fc.py:474) computed on the host side.
+    Blocks k >= 4 use the skip connection (generator.py:1128, 971-973)."""
+
+    @staticmethod
+    def forward(ctx, nblocks, x0, *params):
+        x0 = _c(x0.detach())
+        B, n, _ = x0.shape
+        dev = x0.device
+        blocks = []
+        for k in range(nblocks):
+            W1, s1, W2, s2 = [_c(p.detach()) for p in params[4 * k:4 * k + 4]]
+            blocks.append((W1, s1, W2, s2))
+        rgbp = [_c(p.detach()) for p in params[4 * nblocks:]]
+        _chk(x0, *[t for blk in blocks for t in blk], *rgbp)
+        saved = []
+        x = x0
+        rgb = torch.empty(B, n, 3, device=dev)
+        first_rgb = True
+        for k, (W1, s1, W2, s2) in enumerate(blocks):
+            skip = k >= 4
+            wb1, wbt1, d1 = modfc_prep(W1, s1)
+            a1 = bmm_nn(x, wb1, act=1)
+            wb2, wbt2, d2 = modfc_prep(W2, s2)
+            if skip and a1.shape[-1] == x.shape[-1]:
+                out = torch.empty_like(a1)
+                a2 = bmm_nn(a1, wb2, act=1, resid=x, C2=out)
+            else:
+                a2 = bmm_nn(a1, wb2, act=1)
+                out = a2
+            if k >= 3:
+                T, tau = rgbp[2 * (k - 3)], rgbp[2 * (k - 3) + 1]
+                torgb_fwd(out.view(B * n, -1), T, tau, rgb.view(B * n, 3), accumulate=not first_rgb)
+                first_rgb = False
+            saved.append((x, a1, a2, out, wbt1, d1, wbt2, d2))
+            x = out
+        if first_rgb:
+            rgb.zero_()
+        ctx.nblocks = nblocks
+        ctx.blocks = blocks
+        ctx.rgbp = rgbp
+        ctx.saved = saved
+        return rgb
+
+    @staticmethod
+    def backward(ctx, drgb):
+        nblocks, blocks, rgbp, saved = ctx.nblocks, ctx.blocks, ctx.rgbp, ctx.saved
+        drgb = _c(drgb)
+        B, n, _ = drgb.shape
+        dev = drgb.device
+        drgb2 = drgb.view(B * n, 3)
+        grads_blocks = [None] * nblocks
+        grads_rgb = [None] * len(rgbp)
+        width = saved[-1][3].shape[-1]
+        g2 = torch.empty(B, n, width, device=dev)
+        Dout = None     # unmasked grad wrt out_k (kept while block k has a skip)
+        dx0 = None
+        for k in range(nblocks - 1, -1, -1):
+            xin, a1, a2, out, wbt1, d1, wbt2, d2 = saved[k]
+            W1, s1, W2, s2 = blocks[k]
+            skip = (k >= 4) and (a1.shape[-1] == xin.shape[-1])
+            if k == nblocks - 1:
+                if k >= 3:
+                    T = rgbp[2 * (k - 3)]
+                    Dout = torch.empty(B, n, width, device=dev) if skip else None
+                    torgb_bwd_x(drgb2, T, None, a2, Dout, g2)
+                else:  # degenerate configuration (fewer than 4 blocks): no gradient reaches the head
+                    g2.zero_()
+                    Dout = torch.zeros(B, n, width, device=dev) if skip else None
+            if k >= 3:
+                dT, dtau = torgb_bwd_w(out.view(B * n, -1), drgb2)
+                grads_rgb[2 * (k - 3)], grads_rgb[2 * (k - 3) + 1] = dT, dtau
+            # ---- mod2: y2 = a1 @ wb2 ----
+            gwb2 = bmm_tn(a1, g2)                                  # (B, out, out) = a1^T @ g2
+            dW2, ds2 = modfc_prep_bwd(W2, s2, d2, gwb2)
+            g1 = bmm_nn(g2, wbt2, mask=a1)                         # dL/dy1 = (g2 @ wb2^T) * lrelu'(a1)
+            # ---- mod1: y1 = xin @ wb1 ----
+            gwb1 = bmm_tn(xin, g1)
+            dW1, ds1 = modfc_prep_bwd(W1, s1, d1, gwb1)
+            grads_blocks[k] = (dW1, ds1, dW2, ds2)
+            if k == 0:
+                dx0 = bmm_nn(g1, wbt1)
+            else:
+                # grad wrt out_{k-1} = dx1_k [+ Dout_k via skip] [+ drgb @ T_{k-1}], then the gate of a2_{k-1}
+                a2_prev = saved[k - 1][2]
+                prev_skip = (k - 1 >= 4) and (saved[k - 1][1].shape[-1] == saved[k - 1][0].shape[-1])
+                newD = torch.empty(B, n, width, device=dev) if prev_skip else None
+                epi = dict(mask=a2_prev, C_unmasked=newD)
+                if skip:
+                    epi["add"] = Dout
+                if k - 1 >= 3:
+                    epi["rgb_g"] = drgb2
+                    epi["rgb_w"] = rgbp[2 * (k - 1 - 3)]
+                g2 = bmm_nn(g1, wbt1, out=torch.empty(B, n, width, device=dev), **epi)
+                Dout = newD
+        flat = [None, dx0]
+        for gb in grads_blocks:
+            flat.extend(gb)
+        flat.extend(grads_rgb)
+        return tuple(flat)
+
+
+# --------------------------------------------------------------------------------------
+# H5 discriminator native ops (same contracts as the reference's pybind ops)
+# --------------------------------------------------------------------------------------
+def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
+    """fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale) -> Tensor
+    (exp/comm/op/fused_bias_act.cpp:11-21).  Empty tensor = absent."""
+    lib = _lib.load()
+    if not input.is_cuda:
+        raise RuntimeError("input must be a CUDA tensor")   # CHECK_CUDA, fused_bias_act.cpp:13
+    x = input.contiguous().float()
+    b = bias.contiguous().float() if (bias is not None and bias.numel()) else None
+    r = refer.contiguous().float() if (refer is not None and refer.numel()) else None
+    y = torch.empty_like(x)
+    step_b = 1
+    for i in range(2, x.dim()):
+        step_b *= x.size(i)
+    size_b = b.numel() if b is not None else 0
+    check(lib.cips_fused_bias_act(_p(x), _p(b), _p(r), _p(y), x.numel(), size_b, step_b, act, grad, float(alpha),
+                                  float(scale), _stream()), "cips_fused_bias_act")
+    return y
+
+
+def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """upfirdn2d_op.upfirdn2d(input[N,H,W,minor], kernel, ...) -> Tensor (exp/comm/op/upfirdn2d.cpp:12-23)."""
+    lib = _lib.load()
+    if not input.is_cuda:
+        raise RuntimeError("input must be a CUDA tensor")
+    x = input.contiguous().float()
+    k = kernel.contiguous().float()
+    major, in_h, in_w, minor = x.shape
+    kh, kw = k.shape
+    out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
+    out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
+    out = torch.empty(major, out_h, out_w, minor, device=x.device)
+    check(lib.cips_upfirdn2d(_p(x), _p(k), _p(out), major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y,
+                             pad_x0, pad_x1, pad_y0, pad_y1, _stream()), "cips_upfirdn2d")
+    return out
+
+
+def im2col(x, kh, kw, stride, pad):
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    col = torch.empty(B, Cc * kh * kw, Ho * Wo, device=x.device)
+    check(lib.cips_im2col(_p(x), _p(col), B, Cc, H, W, kh, kw, stride, pad, _stream()), "cips_im2col")
+    return col, Ho, Wo
+
+
+def col2im(col, B, Cc, H, W, kh, kw, stride, pad):
+    lib = _lib.load()
+    dx = torch.empty(B, Cc, H, W, device=col.device)
+    check(lib.cips_col2im(_p(col), _p(dx), B, Cc, H, W, kh, kw, stride, pad, _stream()), "cips_col2im")
+    return dx

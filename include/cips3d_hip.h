@@ -145,16 +145,18 @@ int cips_composite_bwd(const float* feat_c, const float* sig_c, const float* z_c
 /* the SIREN weight gradients, and H5 convolutions (im2col GEMM).       */
 /* ------------------------------------------------------------------ */
 typedef struct cips_gemm_desc {
-  /* C[b] (M,N) = epilogue( A[b] (M,K) @ B[b] (K,N) ) ; B always k-major (row-major K x N). */
+  /* C[b] (M,N) = epilogue( A[b] (M,K) @ B[b] (K,N) ) */
   const float* A; const float* B; float* C;
   int M, N, K;
   int lda, ldb, ldc;
   long long strideA, strideB, strideC; /* elements between batches */
   int batch;
   int a_kmajor;          /* 0: A stored (M,K) row-major; 1: A stored (K,M) row-major ("TN") */
+  int b_nmajor;          /* 0: B stored (K,N) row-major; 1: B stored (N,K) row-major ("NT") */
   /* ---- epilogue (all optional; every aux matrix uses ldc / strideC addressing) ---- */
   float alpha;           /* acc *= alpha (0 is treated as 1) */
   const float* bias;     /* (N) added after alpha */
+  const float* bias_m;   /* (M) per-row bias (conv output channel when C is (O, Ho*Wo)) */
   int act;               /* 0 none; 1 leaky_relu(slope) ; 2 leaky_relu(slope)*act_gain */
   float slope; float act_gain;
   const float* resid;    /* after act: C2 = act(..) + resid */

@@ -1,0 +1,397 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  CPU (torch fp32) restatement of the CIPS-3D hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; it
+is the checker, never the product (the product path is cips3d_amd/ over libcips3d_hip.so and
+fails loudly without the HIP extension).
+
+Every function restates — in a flat, functional form over a plain state_dict — the algorithm
+of the reference code it cites (paths relative to the reference repo).  The restatement is
+PINNED: oracle/make_golden.py runs the unmodified reference (imported through
+oracle/ref_shim.py in the build container) on seeded inputs with every random draw captured,
+and tests/test_oracle_golden.py checks this file against those committed fixtures
+(tests/golden/*.pt) to ~1e-6.
+
+All random tensors are explicit inputs (`rand` dict) in the reference's draw order
+(SURVEY.md §8a): jitter rand(b,n,S,1) comm_utils.py:432 | theta randn(b,1) :485 | phi randn(b,1)
+:488 | noise_c randn(b,n,S,1) pigan_utils.py:246 via generator_nerf_inr.py:564 | u rand(b*n,S)
+pigan_utils.py:192 | noise_f randn(b,n,E,1) pigan_utils.py:246 via generator.py:1744.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LRELU = 0.2
+
+
+# ----------------------------------------------------------------------------------------
+# mapping networks — exp/cips3d/models/multi_head_mapping.py:13-19 (PixelNorm), :130-153
+# ----------------------------------------------------------------------------------------
+def pixel_norm(z):
+    return z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+def mapping_nerf(sd, z, prefix="mapping_network_nerf.base_net."):
+    """4 x Linear(., 128) with LeakyReLU(0.2) between (ffhq_exp.yaml:59-64: head_layers 0)."""
+    x = pixel_norm(z)
+    idxs = [0, 2, 4, 6]
+    for j, i in enumerate(idxs):
+        x = F.linear(x, sd[f"{prefix}{i}.weight"], sd[f"{prefix}{i}.bias"])
+        if j != len(idxs) - 1:
+            x = F.leaky_relu(x, LRELU)
+    return x
+
+
+def mapping_inr(sd, z, prefix="mapping_network_inr.base_net."):
+    """8 x (Linear, LayerNorm, LeakyReLU); the last is Linear + LayerNorm (add_norm, norm_out;
+    ffhq_exp.yaml:73-81, multi_head_mapping.py:62-84)."""
+    x = pixel_norm(z)
+    for j in range(8):
+        i = 3 * j
+        x = F.linear(x, sd[f"{prefix}{i}.weight"], sd[f"{prefix}{i}.bias"])
+        x = F.layer_norm(x, (x.shape[-1],), sd[f"{prefix}{i + 1}.weight"], sd[f"{prefix}{i + 1}.bias"])
+        if j != 7:
+            x = F.leaky_relu(x, LRELU)
+    return x
+
+
+# ----------------------------------------------------------------------------------------
+# H1 rays — exp/comm/comm_utils.py:365-412, 416-438, 451-535, 538-581, 584-679
+# ----------------------------------------------------------------------------------------
+def _unit(v):
+    return v / torch.norm(v, dim=-1, keepdim=True)
+
+
+def rays(b, img_size, fov, ray_start, ray_end, S, jitter, theta_n, phi_n, h_stddev, v_stddev,
+         h_mean=math.pi * 0.5, v_mean=math.pi * 0.5):
+    """-> points (b,n,S,3) world, z (b,n,S,1), dirs (b,n,3), origins (b,n,3), pitch, yaw.
+    jitter = rand(b,n,S,1); theta_n/phi_n = the raw randn(b,1) draws ('gaussian' camera)."""
+    W = H = img_size
+    gx, gy = torch.meshgrid(torch.linspace(-1, 1, W), torch.linspace(1, -1, H), indexing="ij")
+    x = gx.T.flatten()
+    y = gy.T.flatten()
+    zc = -torch.ones_like(x) / np.tan((2 * math.pi * fov / 360) / 2)
+    d_cam = _unit(torch.stack([x, y, zc], -1))                                   # (n,3)
+    z = torch.linspace(ray_start, ray_end, S).reshape(1, S, 1).repeat(W * H, 1, 1)  # (n,S,1)
+    pts = d_cam.unsqueeze(1).repeat(1, S, 1) * z
+    pts = torch.stack(b * [pts]); z = torch.stack(b * [z]); d_cam = torch.stack(b * [d_cam])
+    # stratified jitter (perturb_points)
+    step = z[:, :, 1:2, :] - z[:, :, 0:1, :]
+    off = (jitter - 0.5) * step
+    z = z + off
+    pts = pts + off * d_cam.unsqueeze(2)
+    # camera on the unit sphere (sample_camera_positions, mode gaussian)
+    theta = theta_n * h_stddev + h_mean
+    phi = torch.clamp(phi_n * v_stddev + v_mean, 1e-5, math.pi - 1e-5)
+    o = torch.zeros(b, 3)
+    o[:, 0:1] = torch.sin(phi) * torch.cos(theta)
+    o[:, 2:3] = torch.sin(phi) * torch.sin(theta)
+    o[:, 1:2] = torch.cos(phi)
+    fwd = _unit(-o)
+    up0 = torch.tensor([0., 1., 0.]).expand_as(fwd)
+    left = _unit(torch.cross(up0, fwd, dim=-1))
+    up = _unit(torch.cross(fwd, left, dim=-1))
+    rot = torch.eye(4).unsqueeze(0).repeat(b, 1, 1)
+    rot[:, :3, :3] = torch.stack((-left, up, -fwd), axis=-1)
+    tr = torch.eye(4).unsqueeze(0).repeat(b, 1, 1)
+    tr[:, :3, 3] = o
+    c2w = tr @ rot
+    n = W * H
+    ph = torch.ones(b, n, S, 4)
+    ph[..., :3] = pts
+    wpts = torch.bmm(c2w, ph.reshape(b, -1, 4).permute(0, 2, 1)).permute(0, 2, 1).reshape(b, n, S, 4)[..., :3]
+    wdir = torch.bmm(c2w[..., :3, :3], d_cam.reshape(b, -1, 3).permute(0, 2, 1)).permute(0, 2, 1).reshape(b, n, 3)
+    ho = torch.zeros(b, 4, n)
+    ho[:, 3, :] = 1
+    worig = torch.bmm(c2w, ho).permute(0, 2, 1).reshape(b, n, 4)[..., :3]
+    return dict(points=wpts, z=z, dirs=wdir, origins=worig, pitch=phi, yaw=theta, cam2world=c2w)
+
+
+# ----------------------------------------------------------------------------------------
+# H2 SIREN — exp/cips3d/models/generator.py:260-317, exp/comm/models/film_layer.py:78-107,
+#            exp/comm/models/nerf_network.py:39-45
+# ----------------------------------------------------------------------------------------
+def film(sd, prefix, x, style):
+    gain = F.linear(style, sd[prefix + "gain_fc.weight"], sd[prefix + "gain_fc.bias"]) * 15 + 30
+    bias = F.linear(style, sd[prefix + "bias_fc.weight"], sd[prefix + "bias_fc.bias"])
+    y = F.linear(x, sd[prefix + "linear.weight"], sd[prefix + "linear.bias"])
+    return torch.sin(gain.unsqueeze(1) * y + bias.unsqueeze(1))
+
+
+def siren(sd, points, w_nerf, prefix="siren."):
+    """points (b,P,3), w_nerf (b,128) -> (b,P,33) = [feat(32), sigma(1)]."""
+    x = points * (2 / 0.24)
+    x = film(sd, prefix + "network.0.", x, w_nerf)
+    x = film(sd, prefix + "network.1.", x, w_nerf)
+    sigma = F.linear(x, sd[prefix + "final_layer.weight"], sd[prefix + "final_layer.bias"])
+    c = film(sd, prefix + "color_layer_sine.", x, w_nerf)
+    feat = F.linear(c, sd[prefix + "color_layer_linear.0.weight"], sd[prefix + "color_layer_linear.0.bias"])
+    return torch.cat([feat, sigma], dim=-1)
+
+
+# ----------------------------------------------------------------------------------------
+# H3 — exp/pigan/pigan_utils.py:164-209 (sample_pdf), :212-273 (fancy_integration),
+#       exp/dev/nerf_inr/models/generator_nerf_inr.py:537-598, generator.py:1733-1752
+# ----------------------------------------------------------------------------------------
+def integrate(rgb_sigma, z, noise, noise_std, dim_rgb=32, clamp_mode="relu", last_back=False, white_back=False):
+    """rgb_sigma (b,n,E,33), z (b,n,E,1), noise (b,n,E,1) raw randn -> rgb (b,n,32), depth, weights."""
+    rgbs, sig = rgb_sigma[..., :dim_rgb], rgb_sigma[..., dim_rgb:]
+    d = z[:, :, 1:] - z[:, :, :-1]
+    d = torch.cat([d, 1e10 * torch.ones_like(d[:, :, :1])], -2)
+    nz = noise * noise_std
+    if clamp_mode == "softplus":
+        a = 1 - torch.exp(-d * F.softplus(sig + nz))
+    elif clamp_mode == "relu":
+        a = 1 - torch.exp(-d * F.relu(sig + nz))
+    else:
+        raise AssertionError("Need to choose clamp mode")
+    shifted = torch.cat([torch.ones_like(a[:, :, :1]), 1 - a + 1e-10], -2)
+    w = a * torch.cumprod(shifted, -2)[:, :, :-1]
+    wsum = w.sum(2)
+    if last_back:
+        w[:, :, -1] += (1 - wsum)
+    rgb = torch.sum(w * rgbs, -2)
+    depth = torch.sum(w * z, -2)
+    if white_back:
+        rgb = rgb + 1 - wsum
+    return rgb, depth, w
+
+
+def sample_pdf(bins, weights, u, eps=1e-5):
+    """bins (R,S-1), weights (R,S-2), u (R,S) -> samples (R,S) + (cdf, inds, below, above)."""
+    n_w = weights.shape[1]
+    weights = weights + eps
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u)
+    below = torch.clamp_min(inds - 1, 0)
+    above = torch.clamp_max(inds, n_w)
+    sel = torch.stack([below, above], -1).view(u.shape[0], -1)
+    cg = torch.gather(cdf, 1, sel).view(u.shape[0], -1, 2)
+    bg = torch.gather(bins, 1, sel).view(u.shape[0], -1, 2)
+    den = cg[..., 1] - cg[..., 0]
+    den[den < eps] = 1
+    smp = bg[..., 0] + (u - cg[..., 0]) / den * (bg[..., 1] - bg[..., 0])
+    return smp, dict(cdf=cdf, inds=inds, below=below, above=above)
+
+
+def fine_points(coarse, z, noise_c, nerf_noise, u, origins, dirs, clamp_mode="relu"):
+    """-> fine_points (b, n*S, 3), fine_z (b,n,S,1), plus the bookkeeping dict (all no-grad)."""
+    b, n, S, _ = z.shape
+    _, _, w = integrate(coarse, z, noise_c, nerf_noise, clamp_mode=clamp_mode)
+    w2 = w.reshape(b * n, S) + 1e-5
+    z2 = z.reshape(b * n, S)
+    mid = 0.5 * (z2[:, :-1] + z2[:, 1:])
+    fz, book = sample_pdf(mid, w2[:, 1:-1], u)
+    fz = fz.detach().reshape(b, n, S, 1)
+    fp = origins.unsqueeze(2).contiguous() + dirs.unsqueeze(2).contiguous() * fz.expand(-1, -1, -1, 3).contiguous()
+    book["weights"] = w
+    return fp.reshape(b, n * S, 3), fz, book
+
+
+# ----------------------------------------------------------------------------------------
+# H4 CIPS INR head — exp/cips3d/models/generator.py:949-974, 983-1006, 1107-1153,
+#                     exp/comm/models/mod_conv_fc.py:470-489
+# ----------------------------------------------------------------------------------------
+def mod_fc(sd, prefix, x, style, eps=1e-8):
+    s = F.linear(style, sd[prefix + "modulation.weight"], sd[prefix + "modulation.bias"])
+    w = sd[prefix + "weight"] * (s.unsqueeze(-1) + 1)                    # (b,in,out)
+    w = w * torch.rsqrt(w.pow(2).sum([1]) + eps).unsqueeze(1)
+    return torch.bmm(x, w)
+
+
+INR_NAMES = [str(2 ** i) for i in range(2, 11)]
+
+
+def inr_head(sd, fea, w_inr, prefix="inr_net.", return_all=False):
+    """fea (b,n,32), w_inr (b,512) -> rgb (b,n,3) in [-1,1].  All nine blocks run (the reference
+    calls inr_net without img_size, generator.py:1754 -> default 1024)."""
+    x = fea
+    rgb = 0
+    outs = []
+    for idx, name in enumerate(INR_NAMES):
+        x0 = x
+        x = F.leaky_relu(mod_fc(sd, f"{prefix}network.{name}.mod1.", x, w_inr), LRELU)
+        x = F.leaky_relu(mod_fc(sd, f"{prefix}network.{name}.mod2.", x, w_inr), LRELU)
+        if idx >= 4 and x.shape[-1] == x0.shape[-1]:
+            x = x + x0
+        if idx >= 3:
+            rgb = F.linear(x, sd[f"{prefix}to_rgbs.{name}.linear.weight"], sd[f"{prefix}to_rgbs.{name}.linear.bias"]) + rgb
+        outs.append(x)
+    out = torch.tanh(rgb)
+    return (out, outs) if return_all else out
+
+
+# ----------------------------------------------------------------------------------------
+# generator.forward — exp/cips3d/models/generator.py:1256-1370, 1378-1534, 1659-1762
+# ----------------------------------------------------------------------------------------
+def generator_forward(sd, zs, rand, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                      hierarchical_sample, nerf_noise=0., clamp_mode="relu", return_aux_img=False,
+                      freeze_nerf=False, keep=False):
+    """Returns dict(imgs, pitch_yaw, + intermediates when keep).  `sd` values may require grad."""
+    b = zs["z_nerf"].shape[0]
+    S = num_steps
+    n = img_size * img_size
+    if freeze_nerf:
+        with torch.no_grad():
+            w_nerf = mapping_nerf(sd, zs["z_nerf"])
+    else:
+        w_nerf = mapping_nerf(sd, zs["z_nerf"])
+    w_inr = mapping_inr(sd, zs["z_inr"])
+    with torch.no_grad():
+        r = rays(b, img_size, fov, ray_start, ray_end, S, rand["jitter"], rand["theta"], rand["phi"],
+                 h_stddev, v_stddev)
+    pts = r["points"].reshape(b, n * S, 3)
+    out = {}
+    ctx = torch.no_grad() if freeze_nerf else torch.enable_grad()
+    with ctx:
+        coarse = siren(sd, pts, w_nerf).reshape(b, n, S, 33)
+    if hierarchical_sample:
+        with torch.no_grad():
+            fp, fz, book = fine_points(coarse, r["z"], rand["noise_c"], nerf_noise, rand["u"], r["origins"],
+                                       r["dirs"], clamp_mode)
+        with ctx:
+            fine = siren(sd, fp, w_nerf).reshape(b, n, S, 33)
+        all_o = torch.cat([fine, coarse], dim=-2)
+        all_z = torch.cat([fz, r["z"]], dim=-2)
+        _, idx = torch.sort(all_z, dim=-2)
+        all_z = torch.gather(all_z, -2, idx)
+        all_o = torch.gather(all_o, -2, idx.expand(-1, -1, -1, all_o.shape[-1]))
+    else:
+        all_o, all_z, idx, fz, fp, book, fine = coarse, r["z"], None, None, None, None, None
+    fea, depth, weights = integrate(all_o, all_z, rand["noise_f"], nerf_noise, clamp_mode=clamp_mode)
+    inr = inr_head(sd, fea, w_inr)
+    imgs = inr.reshape(b, img_size, img_size, 3).permute(0, 3, 1, 2)
+    pitch_yaw = torch.cat([r["pitch"], r["yaw"]], -1)
+    if return_aux_img:
+        with ctx:
+            aux = torch.tanh(F.linear(fea, sd["aux_to_rbg.0.weight"], sd["aux_to_rbg.0.bias"]))
+        imgs = torch.cat([imgs, aux.reshape(b, img_size, img_size, 3).permute(0, 3, 1, 2)])
+        pitch_yaw = torch.cat([pitch_yaw, pitch_yaw])
+    out.update(imgs=imgs, pitch_yaw=pitch_yaw)
+    if keep:
+        out.update(w_nerf=w_nerf, w_inr=w_inr, points=r["points"], z=r["z"], dirs=r["dirs"], origins=r["origins"],
+                   coarse=coarse, fine=fine, fine_z=fz, fine_points=fp, book=book, sort_idx=idx,
+                   pixels_fea=fea, depth=depth, weights=weights)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# H5 discriminator — exp/cips3d/models/discriminator.py:20-288, 502-585, 647-664;
+#   native ops: exp/comm/op/fused_bias_act_kernel.cu:36-47, exp/comm/op/upfirdn2d.py:152-186
+# ----------------------------------------------------------------------------------------
+def fused_leaky_relu(x, bias, slope=0.2, scale=2 ** 0.5):
+    rest = [1] * (x.ndim - bias.ndim - 1)
+    return F.leaky_relu(x + bias.view(1, bias.shape[0], *rest), slope) * scale
+
+
+def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
+    """Element-wise restatement of the CUDA kernel's act*10+grad switch (fused_bias_act_kernel.cu:36-47)."""
+    v = x.clone()
+    if bias is not None and bias.numel():
+        step = 1
+        for i in range(2, x.dim()):
+            step *= x.size(i)
+        idx = (torch.arange(x.numel()) // step) % bias.numel()
+        v = (v.reshape(-1) + bias[idx]).reshape(x.shape)
+    mode = act * 10 + grad
+    if mode in (12, 32):
+        y = torch.zeros_like(v)
+    elif mode == 30:
+        y = torch.where(v > 0, v, v * alpha)
+    elif mode == 31:
+        y = torch.where(ref > 0, v, v * alpha)
+    else:
+        y = v
+    return y * scale
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    """x (b,c,h,w); zero-stuff by `up`, pad, correlate with the FLIPPED kernel, decimate by `down`."""
+    b, c, h, w = x.shape
+    kh, kw = kernel.shape
+    t = x.reshape(b * c, 1, h, 1, w, 1)
+    t = F.pad(t, [0, up - 1, 0, 0, 0, up - 1])
+    t = t.reshape(b * c, 1, h * up, w * up)
+    p0, p1 = pad
+    t = F.pad(t, [max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)])
+    t = t[:, :, max(-p0, 0): t.shape[2] - max(-p1, 0), max(-p0, 0): t.shape[3] - max(-p1, 0)]
+    t = F.conv2d(t, torch.flip(kernel, [0, 1]).view(1, 1, kh, kw))
+    t = t[:, :, ::down, ::down]
+    return t.reshape(b, c, t.shape[2], t.shape[3])
+
+
+def _blur_kernel():
+    k = torch.tensor([1., 3., 3., 1.])
+    k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+def conv_layer(sd, prefix, x, k, downsample=False, activate=True, bias=True):
+    """ConvLayer (discriminator.py:134-222): [Blur] -> EqualConv2d -> [FusedLeakyReLU]."""
+    w = sd[prefix + "equal_conv.weight"]
+    cin = w.shape[1]
+    scale = 1 / math.sqrt(cin * k * k)
+    if downsample:
+        p = (4 - 2) + (k - 1)
+        x = upfirdn2d(x, sd.get(prefix + "down_blur.kernel", _blur_kernel()), pad=((p + 1) // 2, p // 2))
+        stride, padding = 2, 0
+    else:
+        stride, padding = 1, (k - 1) // 2
+    cb = sd.get(prefix + "equal_conv.bias") if (bias and not activate) else None
+    x = F.conv2d(x, w * scale, bias=cb, stride=stride, padding=padding)
+    if activate:
+        x = fused_leaky_relu(x, sd[prefix + "flrelu.bias"]) if bias else F.leaky_relu(x, 0.2) * math.sqrt(2)
+    return x
+
+
+def res_block(sd, prefix, x, first_downsample=False):
+    if first_downsample:
+        o = conv_layer(sd, prefix + "conv1.", x, 3, downsample=True)
+        o = conv_layer(sd, prefix + "conv2.", o, 3)
+    else:
+        o = conv_layer(sd, prefix + "conv1.", x, 3)
+        o = conv_layer(sd, prefix + "conv2.", o, 3, downsample=True)
+    s = conv_layer(sd, prefix + "skip.", x, 1, downsample=True, activate=False, bias=False)
+    return (o + s) / math.sqrt(2)
+
+
+def equal_linear(sd, prefix, x, activation=False):
+    w = sd[prefix + "weight"]
+    scale = 1 / math.sqrt(w.shape[1])
+    if activation:
+        return fused_leaky_relu(F.linear(x, w * scale), sd[prefix + "bias"])
+    return F.linear(x, w * scale, bias=sd[prefix + "bias"])
+
+
+def disc_multiscale(sd, prefix, x, alpha=1., first_downsample=False):
+    """Discriminator_MultiScale.forward (discriminator.py:502-585), stddev_group 0, diffaug off."""
+    size = x.shape[-1]
+    ls = int(math.log(size, 2))
+    cur = conv_layer(sd, f"{prefix}conv_in.{2 ** ls}.", x, 1)
+    cur = res_block(sd, f"{prefix}convs.{2 ** ls}.", cur, first_downsample)
+    if alpha < 1:
+        dn = F.interpolate(x, scale_factor=0.5, mode="bilinear")
+        dn = conv_layer(sd, f"{prefix}conv_in.{2 ** (ls - 1)}.", dn, 1)
+        out = alpha * cur + (1 - alpha) * dn
+    else:
+        out = cur
+    for i in range(ls - 1, 2, -1):
+        out = res_block(sd, f"{prefix}convs.{2 ** i}.", out, first_downsample)
+    out = conv_layer(sd, f"{prefix}final_conv.", out, 3)
+    out = out.view(out.shape[0], -1)
+    out = equal_linear(sd, f"{prefix}space_linear.", out, activation=True)
+    return equal_linear(sd, f"{prefix}out_linear.", out)
+
+
+def discriminator_forward(sd, x, alpha=1., use_aux_disc=False):
+    """Discriminator_MultiScale_Aux.forward (discriminator.py:647-664)."""
+    if use_aux_disc:
+        b = x.shape[0] // 2
+        m = disc_multiscale(sd, "main_disc.", x[:b], alpha, first_downsample=False)
+        a = disc_multiscale(sd, "aux_disc.", x[b:], alpha, first_downsample=True)
+        return torch.cat([m, a], dim=0)
+    return disc_multiscale(sd, "main_disc.", x, alpha, first_downsample=False)

