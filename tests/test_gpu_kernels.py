@@ -181,11 +181,11 @@ def test_resample_matches_oracle_bookkeeping(noise_std, clamp):
     print(f"searchsorted index mismatch rate (own cdf) = {mism:.2e}")
     assert mism < 1e-3
     good = (inds_d.cpu() == book["inds"])
-    assert max_rel(fz_d.cpu()[good], fz.view(b * n, S)[good]) < 1e-5
-    assert max_rel(fp_d.cpu().view(b * n, S, 3)[good], fp.view(b * n, S, 3)[good]) < 1e-5
+    assert max_rel(fz_d.cpu()[good], fz.view(b * n, S)[good]) < 1e-4
+    assert max_rel(fp_d.cpu().view(b * n, S, 3)[good], fp.view(b * n, S, 3)[good]) < 1e-4
 
 
-@pytest.mark.parametrize("hier,noise_std,clamp", [(False, 0.0, "relu"), (True, 0.0, "relu"), (True, 0.3, "relu"),
+@pytest.mark.parametrize("hier,noise_std,clamp", [(False, 0.0, "relu"), (False, 0.3, "relu"), (True, 0.0, "relu"), (True, 0.3, "relu"),
                                                   (True, 0.1, "softplus")])
 def test_composite_forward_backward(hier, noise_std, clamp):
     from cips3d_amd import ops
