@@ -1,0 +1,526 @@
+"""MI355X-native drop-in for the reference discriminator API
+(exp/cips3d/models/discriminator.py: Discriminator_MultiScale :406-585, Discriminator_MultiScale_Aux
+:589-664) with identical constructor / forward signatures and state_dict layout.
+
+Native ops, same contracts as the reference's CUDA extensions (exp/comm/op/fused_act.py,
+exp/comm/op/upfirdn2d.py) but backed by libcips3d_hip.so:
+  * fused_leaky_relu / FusedLeakyReLU   -> cips_fused_bias_act (fwd, bwd, double-bwd)
+  * upfirdn2d (Blur)                     -> cips_upfirdn2d      (fwd, bwd, double-bwd)
+  * EqualConv2d                          -> cips_im2col + cips_gemm_f32 (fp32 MFMA) + cips_col2im,
+                                            as three mutually-recursive autograd Functions so the R1
+                                            double-backward of train.py:387-394 works.
+"""
+import collections
+import math
+
+import torch
+from torch import nn
+from torch.autograd import Function
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------
+# fused bias + leaky relu  (mirrors exp/comm/op/fused_act.py:19-86)
+# ------------------------------------------------------------------------------------------
+class FusedLeakyReLUFunctionBackward(Function):
+    @staticmethod
+    def forward(ctx, grad_output, out, negative_slope, scale):
+        ctx.save_for_backward(out)
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        empty = grad_output.new_empty(0)
+        grad_input = ops.fused_bias_act(grad_output, empty, out, 3, 1, negative_slope, scale)
+        dim = [0] + list(range(2, grad_input.ndim))
+        grad_bias = grad_input.sum(dim).detach()
+        return grad_input, grad_bias
+
+    @staticmethod
+    def backward(ctx, gradgrad_input, gradgrad_bias):
+        out, = ctx.saved_tensors
+        gradgrad_out = ops.fused_bias_act(gradgrad_input, gradgrad_bias, out, 3, 1, ctx.negative_slope, ctx.scale)
+        return gradgrad_out, None, None, None
+
+
+class FusedLeakyReLUFunction(Function):
+    @staticmethod
+    def forward(ctx, input, bias, negative_slope, scale):
+        empty = input.new_empty(0)
+        out = ops.fused_bias_act(input, bias, empty, 3, 0, negative_slope, scale)
+        ctx.save_for_backward(out)
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        out, = ctx.saved_tensors
+        grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(grad_output, out, ctx.negative_slope, ctx.scale)
+        return grad_input, grad_bias, None, None
+
+
+def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
+    return FusedLeakyReLUFunction.apply(input, bias, negative_slope, scale)
+
+
+class FusedLeakyReLU(nn.Module):
+    def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel))
+        self.negative_slope = negative_slope
+        self.scale = scale
+
+    def forward(self, input):
+        return fused_leaky_relu(input, self.bias, self.negative_slope, self.scale)
+
+
+# ------------------------------------------------------------------------------------------
+# upfirdn2d  (mirrors exp/comm/op/upfirdn2d.py:18-149)
+# ------------------------------------------------------------------------------------------
+class UpFirDn2dBackward(Function):
+    @staticmethod
+    def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
+        up_x, up_y = up
+        down_x, down_y = down
+        g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1 = g_pad
+        grad_output = grad_output.reshape(-1, out_size[0], out_size[1], 1)
+        grad_input = ops.upfirdn2d_op(grad_output, grad_kernel, down_x, down_y, up_x, up_y,
+                                      g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
+        grad_input = grad_input.view(in_size[0], in_size[1], in_size[2], in_size[3])
+        ctx.save_for_backward(kernel)
+        ctx.up, ctx.down, ctx.pad = up, down, pad
+        ctx.in_size, ctx.out_size = in_size, out_size
+        return grad_input
+
+    @staticmethod
+    def backward(ctx, gradgrad_input):
+        kernel, = ctx.saved_tensors
+        gradgrad_input = gradgrad_input.reshape(-1, ctx.in_size[2], ctx.in_size[3], 1)
+        gradgrad_out = ops.upfirdn2d_op(gradgrad_input, kernel, ctx.up[0], ctx.up[1], ctx.down[0], ctx.down[1], *ctx.pad)
+        gradgrad_out = gradgrad_out.view(ctx.in_size[0], ctx.in_size[1], ctx.out_size[0], ctx.out_size[1])
+        return gradgrad_out, None, None, None, None, None, None, None, None
+
+
+class UpFirDn2d(Function):
+    @staticmethod
+    def forward(ctx, input, kernel, up, down, pad):
+        up_x, up_y = up
+        down_x, down_y = down
+        pad_x0, pad_x1, pad_y0, pad_y1 = pad
+        kernel_h, kernel_w = kernel.shape
+        batch, channel, in_h, in_w = input.shape
+        ctx.in_size = input.shape
+        input = input.reshape(-1, in_h, in_w, 1)
+        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
+        out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h) // down_y + 1
+        out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w) // down_x + 1
+        ctx.out_size = (out_h, out_w)
+        ctx.up, ctx.down, ctx.pad = (up_x, up_y), (down_x, down_y), (pad_x0, pad_x1, pad_y0, pad_y1)
+        g_pad_x0 = kernel_w - pad_x0 - 1
+        g_pad_y0 = kernel_h - pad_y0 - 1
+        g_pad_x1 = in_w * up_x - out_w * down_x + pad_x0 - up_x + 1
+        g_pad_y1 = in_h * up_y - out_h * down_y + pad_y0 - up_y + 1
+        ctx.g_pad = (g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
+        out = ops.upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+        return out.view(-1, channel, out_h, out_w)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        kernel, grad_kernel = ctx.saved_tensors
+        grad_input = UpFirDn2dBackward.apply(grad_output, kernel, grad_kernel, ctx.up, ctx.down, ctx.pad, ctx.g_pad,
+                                             ctx.in_size, ctx.out_size)
+        return grad_input, None, None, None, None
+
+
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+
+
+# ------------------------------------------------------------------------------------------
+# conv2d on the fp32 MFMA GEMM (replaces F.conv2d in EqualConv2d.forward, discriminator.py:40-48)
+# ------------------------------------------------------------------------------------------
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def _conv_fwd(x, w, stride, pad):
+    B, C, H, W = x.shape
+    O, _, kh, kw = w.shape
+    x = x.contiguous()
+    col, Ho, Wo = ops.im2col(x, kh, kw, stride, pad)                  # (B, K, Ho*Wo)
+    K, N = C * kh * kw, Ho * Wo
+    if N % 4:
+        raise NotImplementedError("conv output plane must have a multiple of 4 pixels")
+    wm = w.reshape(O, K)
+    Kp = _pad4(K)
+    if Kp != K:   # RGB input (C_in = 3, 1x1): pad the contraction dim to the GEMM's 16-byte vector granule
+        wm = F.pad(wm, (0, Kp - K))
+        col = F.pad(col, (0, 0, 0, Kp - K))
+    wm = wm.contiguous()
+    y = torch.empty(B, O, Ho, Wo, device=x.device)
+    ops.gemm(wm, col, y, O, N, Kp, Kp, N, N, batch=B, strideA=0, strideB=Kp * N, strideC=O * N)
+    return y
+
+
+def _conv_bwd_data(dy, w, in_shape, stride, pad):
+    B, C, H, W = in_shape
+    O, _, kh, kw = w.shape
+    dy = dy.contiguous()
+    Ho, Wo = dy.shape[2], dy.shape[3]
+    K, N = C * kh * kw, Ho * Wo
+    wm = w.reshape(O, K)
+    Kp = _pad4(K)
+    if Kp != K:
+        wm = F.pad(wm, (0, Kp - K))
+    wm = wm.contiguous()
+    dcol = torch.empty(B, Kp, N, device=dy.device)
+    ops.gemm(wm, dy, dcol, Kp, N, O, Kp, N, N, batch=B, strideA=0, strideB=O * N, strideC=Kp * N, a_kmajor=True)
+    if Kp != K:
+        dcol = dcol[:, :K].contiguous()
+    return ops.col2im(dcol, B, C, H, W, kh, kw, stride, pad)
+
+
+def _conv_bwd_weight(dy, x, w_shape, stride, pad):
+    O, C, kh, kw = w_shape
+    B = x.shape[0]
+    x = x.contiguous()
+    dy = dy.contiguous()
+    col, Ho, Wo = ops.im2col(x, kh, kw, stride, pad)
+    K, N = C * kh * kw, Ho * Wo
+    part = torch.empty(B, O, K, device=x.device)
+    ops.gemm(dy, col, part, O, K, N, N, N, K, batch=B, strideA=O * N, strideB=K * N, strideC=O * K, b_nmajor=True)
+    return part.sum(0).view(O, C, kh, kw)
+
+
+class Conv2dFunction(Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        ctx.save_for_backward(x, w)
+        ctx.stride, ctx.pad = stride, pad
+        return _conv_fwd(x, w, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = Conv2dBwdDataFunction.apply(dy, w, x.shape, ctx.stride, ctx.pad)
+        if ctx.needs_input_grad[1]:
+            dw = Conv2dBwdWeightFunction.apply(dy, x, w.shape, ctx.stride, ctx.pad)
+        return dx, dw, None, None
+
+
+class Conv2dBwdDataFunction(Function):
+    @staticmethod
+    def forward(ctx, dy, w, in_shape, stride, pad):
+        ctx.save_for_backward(dy, w)
+        ctx.in_shape, ctx.stride, ctx.pad = in_shape, stride, pad
+        return _conv_bwd_data(dy, w, in_shape, stride, pad)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        dy, w = ctx.saved_tensors
+        g_dy = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_dy = Conv2dFunction.apply(ggx, w, ctx.stride, ctx.pad)
+        if ctx.needs_input_grad[1]:
+            g_w = Conv2dBwdWeightFunction.apply(dy, ggx, w.shape, ctx.stride, ctx.pad)
+        return g_dy, g_w, None, None, None
+
+
+class Conv2dBwdWeightFunction(Function):
+    @staticmethod
+    def forward(ctx, dy, x, w_shape, stride, pad):
+        ctx.save_for_backward(dy, x)
+        ctx.w_shape, ctx.stride, ctx.pad = w_shape, stride, pad
+        return _conv_bwd_weight(dy, x, w_shape, stride, pad)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        dy, x = ctx.saved_tensors
+        g_dy = g_x = None
+        if ctx.needs_input_grad[0]:
+            g_dy = Conv2dFunction.apply(x, ggw, ctx.stride, ctx.pad)
+        if ctx.needs_input_grad[1]:
+            g_x = Conv2dBwdDataFunction.apply(dy, ggw, x.shape, ctx.stride, ctx.pad)
+        return g_dy, g_x, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, padding=0):
+    y = Conv2dFunction.apply(x, w, stride, padding)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# modules (same names / shapes / init as the reference)
+# ------------------------------------------------------------------------------------------
+class EqualConv2d(nn.Module):
+    """discriminator.py:20-54"""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride, self.padding = stride, padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input):
+        return conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
+
+
+def make_kernel(k):
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    k /= k.sum()
+    return k
+
+
+class Blur(nn.Module):
+    """discriminator.py:67-82"""
+
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        kernel = make_kernel(kernel)
+        if upsample_factor > 1:
+            kernel = kernel * (upsample_factor ** 2)
+        self.register_buffer('kernel', kernel)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class ScaledLeakyReLU(nn.Module):
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, input):
+        return F.leaky_relu(input, negative_slope=self.negative_slope) * math.sqrt(2)
+
+
+class ConvLayer(nn.Sequential):
+    """discriminator.py:134-222 (down path only: the discriminator never upsamples)"""
+
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=[1, 3, 3, 1], bias=True,
+                 activate=True, upsample=False, padding="zero"):
+        layers = collections.OrderedDict()
+        self.padding = 0
+        stride = 1
+        if upsample or padding != "zero":
+            raise NotImplementedError("only the discriminator's ConvLayer modes are built (zero padding, no upsample)")
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            layers['down_blur'] = Blur(blur_kernel, pad=((p + 1) // 2, p // 2))
+            stride = 2
+        else:
+            self.padding = (kernel_size - 1) // 2
+        layers['equal_conv'] = EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding, stride=stride,
+                                           bias=bias and not activate)
+        if activate:
+            if bias:
+                layers['flrelu'] = FusedLeakyReLU(out_channel)
+            else:
+                layers['slrelu'] = ScaledLeakyReLU(0.2)
+        super().__init__(layers)
+
+
+class ResBlock(nn.Module):
+    """discriminator.py:224-252"""
+
+    def __init__(self, in_channel, out_channel, blur_kernel=[1, 3, 3, 1], kernel_size=3, downsample=True,
+                 first_downsample=False):
+        super().__init__()
+        if first_downsample:
+            self.conv1 = ConvLayer(in_channel, in_channel, kernel_size, downsample=downsample)
+            self.conv2 = ConvLayer(in_channel, out_channel, kernel_size)
+        else:
+            self.conv1 = ConvLayer(in_channel, in_channel, kernel_size)
+            self.conv2 = ConvLayer(in_channel, out_channel, kernel_size, downsample=downsample)
+        self.skip = ConvLayer(in_channel, out_channel, 1, downsample=downsample, activate=False, bias=False)
+
+    def forward(self, input):
+        out = self.conv2(self.conv1(input))
+        skip = self.skip(input)
+        return (out + skip) / math.sqrt(2)
+
+
+class EqualLinear(nn.Module):
+    """discriminator.py:254-288.  (b x 8192) @ (8192 x 512) and (b x 512) @ (512 x 1): tiny-M GEMMs,
+    left on torch (natively double-differentiable); the activation uses the HIP fused op."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        if self.activation:
+            out = F.linear(input, self.weight * self.scale)
+            return fused_leaky_relu(out, self.bias * self.lr_mul)
+        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+
+
+def DiffAugment(x, policy='', channels_first=True):
+    """exp/cips3d/models/diffaug.py:9-85 (color, translation, cutout) — elementwise / gather torch ops
+    ('next' row; only the r256 stages enable it)."""
+    if not policy:
+        return x
+    if not channels_first:
+        x = x.permute(0, 3, 1, 2)
+    for p in policy.split(','):
+        for f in _AUGMENT_FNS[p]:
+            x = f(x)
+    if not channels_first:
+        x = x.permute(0, 2, 3, 1)
+    return x.contiguous()
+
+
+def _rand_brightness(x):
+    return x + (torch.rand(x.size(0), 1, 1, 1, dtype=x.dtype, device=x.device) - 0.5)
+
+
+def _rand_saturation(x):
+    m = x.mean(dim=1, keepdim=True)
+    return (x - m) * (torch.rand(x.size(0), 1, 1, 1, dtype=x.dtype, device=x.device) * 2) + m
+
+
+def _rand_contrast(x):
+    m = x.mean(dim=[1, 2, 3], keepdim=True)
+    return (x - m) * (torch.rand(x.size(0), 1, 1, 1, dtype=x.dtype, device=x.device) + 0.5) + m
+
+
+def _rand_translation(x, ratio=0.125):
+    sx, sy = int(x.size(2) * ratio + 0.5), int(x.size(3) * ratio + 0.5)
+    tx = torch.randint(-sx, sx + 1, size=[x.size(0), 1, 1], device=x.device)
+    ty = torch.randint(-sy, sy + 1, size=[x.size(0), 1, 1], device=x.device)
+    gb, gx, gy = torch.meshgrid(torch.arange(x.size(0), dtype=torch.long, device=x.device),
+                                torch.arange(x.size(2), dtype=torch.long, device=x.device),
+                                torch.arange(x.size(3), dtype=torch.long, device=x.device), indexing="ij")
+    gx = torch.clamp(gx + tx + 1, 0, x.size(2) + 1)
+    gy = torch.clamp(gy + ty + 1, 0, x.size(3) + 1)
+    xp = F.pad(x, [1, 1, 1, 1, 0, 0, 0, 0])
+    return xp.permute(0, 2, 3, 1).contiguous()[gb, gx, gy].permute(0, 3, 1, 2)
+
+
+def _rand_cutout(x, ratio=0.5):
+    cs = int(x.size(2) * ratio + 0.5), int(x.size(3) * ratio + 0.5)
+    ox = torch.randint(0, x.size(2) + (1 - cs[0] % 2), size=[x.size(0), 1, 1], device=x.device)
+    oy = torch.randint(0, x.size(3) + (1 - cs[1] % 2), size=[x.size(0), 1, 1], device=x.device)
+    gb, gx, gy = torch.meshgrid(torch.arange(x.size(0), dtype=torch.long, device=x.device),
+                                torch.arange(cs[0], dtype=torch.long, device=x.device),
+                                torch.arange(cs[1], dtype=torch.long, device=x.device), indexing="ij")
+    gx = torch.clamp(gx + ox - cs[0] // 2, min=0, max=x.size(2) - 1)
+    gy = torch.clamp(gy + oy - cs[1] // 2, min=0, max=x.size(3) - 1)
+    mask = torch.ones(x.size(0), x.size(2), x.size(3), dtype=x.dtype, device=x.device)
+    mask[gb, gx, gy] = 0
+    return x * mask.unsqueeze(1)
+
+
+_AUGMENT_FNS = {'color': [_rand_brightness, _rand_saturation, _rand_contrast],
+                'translation': [_rand_translation], 'cutout': [_rand_cutout]}
+
+
+class Discriminator_MultiScale(nn.Module):
+    """discriminator.py:406-585"""
+
+    def __init__(self, diffaug, max_size, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], input_size=3,
+                 first_downsample=False, channels=None, stddev_group=4, **kwargs):
+        super().__init__()
+        self.epoch = 0
+        self.step = 0
+        self.diffaug, self.max_size, self.input_size, self.stddev_group = diffaug, max_size, input_size, stddev_group
+        self.module_name_list = []
+        if channels is None:
+            channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
+                        256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+        self.conv_in = nn.ModuleDict()
+        self.module_name_list.append('conv_in')
+        for name, channel_ in channels.items():
+            self.conv_in[f"{name}"] = ConvLayer(input_size, channel_, 1)
+        self.convs = nn.ModuleDict()
+        self.module_name_list.append('convs')
+        log_size = int(math.log(max_size, 2))
+        in_channel = channels[max_size]
+        for i in range(log_size, 2, -1):
+            out_channel = channels[2 ** (i - 1)]
+            self.convs[f"{2 ** i}"] = ResBlock(in_channel, out_channel, blur_kernel, first_downsample=first_downsample)
+            in_channel = out_channel
+        self.stddev_feat = 1
+        self.final_conv = ConvLayer(in_channel + (1 if self.stddev_group > 1 else 0), channels[4], 3)
+        self.module_name_list.append('final_conv')
+        self.space_linear = EqualLinear(channels[4] * 4 * 4, channels[4], activation='fused_lrelu')
+        self.module_name_list.append('space_linear')
+        self.out_linear = EqualLinear(channels[4], 1)
+        self.module_name_list.append('out_linear')
+
+    def diff_aug_img(self, img):
+        return DiffAugment(img, policy='color,translation,cutout')
+
+    def forward(self, input, alpha, summary_ddict=None):
+        if self.diffaug:
+            input = self.diff_aug_img(input)
+        size = input.shape[-1]
+        log_size = int(math.log(size, 2))
+        cur = self.conv_in[f"{2 ** log_size}"](input)
+        cur = self.convs[f"{2 ** log_size}"](cur)
+        if alpha < 1:
+            down_input = F.interpolate(input, scale_factor=0.5, mode='bilinear')
+            down = self.conv_in[f"{2 ** (log_size - 1)}"](down_input)
+            out = alpha * cur + (1 - alpha) * down
+        else:
+            out = cur
+        for i in range(log_size - 1, 2, -1):
+            out = self.convs[f"{2 ** i}"](out)
+        batch, channel, height, width = out.shape
+        if self.stddev_group > 0:
+            group = min(batch, self.stddev_group)
+            stddev = out.view(group, -1, self.stddev_feat, channel // self.stddev_feat, height, width)
+            stddev = torch.sqrt(stddev.var(0, unbiased=False) + 1e-8)
+            stddev = stddev.mean([2, 3, 4], keepdims=True).squeeze(2)
+            stddev = stddev.repeat(group, 1, height, width)
+            out = torch.cat([out, stddev], 1)
+        out = self.final_conv(out)
+        out = out.view(batch, -1)
+        out = self.space_linear(out)
+        if summary_ddict is not None:
+            with torch.no_grad():
+                summary_ddict['logits_norm']['logits_norm'] = out.norm(dim=1).mean().item()
+                summary_ddict['w_norm']['w_norm'] = self.out_linear.weight.norm(dim=1).mean().item()
+        out = self.out_linear(out)
+        return out, None, None
+
+
+class Discriminator_MultiScale_Aux(nn.Module):
+    """discriminator.py:589-664"""
+
+    def __init__(self, diffaug, max_size, channel_multiplier=2, first_downsample=False, stddev_group=0, **kwargs):
+        super().__init__()
+        self.epoch = 0
+        self.step = 0
+        self.main_disc = Discriminator_MultiScale(diffaug=diffaug, max_size=max_size,
+                                                  channel_multiplier=channel_multiplier,
+                                                  first_downsample=first_downsample, stddev_group=stddev_group)
+        channel_multiplier = 2
+        channels = {4: 128 * channel_multiplier, 8: 128 * channel_multiplier, 16: 128 * channel_multiplier,
+                    32: 128 * channel_multiplier, 64: 128 * channel_multiplier, 128: 128 * channel_multiplier,
+                    256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+        self.aux_disc = Discriminator_MultiScale(diffaug=diffaug, max_size=max_size,
+                                                 channel_multiplier=channel_multiplier, first_downsample=True,
+                                                 channels=channels, stddev_group=stddev_group)
+
+    def forward(self, input, use_aux_disc=False, summary_ddict=None, alpha=1., **kwargs):
+        if use_aux_disc:
+            b = input.shape[0] // 2
+            main_out, latent, position = self.main_disc(input[:b], alpha, summary_ddict=summary_ddict)
+            aux_out, _, _ = self.aux_disc(input[b:], alpha)
+            out = torch.cat([main_out, aux_out], dim=0)
+        else:
+            out, latent, position = self.main_disc(input, alpha, summary_ddict=summary_ddict)
+        return out, latent, position

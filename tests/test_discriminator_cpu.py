@@ -1,0 +1,31 @@
+"""CPU: the drop-in discriminator reproduces the reference's initial state_dict bit-for-bit, and the
+oracle's discriminator restatement is pinned to the golden vectors minted from the reference
+(forward logits, R1 gradient w.r.t. the input, loss)."""
+import pytest
+import torch
+
+from conftest import load_golden, check_checksums, max_rel, D_CFG
+from oracle import cips3d_oracle as orc
+
+
+def seeded_discriminator(seed):
+    from cips3d_amd.discriminator import Discriminator_MultiScale_Aux
+    torch.manual_seed(seed)
+    return Discriminator_MultiScale_Aux(**D_CFG)
+
+
+@pytest.mark.parametrize("tag", ["d_r16", "d_r16_aux_alpha"])
+def test_discriminator_oracle_matches_reference(tag):
+    fix = load_golden(tag)
+    D = seeded_discriminator(fix["seed"])
+    check_checksums(D.state_dict(), fix["state_checksums"])
+    assert sum(p.numel() for p in D.parameters()) == 37518914
+    sd = dict(D.state_dict())
+    sd.update(dict(D.named_parameters()))
+    x = fix["x"].clone().requires_grad_(True)
+    out = orc.discriminator_forward(sd, x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"])
+    assert max_rel(out, fix["out"]) < 1e-5
+    g, = torch.autograd.grad(out.sum(), x, create_graph=True)
+    assert max_rel(g, fix["grad_real"]) < 1e-4
+    loss = torch.nn.functional.softplus(-out).mean() + 0.5 * 10. * g.flatten(1).pow(2).sum(1).mean()
+    assert abs(float(loss) - fix["loss"]) < 1e-5 * max(1.0, abs(fix["loss"]))
