@@ -1,0 +1,63 @@
+"""CPU, world_size 2 over gloo: the flat-bucket gradient all-reduce used for the batch-sharded path
+(cips3d_amd/distributed.py) averages exactly like DDP would, including parameters that received a
+gradient on only some ranks and parameters that never receive one."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cips3d_amd.distributed import allreduce_grads
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(300000)),
+              torch.nn.Parameter(torch.randn(3)), torch.nn.Parameter(torch.randn(4))]
+    g = torch.Generator().manual_seed(100 + rank)
+    params[0].grad = torch.randn(7, 5, generator=g)
+    params[1].grad = torch.randn(300000, generator=g)
+    if rank == 0:
+        params[2].grad = torch.randn(3, generator=g)     # only rank 0 has a grad for this one
+    # params[3]: never used on any rank -> must stay None (find_unused_parameters semantics)
+    nbytes = allreduce_grads(params, bucket_mb=0.5)
+    out = [None if p.grad is None else p.grad.clone() for p in params]
+    q.put((rank, out, nbytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_grads_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, out, nbytes = q.get(timeout=120)
+        res[r] = (out, nbytes)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = []
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+    g0 = [torch.randn(7, 5, generator=g) for g in gens]
+    g1 = [torch.randn(300000, generator=g) for g in gens]
+    g2 = torch.randn(3, generator=gens[0])
+    for r in range(world):
+        out, nbytes = res[r]
+        assert torch.allclose(out[0], (g0[0] + g0[1]) / 2, atol=1e-6)
+        assert torch.allclose(out[1], (g1[0] + g1[1]) / 2, atol=1e-6)
+        assert torch.allclose(out[2], g2 / 2, atol=1e-6)
+        assert out[3] is None
+        assert nbytes == (35 + 300000 + 3) * 4
