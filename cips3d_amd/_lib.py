@@ -36,6 +36,19 @@ class GemmDesc(C.Structure):
     ]
 
 
+class GemmX3Desc(C.Structure):
+    _fields_ = [
+        ("A_hi", vp), ("A_lo", vp), ("B_hi", vp), ("B_lo", vp),
+        ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32),
+        ("strideA", i64), ("strideB", i64), ("batch", i32),
+        ("C", vp), ("ldc", i32), ("strideC", i64),
+        ("P_hi", vp), ("P_lo", vp), ("ldp", i32), ("strideP", i64),
+        ("T_hi", vp), ("T_lo", vp), ("ldt", i32), ("strideT", i64),
+        ("mask_out", vp), ("add", vp), ("rgb_g", vp), ("rgb_w", vp), ("C_unmasked", vp), ("mask", vp),
+        ("act", i32), ("slope", f32), ("res_hi", vp), ("res_lo", vp),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/cips3d_hip.h
 SIGNATURES = {
     "cips_version": (i32, []),
@@ -48,6 +61,11 @@ SIGNATURES = {
     "cips_composite_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_composite_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_gemm_f32": (i32, [C.POINTER(GemmDesc), vp]),
+    "cips_gemm_bf16x3": (i32, [C.POINTER(GemmX3Desc), vp]),
+    "cips_split_planes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
+    "cips_modfc_prep_x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "cips_torgb_fwd_x3": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "cips_torgb_bwd_w_x3": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "cips_modfc_prep": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cips_modfc_prep_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "cips_torgb_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),

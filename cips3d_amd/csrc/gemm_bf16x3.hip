@@ -1,0 +1,304 @@
+// gemm_bf16x3.hip — fp32-grade batched GEMM on the bf16 matrix cores of gfx950 by 3-pass
+// operand splitting ("bf16x3"), for the CIPS INR head (H4), where 87 % of the generator's
+// FLOPs live (17 modulated 512x512 layers x {fwd, dX, dW}).
+//
+// Every fp32 operand x is carried as two bf16 planes, x = hi + lo (hi = rne_bf16(x),
+// lo = rne_bf16(x - hi); |x - hi - lo| <= 2^-17 |x|).  A product sum is evaluated as
+//     sum a*b  ~=  sum a_hi*b_hi + a_hi*b_lo + a_lo*b_hi        (dropped a_lo*b_lo ~ 2^-18)
+// with three v_mfma_f32_32x32x16_bf16 per fragment pair, accumulating in fp32.  Per-layer relative
+// error ~1e-5 against 1e-3 allowed by the parity bar (SURVEY.md §7 "3-pass split-bf16 scheme");
+// the matrix pipe runs 16x the fp32-MFMA rate, so three passes = 5.3x the fp32 MFMA roof
+// (~0.83 PFLOP/s effective).  The SIREN keeps exact fp32 MFMA (its FiLM gains amplify phase error).
+//
+// One kernel form, "NT": C[m][n] = sum_k A[m][k] * B[n][k], both operands with the contraction index
+// contiguous (what the bf16 MFMA fragments want: 8 consecutive k per lane = one 16-byte LDS read).
+// All three INR GEMMs are expressed in it by keeping every activation / gradient in HBM in BOTH
+// orientations (row-major planes and transposed planes), written by the producing GEMM's epilogue:
+//   forward  Y  = X  . Wbt^T      A = X   [rows][in]     B = Wbt [out][in]
+//   dX       dX = G  . Wb^T       A = G   [rows][out]    B = Wb  [in][out]
+//   dW       dW = XT . GT^T       A = XT  [in][rows]     B = GT  [out][rows]
+//
+// Tiling (wave64): 256x128x32 workgroup tile, 512 threads = 8 waves as 4(M) x 2(N), each wave a
+// 64x64 sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs), 24 MFMAs per k-tile per wave.
+// LDS: four planes per stage (A_hi, A_lo, B_hi, B_lo), rows padded to 80 bytes so that the
+// ds_read_b128 fragment reads are bank-conflict free (5r mod 16 is a bijection over each 16-lane
+// service group), two stages (120 KB) with a one-tile register prefetch and a single barrier per
+// k-tile.  Workgroup ids are remapped per XCD like the fp32 kernel.
+#include "common.h"
+#include "../../include/cips3d_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+constexpr int BM = 256, BN = 128, BK = 32;
+constexpr int ROWB = 80;                     // padded LDS row pitch in bytes (32 bf16 = 64 B + 16 B pad)
+constexpr int OFF_AHI = 0;
+constexpr int OFF_ALO = OFF_AHI + BM * ROWB;
+constexpr int OFF_BHI = OFF_ALO + BM * ROWB;
+constexpr int OFF_BLO = OFF_BHI + BN * ROWB;
+constexpr int STAGE = OFF_BLO + BN * ROWB;   // 61440 B
+constexpr int SMEM_BYTES = 2 * STAGE;        // 122880 B
+
+struct Args {
+  cips_gemm_x3_desc d;
+  int tiles_m, tiles_n, total;
+};
+
+__device__ __forceinline__ u16 f2bf(float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ void split2(float v, u16& hi, u16& lo) {
+  hi = f2bf(v);
+  lo = f2bf(v - bf2f(hi));
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_kernel(Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const cips_gemm_x3_desc& d = g.d;
+
+  int bid = blockIdx.x;
+  {
+    const int nx = 8;
+    int q = g.total / nx, r = g.total % nx;
+    int xcd = bid % nx, idx = bid / nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + idx;
+  }
+  const int tn = bid % g.tiles_n;
+  const int tm = (bid / g.tiles_n) % g.tiles_m;
+  const int bz = bid / (g.tiles_n * g.tiles_m);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = d.M, N = d.N, K = d.K;
+
+  const u16* Ahi = (const u16*)d.A_hi + (long long)bz * d.strideA;
+  const u16* Alo = (const u16*)d.A_lo + (long long)bz * d.strideA;
+  const u16* Bhi = (const u16*)d.B_hi + (long long)bz * d.strideB;
+  const u16* Blo = (const u16*)d.B_lo + (long long)bz * d.strideB;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hf = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging map: 16-byte chunks (8 bf16); chunk c -> row c>>2, k-chunk c&3
+  uint4 ra[4], rb[2];
+  const int kc = tid & 3;
+  auto load_tile = [&](int k0) {
+    const int gk = k0 + kc * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 2) + 128 * i;
+      const int gm = m0 + r;
+      uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
+      if (gm < M && gk < K) {
+        vh = *reinterpret_cast<const uint4*>(Ahi + (long long)gm * d.lda + gk);
+        vl = *reinterpret_cast<const uint4*>(Alo + (long long)gm * d.lda + gk);
+      }
+      ra[2 * i] = vh; ra[2 * i + 1] = vl;
+    }
+    {
+      const int r = tid >> 2;
+      const int gn = n0 + r;
+      uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
+      if (gn < N && gk < K) {
+        vh = *reinterpret_cast<const uint4*>(Bhi + (long long)gn * d.ldb + gk);
+        vl = *reinterpret_cast<const uint4*>(Blo + (long long)gn * d.ldb + gk);
+      }
+      rb[0] = vh; rb[1] = vl;
+    }
+  };
+  auto store_tile = [&](int stage) {
+    unsigned char* s = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 2) + 128 * i;
+      *reinterpret_cast<uint4*>(s + OFF_AHI + r * ROWB + kc * 16) = ra[2 * i];
+      *reinterpret_cast<uint4*>(s + OFF_ALO + r * ROWB + kc * 16) = ra[2 * i + 1];
+    }
+    const int r = tid >> 2;
+    *reinterpret_cast<uint4*>(s + OFF_BHI + r * ROWB + kc * 16) = rb[0];
+    *reinterpret_cast<uint4*>(s + OFF_BLO + r * ROWB + kc * 16) = rb[1];
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    const unsigned char* s = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int off = (wm * 64 + i * 32 + l31) * ROWB + ks * 32 + hf * 16;
+        ah[i] = *reinterpret_cast<const bf16x8*>(s + OFF_AHI + off);
+        al[i] = *reinterpret_cast<const bf16x8*>(s + OFF_ALO + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int off = (wn * 64 + j * 32 + l31) * ROWB + ks * 32 + hf * 16;
+        bh[j] = *reinterpret_cast<const bf16x8*>(s + OFF_BHI + off);
+        bl[j] = *reinterpret_cast<const bf16x8*>(s + OFF_BLO + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  const long long cb = (long long)bz * d.strideC;
+  const long long pb = (long long)bz * d.strideP;
+  const long long tb = (long long)bz * d.strideT;
+  float* C = d.C;
+  u16* Phi = (u16*)d.P_hi; u16* Plo = (u16*)d.P_lo;
+  u16* Thi = (u16*)d.T_hi; u16* Tlo = (u16*)d.T_lo;
+  u16* Mout = (u16*)d.mask_out;
+  const u16* Rhi = (const u16*)d.res_hi; const u16* Rlo = (const u16*)d.res_lo;
+  const u16* Mk = (const u16*)d.mask;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      const bool colok = col < N;
+      float rw0 = 0.f, rw1 = 0.f, rw2 = 0.f;
+      if (d.rgb_g && colok) { rw0 = d.rgb_w[col]; rw1 = d.rgb_w[N + col]; rw2 = d.rgb_w[2 * N + col]; }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        u16 th[4], tl[4];
+        const int row0 = m0 + wm * 64 + i * 32 + 8 * rg + 4 * hf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = row0 + e;
+          float v = acc[i][j][4 * rg + e];
+          th[e] = 0; tl[e] = 0;
+          if (row < M && colok) {
+            if (d.add) v += d.add[cb + (long long)row * d.ldc + col];
+            if (d.rgb_g) {
+              const float* gp = d.rgb_g + ((long long)bz * M + row) * 3;
+              v = fmaf(gp[0], rw0, fmaf(gp[1], rw1, fmaf(gp[2], rw2, v)));
+            }
+            if (d.C_unmasked) d.C_unmasked[cb + (long long)row * d.ldc + col] = v;
+            if (Mk) {
+              const u16 mb = Mk[pb + (long long)row * d.ldp + col];
+              const bool pos = ((mb & 0x8000u) == 0) && ((mb & 0x7fffu) != 0);
+              v *= pos ? 1.f : d.slope;
+            }
+            if (d.act) v = lrelu(v, d.slope);
+            if (Mout) Mout[pb + (long long)row * d.ldp + col] = f2bf(v);
+            if (Rhi) {
+              const long long o = pb + (long long)row * d.ldp + col;
+              v += bf2f(Rhi[o]) + bf2f(Rlo[o]);
+            }
+            if (C) C[cb + (long long)row * d.ldc + col] = v;
+            u16 h, l;
+            split2(v, h, l);
+            th[e] = h; tl[e] = l;
+            if (Phi) {
+              const long long o = pb + (long long)row * d.ldp + col;
+              Phi[o] = h; Plo[o] = l;
+            }
+          }
+        }
+        if (Thi && colok) {
+          // transposed planes: 4 consecutive rows of this column -> one 8-byte store per plane
+          const long long o = tb + (long long)col * d.ldt + row0;
+          if (row0 + 3 < M) {
+            *reinterpret_cast<uint2*>(Thi + o) = make_uint2(th[0] | ((unsigned)th[1] << 16), th[2] | ((unsigned)th[3] << 16));
+            *reinterpret_cast<uint2*>(Tlo + o) = make_uint2(tl[0] | ((unsigned)tl[1] << 16), tl[2] | ((unsigned)tl[3] << 16));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (row0 + e < M) { Thi[o + e] = th[e]; Tlo[o + e] = tl[e]; }
+          }
+        }
+      }
+    }
+  }
+}
+
+// fp32 (rows, cols) row-major -> split planes row-major [rows][ldp] and/or transposed [cols][ldt]
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, u16* __restrict__ phi,
+                                                           u16* __restrict__ plo, u16* __restrict__ thi,
+                                                           u16* __restrict__ tlo, int rows, int cols, int ldx,
+                                                           int ldp, int ldt, long long sx, long long sp, long long st) {
+  __shared__ u16 th[32][33], tl[32][33];
+  const int bz = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int r = r0 + rr, c = c0 + tx;
+    u16 h = 0, l = 0;
+    if (r < rows && c < cols) {
+      split2(x[bz * sx + (long long)r * ldx + c], h, l);
+      if (phi) { phi[bz * sp + (long long)r * ldp + c] = h; plo[bz * sp + (long long)r * ldp + c] = l; }
+    }
+    th[rr][tx] = h; tl[rr][tx] = l;
+  }
+  __syncthreads();
+  if (thi)
+    for (int cc = ty; cc < 32; cc += 8) {
+      const int c = c0 + cc, r = r0 + tx;
+      if (r < rows && c < cols) {
+        thi[bz * st + (long long)c * ldt + r] = th[tx][cc];
+        tlo[bz * st + (long long)c * ldt + r] = tl[tx][cc];
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
+  if ((d->K & 31) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
+    return (int)hipErrorInvalidValue;
+  if (d->T_hi && ((d->ldt & 3) || (d->strideT & 3))) return (int)hipErrorInvalidValue;
+  Args g;
+  g.d = *d;
+  g.tiles_m = (d->M + BM - 1) / BM;
+  g.tiles_n = (d->N + BN - 1) / BN;
+  long long total = (long long)g.tiles_m * g.tiles_n * d->batch;
+  if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  g.total = (int)total;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(g.total), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_split_planes(const float* x, void* p_hi, void* p_lo, void* t_hi, void* t_lo, int rows,
+                                 int cols, int ldx, int ldp, int ldt, int batch, long long stride_x,
+                                 long long stride_p, long long stride_t, cips_stream_t stream) {
+  if (rows <= 0 || cols <= 0 || batch <= 0) return (int)hipErrorInvalidValue;
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+  hipLaunchKernelGGL(split_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (u16*)p_hi, (u16*)p_lo,
+                     (u16*)t_hi, (u16*)t_lo, rows, cols, ldx, ldp, ldt, stride_x, stride_p, stride_t);
+  return CIPS_CHECK_LAUNCH();
+}

@@ -55,6 +55,61 @@ __global__ __launch_bounds__(256) void modfc_prep_kernel(const float* __restrict
   }
 }
 
+// same as modfc_prep_kernel but emits the bf16x3 operand planes (hi/lo) of Wb [in][out] and Wbt [out][in]
+__device__ __forceinline__ unsigned short f2bf_rne(float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__global__ __launch_bounds__(256) void modfc_prep_x3_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                            unsigned short* __restrict__ wbh, unsigned short* __restrict__ wbl,
+                                                            unsigned short* __restrict__ wth, unsigned short* __restrict__ wtl,
+                                                            float* __restrict__ demod, int in_dim, int out_dim, float eps) {
+  __shared__ float red[8][33];
+  __shared__ float dsh[32];
+  const int b = blockIdx.y;
+  const int c = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  const float* sb = s + (long long)b * in_dim;
+  float q = 0.f;
+  if (n < out_dim)
+    for (int k = kg; k < in_dim; k += 8) {
+      float u = W[(long long)k * out_dim + n] * (sb[k] + 1.f);
+      q = fmaf(u, u, q);
+    }
+  red[kg][c] = q;
+  __syncthreads();
+  if (kg == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][c];
+    float d = rsqrtf(t + eps);
+    dsh[c] = d;
+    if (n < out_dim) demod[(long long)b * out_dim + n] = d;
+  }
+  __syncthreads();
+  const long long base = (long long)b * in_dim * out_dim;
+  if (n < out_dim) {
+    const float d = dsh[c];
+    for (int k = kg; k < in_dim; k += 8) {
+      const float v = W[(long long)k * out_dim + n] * (sb[k] + 1.f) * d;
+      const unsigned short h = f2bf_rne(v);
+      wbh[base + (long long)k * out_dim + n] = h;
+      wbl[base + (long long)k * out_dim + n] = f2bf_rne(v - __uint_as_float(((unsigned)h) << 16));
+    }
+  }
+  for (int idx = threadIdx.x; idx < 32 * in_dim; idx += 256) {
+    const int k = idx % in_dim, cc = idx / in_dim;
+    const int nn = blockIdx.x * 32 + cc;
+    if (nn < out_dim) {
+      const float v = W[(long long)k * out_dim + nn] * (sb[k] + 1.f) * dsh[cc];
+      const unsigned short h = f2bf_rne(v);
+      wth[base + (long long)nn * in_dim + k] = h;
+      wtl[base + (long long)nn * in_dim + k] = f2bf_rne(v - __uint_as_float(((unsigned)h) << 16));
+    }
+  }
+}
+
 // ---- prep backward -------------------------------------------------------------------
 // u = W*(s+1), q_n = sum_k u^2 + eps, d = q^-1/2, Wb = u*d.  With G = dL/dWb:
 //   c_n  = sum_k G_kn u_kn
@@ -126,8 +181,26 @@ __global__ __launch_bounds__(256) void modfc_prep_bwd_s_kernel(const float* __re
 }
 
 // ---- ToRGB --------------------------------------------------------------------------
+typedef unsigned short u16;
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
+// load 4 consecutive activations either from fp32 or from bf16 hi/lo planes
+template <bool X3>
+__device__ __forceinline__ float4 ldx4(const void* xa, const void* xb, long long e) {
+  if (!X3) return *reinterpret_cast<const float4*>((const float*)xa + e);
+  const uint2 h = *reinterpret_cast<const uint2*>((const u16*)xa + e);
+  const uint2 l = *reinterpret_cast<const uint2*>((const u16*)xb + e);
+  float4 v;
+  v.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+  v.y = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+  v.z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+  v.w = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+  return v;
+}
+
 // rgb[m][c] (+)= sum_k x[m][k] w[c][k] + bias[c];  one wave per row, float4 lanes
-__global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <bool X3>
+__global__ __launch_bounds__(256) void torgb_fwd_kernel(const void* __restrict__ xa, const void* __restrict__ xb,
+                                                        const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ rgb,
                                                         long long M, int K, int accumulate) {
   const int lane = threadIdx.x & 63;
@@ -135,9 +208,8 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
   const long long nwaves = (long long)gridDim.x * 4;
   for (long long m = wave0; m < M; m += nwaves) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    const float* xr = x + m * K;
     for (int k = lane * 4; k < K; k += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(xr + k);
+      const float4 v = ldx4<X3>(xa, xb, m * K + k);
       const float4 w0 = *reinterpret_cast<const float4*>(w + k);
       const float4 w1 = *reinterpret_cast<const float4*>(w + K + k);
       const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * K + k);
@@ -158,24 +230,56 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
   }
 }
 
-constexpr int TORGB_ROWS = 512;  // rows per partial chunk
+constexpr int TORGB_ROWS = 64;  // rows per partial chunk
 
 // partial[chunk][c][k] = sum_{m in chunk} drgb[m][c] x[m][k] ; partial[chunk][3][0..2] = sum drgb
-__global__ __launch_bounds__(256) void torgb_bwd_w_partial_kernel(const float* __restrict__ x, const float* __restrict__ drgb,
+// 256 threads: thread -> 4 consecutive k (float4) x row parity group; K <= 512 per pass.
+template <bool X3>
+__global__ __launch_bounds__(256) void torgb_bwd_w_partial_kernel(const void* __restrict__ xa, const void* __restrict__ xb,
+                                                                  const float* __restrict__ drgb,
                                                                   float* __restrict__ partial, long long M, int K) {
+  __shared__ float sh[3][512];
   const long long m0 = (long long)blockIdx.x * TORGB_ROWS;
   const long long m1 = (m0 + TORGB_ROWS < M) ? m0 + TORGB_ROWS : M;
   float* out = partial + (long long)blockIdx.x * 4 * K;
-  for (int k = threadIdx.x; k < K; k += 256) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (long long m = m0; m < m1; ++m) {
-      const float v = x[m * K + k];
-      a0 = fmaf(drgb[m * 3 + 0], v, a0);
-      a1 = fmaf(drgb[m * 3 + 1], v, a1);
-      a2 = fmaf(drgb[m * 3 + 2], v, a2);
+  const int nk4 = K / 4;                       // float4 columns
+  const int groups = 256 / (nk4 < 256 ? nk4 : 256) > 0 ? 256 / (nk4 < 256 ? nk4 : 256) : 1;
+  for (int kb = 0; kb < nk4; kb += 256) {
+    const int cols = (nk4 - kb) < 256 ? (nk4 - kb) : 256;     // float4 columns handled this pass
+    const int grp = 256 / cols;                               // row-interleave groups
+    const int c4 = threadIdx.x % cols, gi = threadIdx.x / cols;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    if (gi < grp)
+      for (long long m = m0 + gi; m < m1; m += grp) {
+        const float4 v = ldx4<X3>(xa, xb, m * K + (kb + c4) * 4);
+        const float g0 = drgb[m * 3 + 0], g1 = drgb[m * 3 + 1], g2 = drgb[m * 3 + 2];
+        a0.x = fmaf(g0, v.x, a0.x); a0.y = fmaf(g0, v.y, a0.y); a0.z = fmaf(g0, v.z, a0.z); a0.w = fmaf(g0, v.w, a0.w);
+        a1.x = fmaf(g1, v.x, a1.x); a1.y = fmaf(g1, v.y, a1.y); a1.z = fmaf(g1, v.z, a1.z); a1.w = fmaf(g1, v.w, a1.w);
+        a2.x = fmaf(g2, v.x, a2.x); a2.y = fmaf(g2, v.y, a2.y); a2.z = fmaf(g2, v.z, a2.z); a2.w = fmaf(g2, v.w, a2.w);
+      }
+    // combine row groups deterministically through LDS (group 0 first, then 1, ...)
+    for (int g = 0; g < grp; ++g) {
+      __syncthreads();
+      if (gi == g) {
+        float* s0 = &sh[0][c4 * 4]; float* s1 = &sh[1][c4 * 4]; float* s2 = &sh[2][c4 * 4];
+        if (g == 0) {
+          s0[0] = a0.x; s0[1] = a0.y; s0[2] = a0.z; s0[3] = a0.w;
+          s1[0] = a1.x; s1[1] = a1.y; s1[2] = a1.z; s1[3] = a1.w;
+          s2[0] = a2.x; s2[1] = a2.y; s2[2] = a2.z; s2[3] = a2.w;
+        } else {
+          s0[0] += a0.x; s0[1] += a0.y; s0[2] += a0.z; s0[3] += a0.w;
+          s1[0] += a1.x; s1[1] += a1.y; s1[2] += a1.z; s1[3] += a1.w;
+          s2[0] += a2.x; s2[1] += a2.y; s2[2] += a2.z; s2[3] += a2.w;
+        }
+      }
     }
-    out[k] = a0; out[K + k] = a1; out[2 * K + k] = a2;
+    __syncthreads();
+    for (int i = threadIdx.x; i < cols * 4; i += 256) {
+      out[kb * 4 + i] = sh[0][i]; out[K + kb * 4 + i] = sh[1][i]; out[2 * K + kb * 4 + i] = sh[2][i];
+    }
+    __syncthreads();
   }
+  (void)groups;
   if (threadIdx.x < 3) {
     float sacc = 0.f;
     for (long long m = m0; m < m1; ++m) sacc += drgb[m * 3 + threadIdx.x];
@@ -262,8 +366,29 @@ extern "C" int cips_torgb_fwd(const float* x, const float* w, const float* bias,
   if (M <= 0 || K <= 0 || (K & 3)) return (int)hipErrorInvalidValue;
   long long blocks = (M + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(torgb_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                     rgb, M, K, accumulate);
+  hipLaunchKernelGGL(torgb_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const void*)x, (const void*)nullptr, w, bias, rgb, M, K, accumulate);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_torgb_fwd_x3(const void* x_hi, const void* x_lo, const float* w, const float* bias, float* rgb,
+                                 long long M, int K, int accumulate, cips_stream_t stream) {
+  if (M <= 0 || K <= 0 || (K & 3)) return (int)hipErrorInvalidValue;
+  long long blocks = (M + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(torgb_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_hi, x_lo,
+                     w, bias, rgb, M, K, accumulate);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_modfc_prep_x3(const float* weight, const float* s, void* wb_hi, void* wb_lo, void* wbt_hi,
+                                  void* wbt_lo, float* demod, int B, int in_dim, int out_dim, float eps,
+                                  cips_stream_t stream) {
+  if (B <= 0 || in_dim <= 0 || out_dim <= 0) return (int)hipErrorInvalidValue;
+  dim3 grid((out_dim + 31) / 32, B);
+  hipLaunchKernelGGL(modfc_prep_x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, weight, s,
+                     (unsigned short*)wb_hi, (unsigned short*)wb_lo, (unsigned short*)wbt_hi,
+                     (unsigned short*)wbt_lo, demod, in_dim, out_dim, eps);
   return CIPS_CHECK_LAUNCH();
 }
 
@@ -274,7 +399,21 @@ extern "C" int cips_torgb_bwd_w(const float* x, const float* drgb, float* partia
   if (M <= 0 || K <= 0) return (int)hipErrorInvalidValue;
   int chunks = cips_torgb_bwd_partials(M);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(torgb_bwd_w_partial_kernel, dim3(chunks), dim3(256), 0, st, x, drgb, partials, M, K);
+  if ((K & 3) || K > 2048) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(torgb_bwd_w_partial_kernel<false>, dim3(chunks), dim3(256), 0, st, (const void*)x,
+                     (const void*)nullptr, drgb, partials, M, K);
+  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 255) / 256), dim3(256), 0, st, partials, dw,
+                     dbias, chunks, K);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_torgb_bwd_w_x3(const void* x_hi, const void* x_lo, const float* drgb, float* partials,
+                                   float* dw, float* dbias, long long M, int K, cips_stream_t stream) {
+  if (M <= 0 || K <= 0 || (K & 3) || K > 2048) return (int)hipErrorInvalidValue;
+  int chunks = cips_torgb_bwd_partials(M);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(torgb_bwd_w_partial_kernel<true>, dim3(chunks), dim3(256), 0, st, x_hi, x_lo, drgb, partials,
+                     M, K);
   hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 255) / 256), dim3(256), 0, st, partials, dw,
                      dbias, chunks, K);
   return CIPS_CHECK_LAUNCH();

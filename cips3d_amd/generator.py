@@ -269,7 +269,7 @@ class CIPSNet(nn.Module):
         for idx, name in enumerate(names):
             if idx >= 3:
                 params += [self.to_rgbs[name].linear.weight, self.to_rgbs[name].linear.bias]
-        rgb = ops.InrHeadFunction.apply(len(names), input, *params)
+        rgb = ops.inr_head(len(names), input, *params)
         return self.tanh(rgb)
 
 

@@ -11,7 +11,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, SirenWeights, check
+from ._lib import GemmDesc, GemmX3Desc, SirenWeights, check
 
 LRELU_SLOPE = 0.2
 
@@ -30,7 +30,7 @@ def _chk(*tensors):
             continue
         if not t.is_cuda:
             raise RuntimeError("cips3d_amd ops need tensors on the GPU (no CPU fallback)")
-        if t.dtype != torch.float32 and t.dtype not in (torch.int32, torch.int64):
+        if t.dtype != torch.float32 and t.dtype not in (torch.int32, torch.int64, torch.bfloat16):
             raise RuntimeError(f"cips3d_amd ops are fp32 (got {t.dtype})")
         if not t.is_contiguous():
             raise RuntimeError("cips3d_amd ops need contiguous tensors")
@@ -446,6 +446,216 @@ class InrHeadFunction(torch.autograd.Function):
             flat.extend(gb)
         flat.extend(grads_rgb)
         return tuple(flat)
+
+
+# --------------------------------------------------------------------------------------
+# H4 on the bf16 matrix cores: 3-pass split GEMM ("bf16x3"), see csrc/gemm_bf16x3.hip
+# --------------------------------------------------------------------------------------
+import os as _os
+INR_MODE = _os.environ.get("CIPS_INR_MODE", "bf16x3")   # "bf16x3" (default, ~1e-5 rel. per layer) or "f32" (exact fp32 MFMA)
+BF = torch.bfloat16
+
+
+class Planes:
+    """An fp32 matrix carried as two bf16 planes (x = hi + lo)."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+    @staticmethod
+    def empty(*shape, device):
+        return Planes(torch.empty(*shape, device=device, dtype=BF), torch.empty(*shape, device=device, dtype=BF))
+
+    def float(self):
+        return self.hi.float() + self.lo.float()
+
+
+def gemm_x3(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, T=None, ldt=0, strideT=0,
+            mask_out=None, add=None, rgb_g=None, rgb_w=None, C_unmasked=None, mask=None, act=0, res=None):
+    """C[b][m][n] = epi(sum_k A[b][m][k] * B[b][n][k]); A, B, P, T, res: Planes; row-major aux use ld = N."""
+    lib = _lib.load()
+    d = GemmX3Desc()
+    d.A_hi, d.A_lo, d.B_hi, d.B_lo = _p(A.hi), _p(A.lo), _p(Bm.hi), _p(Bm.lo)
+    d.M, d.N, d.K, d.lda, d.ldb = M, N, K, lda, ldb
+    d.strideA, d.strideB, d.batch = strideA, strideB, batch
+    d.C, d.ldc, d.strideC = _p(C), N, M * N
+    d.P_hi, d.P_lo = (_p(P.hi), _p(P.lo)) if P is not None else (None, None)
+    d.ldp, d.strideP = N, M * N
+    d.T_hi, d.T_lo = (_p(T.hi), _p(T.lo)) if T is not None else (None, None)
+    d.ldt, d.strideT = ldt, strideT
+    d.mask_out, d.add, d.rgb_g, d.rgb_w = _p(mask_out), _p(add), _p(rgb_g), _p(rgb_w)
+    d.C_unmasked, d.mask = _p(C_unmasked), _p(mask)
+    d.act, d.slope = act, LRELU_SLOPE
+    d.res_hi, d.res_lo = (_p(res.hi), _p(res.lo)) if res is not None else (None, None)
+    check(lib.cips_gemm_bf16x3(C.byref(d), _stream()), "cips_gemm_bf16x3")
+
+
+def split_planes(x, want_p=True, want_t=True):
+    """x (B, rows, cols) fp32 -> Planes row-major (B,rows,cols) and transposed (B,cols,rows)."""
+    lib = _lib.load()
+    B, rows, cols = x.shape
+    dev = x.device
+    P = Planes.empty(B, rows, cols, device=dev) if want_p else None
+    T = Planes.empty(B, cols, rows, device=dev) if want_t else None
+    check(lib.cips_split_planes(_p(x), _p(P.hi) if P else None, _p(P.lo) if P else None,
+                                _p(T.hi) if T else None, _p(T.lo) if T else None, rows, cols, cols, cols, rows, B,
+                                rows * cols, rows * cols, rows * cols, _stream()), "cips_split_planes")
+    return P, T
+
+
+def modfc_prep_x3(W, s, eps=1e-8):
+    lib = _lib.load()
+    in_dim, out_dim = W.shape
+    B = s.shape[0]
+    dev = W.device
+    wb = Planes.empty(B, in_dim, out_dim, device=dev)
+    wbt = Planes.empty(B, out_dim, in_dim, device=dev)
+    demod = torch.empty(B, out_dim, device=dev)
+    check(lib.cips_modfc_prep_x3(_p(W), _p(s), _p(wb.hi), _p(wb.lo), _p(wbt.hi), _p(wbt.lo), _p(demod), B, in_dim,
+                                 out_dim, eps, _stream()), "cips_modfc_prep_x3")
+    return wb, wbt, demod
+
+
+def torgb_fwd_x3(xp, w, b, rgb2d, accumulate):
+    lib = _lib.load()
+    K = xp.hi.shape[-1]
+    M = xp.hi.numel() // K
+    check(lib.cips_torgb_fwd_x3(_p(xp.hi), _p(xp.lo), _p(w), _p(b), _p(rgb2d), M, K, 1 if accumulate else 0,
+                                _stream()), "cips_torgb_fwd_x3")
+
+
+def torgb_bwd_w_x3(xp, drgb2d):
+    lib = _lib.load()
+    K = xp.hi.shape[-1]
+    M = xp.hi.numel() // K
+    chunks = lib.cips_torgb_bwd_partials(M)
+    part = torch.empty(chunks, 4, K, device=drgb2d.device)
+    dw = torch.empty(3, K, device=drgb2d.device)
+    db = torch.empty(3, device=drgb2d.device)
+    check(lib.cips_torgb_bwd_w_x3(_p(xp.hi), _p(xp.lo), _p(drgb2d), _p(part), _p(dw), _p(db), M, K, _stream()),
+          "cips_torgb_bwd_w_x3")
+    return dw, db
+
+
+class InrHeadX3Function(torch.autograd.Function):
+    """Same contract as InrHeadFunction, on the bf16x3 GEMM.  Every activation / gradient lives in HBM
+    as bf16 hi/lo planes in both orientations (row-major for the forward / dX operand, transposed for
+    the dW operand), written by the producing GEMM's epilogue."""
+
+    @staticmethod
+    def forward(ctx, nblocks, x0, *params):
+        x0 = _c(x0.detach())
+        B, n, in0 = x0.shape
+        if n % 32 or in0 % 32:
+            raise RuntimeError("bf16x3 INR path needs pixels per image and feature width to be multiples of 32")
+        dev = x0.device
+        blocks = []
+        for k in range(nblocks):
+            blocks.append(tuple(_c(p.detach()) for p in params[4 * k:4 * k + 4]))
+        rgbp = [_c(p.detach()) for p in params[4 * nblocks:]]
+        _chk(x0, *[t for blk in blocks for t in blk], *rgbp)
+        xP, xT = split_planes(x0)
+        rgb = torch.empty(B, n, 3, device=dev)
+        first_rgb = True
+        saved = []
+        for k, (W1, s1, W2, s2) in enumerate(blocks):
+            cin, cout = W1.shape
+            wb1, wbt1, d1 = modfc_prep_x3(W1, s1)
+            a1P, a1T = Planes.empty(B, n, cout, device=dev), Planes.empty(B, cout, n, device=dev)
+            gemm_x3(xP, wbt1, n, cout, cin, cin, cin, B, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
+                    act=1)
+            wb2, wbt2, d2 = modfc_prep_x3(W2, s2)
+            skip = (k >= 4) and (cin == cout)
+            oP, oT = Planes.empty(B, n, cout, device=dev), Planes.empty(B, cout, n, device=dev)
+            if skip:
+                m2 = torch.empty(B, n, cout, device=dev, dtype=BF)
+                gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
+                        strideT=cout * n, act=1, res=xP, mask_out=m2)
+            else:
+                m2 = oP.hi
+                gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
+                        strideT=cout * n, act=1)
+            if k >= 3:
+                torgb_fwd_x3(oP, rgbp[2 * (k - 3)], rgbp[2 * (k - 3) + 1], rgb.view(B * n, 3), accumulate=not first_rgb)
+                first_rgb = False
+            # keep for backward: xT (dW1), a1 gate + a1T (dW2), out planes (ToRGB grad), m2 gate, weights
+            saved.append(dict(xT=xT, a1m=a1P.hi, a1T=a1T, oP=oP, m2=m2, wb1=wb1, d1=d1, wb2=wb2, d2=d2, skip=skip))
+            xP, xT = oP, oT
+        if first_rgb:
+            rgb.zero_()
+        ctx.nblocks, ctx.blocks, ctx.rgbp, ctx.saved = nblocks, blocks, rgbp, saved
+        ctx.dims = (B, n)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, drgb):
+        nblocks, blocks, rgbp, saved = ctx.nblocks, ctx.blocks, ctx.rgbp, ctx.saved
+        B, n = ctx.dims
+        drgb = _c(drgb)
+        dev = drgb.device
+        drgb2 = drgb.view(B * n, 3)
+        grads_blocks = [None] * nblocks
+        grads_rgb = [None] * len(rgbp)
+        width = blocks[-1][2].shape[1]
+        k = nblocks - 1
+        gP, gT = Planes.empty(B, n, width, device=dev), Planes.empty(B, width, n, device=dev)
+        Dout = None
+        if k >= 3:
+            # grad wrt out_k = drgb @ T_k as a K=32 zero-padded bf16x3 GEMM (gate of a2_k fused)
+            T = rgbp[2 * (k - 3)]
+            dpad = torch.zeros(B, n, 32, device=dev); dpad[..., :3] = drgb
+            tpad = torch.zeros(1, width, 32, device=dev); tpad[0, :, :3] = T.t()
+            dP, _ = split_planes(dpad, want_t=False)
+            tP, _ = split_planes(tpad, want_t=False)
+            Dout = torch.empty(B, n, width, device=dev) if saved[k]["skip"] else None
+            gemm_x3(dP, tP, n, width, 32, 32, 32, B, n * 32, 0, P=gP, T=gT, ldt=n, strideT=width * n,
+                    C_unmasked=Dout, mask=saved[k]["m2"])
+        else:
+            gP.hi.zero_(); gP.lo.zero_(); gT.hi.zero_(); gT.lo.zero_()
+            Dout = torch.zeros(B, n, width, device=dev) if saved[k]["skip"] else None
+        dx0 = None
+        for k in range(nblocks - 1, -1, -1):
+            sv = saved[k]
+            W1, s1, W2, s2 = blocks[k]
+            cin, cout = W1.shape
+            if k >= 3:
+                dT, dtau = torgb_bwd_w_x3(sv["oP"], drgb2)
+                grads_rgb[2 * (k - 3)], grads_rgb[2 * (k - 3) + 1] = dT, dtau
+            # ---- mod2 ----
+            gwb2 = torch.empty(B, cout, cout, device=dev)
+            gemm_x3(sv["a1T"], gT, cout, cout, n, n, n, B, cout * n, cout * n, C=gwb2)
+            dW2, ds2 = modfc_prep_bwd(W2, s2, sv["d2"], gwb2)
+            g1P, g1T = Planes.empty(B, n, cout, device=dev), Planes.empty(B, cout, n, device=dev)
+            gemm_x3(gP, sv["wb2"], n, cout, cout, cout, cout, B, n * cout, cout * cout, P=g1P, T=g1T, ldt=n,
+                    strideT=cout * n, mask=sv["a1m"])
+            # ---- mod1 ----
+            gwb1 = torch.empty(B, cin, cout, device=dev)
+            gemm_x3(sv["xT"], g1T, cin, cout, n, n, n, B, cin * n, cout * n, C=gwb1)
+            dW1, ds1 = modfc_prep_bwd(W1, s1, sv["d1"], gwb1)
+            grads_blocks[k] = (dW1, ds1, dW2, ds2)
+            if k == 0:
+                dx0 = torch.empty(B, n, cin, device=dev)
+                gemm_x3(g1P, sv["wb1"], n, cin, cout, cout, cout, B, n * cout, cin * cout, C=dx0)
+            else:
+                pv = saved[k - 1]
+                newD = torch.empty(B, n, cin, device=dev) if pv["skip"] else None
+                gP, gT = Planes.empty(B, n, cin, device=dev), Planes.empty(B, cin, n, device=dev)
+                gemm_x3(g1P, sv["wb1"], n, cin, cout, cout, cout, B, n * cout, cin * cout, P=gP, T=gT, ldt=n,
+                        strideT=cin * n, add=Dout if sv["skip"] else None,
+                        rgb_g=drgb2 if k - 1 >= 3 else None, rgb_w=rgbp[2 * (k - 1 - 3)] if k - 1 >= 3 else None,
+                        C_unmasked=newD, mask=pv["m2"])
+                Dout = newD
+        flat = [None, dx0]
+        for gb in grads_blocks:
+            flat.extend(gb)
+        flat.extend(grads_rgb)
+        return tuple(flat)
+
+
+def inr_head(nblocks, x0, *params):
+    fn = InrHeadX3Function if INR_MODE == "bf16x3" else InrHeadFunction
+    return fn.apply(nblocks, x0, *params)
 
 
 # --------------------------------------------------------------------------------------

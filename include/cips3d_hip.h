@@ -171,6 +171,42 @@ typedef struct cips_gemm_desc {
 int cips_gemm_f32(const cips_gemm_desc* d, cips_stream_t stream);
 
 /* ------------------------------------------------------------------ */
+/* fp32-grade GEMM on the bf16 matrix cores by 3-pass operand splitting */
+/* ("bf16x3": x = hi + lo in two bf16 planes; a*b ~ ah*bh + ah*bl + al*bh, */
+/* fp32 accumulate; ~1e-5 relative per layer against the 1e-3 parity bar). */
+/* Used for the 17 modulated 512x512 layers of the CIPS INR head        */
+/* (torch.bmm in exp/comm/models/mod_conv_fc.py:489 and its backward).  */
+/* ------------------------------------------------------------------ */
+typedef struct cips_gemm_x3_desc {
+  /* C[b][m][n] = epilogue( sum_k A[b][m][k] * B[b][n][k] ): both operands contraction-contiguous ("NT"),
+   * each given as two bf16 planes (uint16 storage). */
+  const void* A_hi; const void* A_lo; const void* B_hi; const void* B_lo;
+  int M, N, K;                 /* K % 32 == 0 */
+  int lda, ldb;                /* elements; multiples of 8 */
+  long long strideA, strideB;  /* elements between batches; multiples of 8 */
+  int batch;
+  /* outputs, any may be NULL */
+  float* C; int ldc; long long strideC;                /* fp32 row-major */
+  void* P_hi; void* P_lo; int ldp; long long strideP;  /* split planes, row-major [M][ldp] */
+  void* T_hi; void* T_lo; int ldt; long long strideT;  /* split planes, transposed [N][ldt] */
+  void* mask_out;              /* bf16 plane [M][ldp] of the value right after `act` (LeakyReLU gate source) */
+  /* epilogue, in this order: +add, +rgb term, store C_unmasked, *gate(mask), act, store mask_out, +res, outputs */
+  const float* add;            /* fp32 [M][ldc] */
+  const float* rgb_g; const float* rgb_w;   /* (batch*M,3), (3,N) */
+  float* C_unmasked;           /* fp32 [M][ldc] */
+  const void* mask;            /* bf16 plane [M][ldp]: v *= (mask > 0 ? 1 : slope) */
+  int act; float slope;        /* act 1: leaky_relu(slope) */
+  const void* res_hi; const void* res_lo;   /* residual planes [M][ldp], added after act */
+} cips_gemm_x3_desc;
+
+int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream);
+
+/* fp32 (rows, cols) [ldx] -> split bf16 planes row-major [rows][ldp] and/or transposed [cols][ldt]. */
+int cips_split_planes(const float* x, void* p_hi, void* p_lo, void* t_hi, void* t_lo, int rows, int cols,
+                      int ldx, int ldp, int ldt, int batch, long long stride_x, long long stride_p,
+                      long long stride_t, cips_stream_t stream);
+
+/* ------------------------------------------------------------------ */
 /* H4  CIPS INR head helpers (modulated FC, demodulated)                */
 /* replaces exp/comm/models/mod_conv_fc.py:470-489 (SinStyleMod.forward_bmm) */
 /* ------------------------------------------------------------------ */
@@ -179,6 +215,10 @@ int cips_gemm_f32(const cips_gemm_desc* d, cips_stream_t stream);
  * demod (B,out) = rsqrt(sum_in (W*(s+1))^2 + eps). */
 int cips_modfc_prep(const float* weight, const float* s, float* wb, float* wbt, float* demod,
                     int B, int in_dim, int out_dim, float eps, cips_stream_t stream);
+/* same, writing the bf16x3 operand planes: wb [in][out] and wbt [out][in], hi/lo each. */
+int cips_modfc_prep_x3(const float* weight, const float* s, void* wb_hi, void* wb_lo, void* wbt_hi,
+                       void* wbt_lo, float* demod, int B, int in_dim, int out_dim, float eps,
+                       cips_stream_t stream);
 /* backward of prep: gwb (B,in,out) = dL/d wb  ->  dweight (in,out), ds (B,in).
  * cbuf: caller-provided scratch of B*out floats. */
 int cips_modfc_prep_bwd(const float* weight, const float* s, const float* demod, const float* gwb,
@@ -194,6 +234,11 @@ int cips_torgb_fwd(const float* x, const float* w, const float* bias, float* rgb
 int cips_torgb_bwd_partials(long long M);
 int cips_torgb_bwd_w(const float* x, const float* drgb, float* partials, float* dw, float* dbias,
                      long long M, int K, cips_stream_t stream);
+/* split-plane input variants of the two ToRGB reductions (x = x_hi + x_lo, bf16 planes [M][K]). */
+int cips_torgb_fwd_x3(const void* x_hi, const void* x_lo, const float* w, const float* bias, float* rgb,
+                      long long M, int K, int accumulate, cips_stream_t stream);
+int cips_torgb_bwd_w_x3(const void* x_hi, const void* x_lo, const float* drgb, float* partials, float* dw,
+                        float* dbias, long long M, int K, cips_stream_t stream);
 /* dx (M,K) = drgb (M,3) @ w (3,K) [+ add]; optional copy before masking; out = dx * (mask>0 ? 1 : slope)
  * (the LeakyReLU gate of the layer below, fused).  mask / add / out_unmasked may be NULL. */
 int cips_torgb_bwd_x(const float* drgb, const float* w, const float* add, const float* mask, float slope,
