@@ -6,6 +6,7 @@ kernel on the hot path is a hand-written HIP kernel in libcips3d_hip.so.  There 
 fallback: tensors must live on a ROCm device and the extension must be built.
 """
 import ctypes as C
+import ctypes as _ct
 import math
 
 import torch
@@ -488,7 +489,7 @@ def gemm_x3(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, T
     d.C_unmasked, d.mask = _p(C_unmasked), _p(mask)
     d.act, d.slope = act, LRELU_SLOPE
     d.res_hi, d.res_lo = (_p(res.hi), _p(res.lo)) if res is not None else (None, None)
-    check(lib.cips_gemm_bf16x3(C.byref(d), _stream()), "cips_gemm_bf16x3")
+    check(lib.cips_gemm_bf16x3(_ct.byref(d), _stream()), "cips_gemm_bf16x3")
 
 
 def split_planes(x, want_p=True, want_t=True):
