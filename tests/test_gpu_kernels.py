@@ -340,11 +340,46 @@ def test_inr_head_forward_backward(mode):
         if k in refg:
             e = rel_err(p.grad, refg[k])
             worst = max(worst, e)
-            assert e < 5 * TOL, (k, e)      # one LeakyReLU gate flip in 2*192 rows moves a weight grad by ~2e-3
+            # LeakyReLU gate flips (pre-activation within rounding of 0): ~1 per 1e6 activations in fp32,
+            # ~10x more with bf16x3's ~1e-5 pre-activation error; each moves a weight grad by ~0.8/sqrt(rows*512)
+            assert e < (5 * TOL if mode == "f32" else 2e-2), (k, e)
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0, k
     print(f"inr head [{mode}] worst grad rel err {worst:.3e}")
-    assert rel_err(fd.grad, rf) < 5 * TOL and rel_err(wd.grad, rw) < 5 * TOL
+    assert rel_err(fd.grad, rf) < (5 * TOL if mode == "f32" else 2e-2)
+    assert rel_err(wd.grad, rw) < (5 * TOL if mode == "f32" else 2e-2)
+
+
+def test_inr_head_bf16x3_vs_f32_at_scale():
+    """At realistic row counts the gate-flip noise averages out: bf16x3 and exact-fp32 HIP paths must agree
+    to well within the 1e-3 bar on every gradient."""
+    from cips3d_amd import ops
+    b, n = 2, 4096
+    G = seeded_generator(7).to(dev())
+    g = torch.Generator().manual_seed(7)
+    fea = torch.randn(b, n, 32, generator=g).to(dev()); w_inr = torch.randn(b, 512, generator=g).to(dev())
+    up = torch.randn(b, n, 3, generator=g).to(dev())
+    res = {}
+    old = ops.INR_MODE
+    try:
+        for mode in ("f32", "bf16x3"):
+            ops.INR_MODE = mode
+            G.zero_grad()
+            fd = fea.clone().requires_grad_(True); wd = w_inr.clone().requires_grad_(True)
+            out = G.inr_net(fd, {k: wd for k in G.inr_net.style_dim_dict})
+            (out * up).sum().backward()
+            torch.cuda.synchronize()
+            res[mode] = (out.detach(), fd.grad.clone(), wd.grad.clone(),
+                         {k: p.grad.clone() for k, p in G.inr_net.named_parameters() if p.grad is not None})
+    finally:
+        ops.INR_MODE = old
+    a, c = res["f32"], res["bf16x3"]
+    e_out = max_rel(c[0], a[0])
+    errs = {k: rel_err(c[3][k], a[3][k]) for k in a[3]}
+    worst = max(errs, key=errs.get)
+    print(f"bf16x3 vs f32 @ {b}x{n} rows: out max_rel {e_out:.3e}, dfea {rel_err(c[1], a[1]):.3e}, "
+          f"dstyle {rel_err(c[2], a[2]):.3e}, worst param grad {errs[worst]:.3e} at {worst}")
+    assert e_out < 1e-4 and rel_err(c[1], a[1]) < TOL and rel_err(c[2], a[2]) < TOL and errs[worst] < TOL
 
 
 # --------------------------------------------------------------------------------------
