@@ -39,7 +39,8 @@ constexpr int OFF_ALO = OFF_AHI + BM * ROWB;
 constexpr int OFF_BHI = OFF_ALO + BM * ROWB;
 constexpr int OFF_BLO = OFF_BHI + BN * ROWB;
 constexpr int STAGE = OFF_BLO + BN * ROWB;   // 61440 B
-constexpr int SMEM_BYTES = 2 * STAGE;        // 122880 B
+constexpr int SMEM_EPI = 8 * 2 * 64 * 72 * 2;   // per-wave epilogue scratch: 147456 B
+constexpr int SMEM_BYTES = (2 * STAGE > SMEM_EPI) ? 2 * STAGE : SMEM_EPI;
 
 struct Args {
   cips_gemm_x3_desc d;
@@ -93,10 +94,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_kernel(Args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging map: 16-byte chunks (8 bf16); chunk c -> row c>>2, k-chunk c&3
-  uint4 ra[4], rb[2];
+  // staging map: 16-byte chunks (8 bf16); chunk c -> row c>>2, k-chunk c&3.
+  // Two register sets: the loads for tile t+2 are issued while tile t is multiplied and tile t+1 sits in
+  // the other LDS stage, i.e. every global load has two full MFMA phases (~3000 cycles) to land.
+  struct Regs { uint4 a[4], b[2]; };
+  Regs R0, R1;
   const int kc = tid & 3;
-  auto load_tile = [&](int k0) {
+  auto load_tile = [&](Regs& R, int k0) {
     const int gk = k0 + kc * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_kernel(Args g) {
         vh = *reinterpret_cast<const uint4*>(Ahi + (long long)gm * d.lda + gk);
         vl = *reinterpret_cast<const uint4*>(Alo + (long long)gm * d.lda + gk);
       }
-      ra[2 * i] = vh; ra[2 * i + 1] = vl;
+      R.a[2 * i] = vh; R.a[2 * i + 1] = vl;
     }
     {
       const int r = tid >> 2;
@@ -117,30 +121,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_kernel(Args g) {
         vh = *reinterpret_cast<const uint4*>(Bhi + (long long)gn * d.ldb + gk);
         vl = *reinterpret_cast<const uint4*>(Blo + (long long)gn * d.ldb + gk);
       }
-      rb[0] = vh; rb[1] = vl;
+      R.b[0] = vh; R.b[1] = vl;
     }
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](const Regs& R, int stage) {
     unsigned char* s = smem + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = (tid >> 2) + 128 * i;
-      *reinterpret_cast<uint4*>(s + OFF_AHI + r * ROWB + kc * 16) = ra[2 * i];
-      *reinterpret_cast<uint4*>(s + OFF_ALO + r * ROWB + kc * 16) = ra[2 * i + 1];
+      *reinterpret_cast<uint4*>(s + OFF_AHI + r * ROWB + kc * 16) = R.a[2 * i];
+      *reinterpret_cast<uint4*>(s + OFF_ALO + r * ROWB + kc * 16) = R.a[2 * i + 1];
     }
     const int r = tid >> 2;
-    *reinterpret_cast<uint4*>(s + OFF_BHI + r * ROWB + kc * 16) = rb[0];
-    *reinterpret_cast<uint4*>(s + OFF_BLO + r * ROWB + kc * 16) = rb[1];
+    *reinterpret_cast<uint4*>(s + OFF_BHI + r * ROWB + kc * 16) = R.b[0];
+    *reinterpret_cast<uint4*>(s + OFF_BLO + r * ROWB + kc * 16) = R.b[1];
   };
-
-  const int nk = (K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);
-    const unsigned char* s = smem + (kt & 1) * STAGE;
+  auto compute = [&](int stage) {
+    const unsigned char* s = smem + stage * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 ah[2], al[2], bh[2], bl[2];
@@ -165,11 +162,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_kernel(Args g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tile((kt + 1) & 1);
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  load_tile(R0, 0);
+  store_tile(R0, 0);
+  if (nk > 1) load_tile(R1, BK);        // tile 1 -> R1 (in flight)
+  __syncthreads();
+  // invariant at the top of iteration kt: LDS[kt&1] = tile kt; tile kt+1 is in R1 (kt even) / R0 (kt odd)
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) load_tile(R0, (kt + 2) * BK);
+    compute(0);
+    if (kt + 1 < nk) store_tile(R1, 1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) load_tile(R1, (kt + 3) * BK);
+    compute(1);
+    if (kt + 2 < nk) store_tile(R0, 0);
     __syncthreads();
   }
 
   // ---------------- epilogue ----------------
+  // Values are finalised per element (aux tensors read with plain coalesced loads), split into hi/lo and
+  // staged through a per-wave LDS scratch so that both orientations leave the CU as 16-byte stores:
+  // phase A row-major image [64 rows][72] -> P planes, phase B transposed image [64 cols][72] -> T planes.
   const long long cb = (long long)bz * d.strideC;
   const long long pb = (long long)bz * d.strideP;
   const long long tb = (long long)bz * d.strideT;
@@ -179,61 +195,110 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_kernel(Args g) {
   u16* Mout = (u16*)d.mask_out;
   const u16* Rhi = (const u16*)d.res_hi; const u16* Rlo = (const u16*)d.res_lo;
   const u16* Mk = (const u16*)d.mask;
+  constexpr int PITCH = 72;                                    // bf16 elements per scratch row (144 B)
+  u16* sc_hi = reinterpret_cast<u16*>(smem) + wave * (2 * 64 * PITCH);
+  u16* sc_lo = sc_hi + 64 * PITCH;
+  const int wrow0 = m0 + wm * 64, wcol0 = n0 + wn * 64;
+  u16 vh[2][2][16], vl[2][2][16];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + l31;
+      const int col = wcol0 + j * 32 + l31;
       const bool colok = col < N;
       float rw0 = 0.f, rw1 = 0.f, rw2 = 0.f;
       if (d.rgb_g && colok) { rw0 = d.rgb_w[col]; rw1 = d.rgb_w[N + col]; rw2 = d.rgb_w[2 * N + col]; }
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        u16 th[4], tl[4];
-        const int row0 = m0 + wm * 64 + i * 32 + 8 * rg + 4 * hf;
+      for (int r = 0; r < 16; ++r) {
+        const int row = wrow0 + i * 32 + mfma_row(r, hf);
+        float v = acc[i][j][r];
+        u16 h = 0, l = 0;
+        if (row < M && colok) {
+          if (d.add) v += d.add[cb + (long long)row * d.ldc + col];
+          if (d.rgb_g) {
+            const float* gp = d.rgb_g + ((long long)bz * M + row) * 3;
+            v = fmaf(gp[0], rw0, fmaf(gp[1], rw1, fmaf(gp[2], rw2, v)));
+          }
+          if (d.C_unmasked) d.C_unmasked[cb + (long long)row * d.ldc + col] = v;
+          if (Mk) {
+            const u16 mb = Mk[pb + (long long)row * d.ldp + col];
+            const bool pos = ((mb & 0x8000u) == 0) && ((mb & 0x7fffu) != 0);
+            v *= pos ? 1.f : d.slope;
+          }
+          if (d.act) v = lrelu(v, d.slope);
+          if (Mout) Mout[pb + (long long)row * d.ldp + col] = f2bf(v);
+          if (Rhi) {
+            const long long o = pb + (long long)row * d.ldp + col;
+            v += bf2f(Rhi[o]) + bf2f(Rlo[o]);
+          }
+          if (C) C[cb + (long long)row * d.ldc + col] = v;
+          split2(v, h, l);
+        }
+        vh[i][j][r] = h; vl[i][j][r] = l;
+      }
+    }
+  }
+  const bool vec_p = Phi && ((d.ldp & 7) == 0) && ((d.strideP & 7) == 0);
+  const bool vec_t = Thi && ((d.ldt & 7) == 0) && ((d.strideT & 7) == 0);
+  if (Phi) {
+    __syncthreads();   // main-loop LDS reads are done everywhere; scratch regions are per wave from here on
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = row0 + e;
-          float v = acc[i][j][4 * rg + e];
-          th[e] = 0; tl[e] = 0;
-          if (row < M && colok) {
-            if (d.add) v += d.add[cb + (long long)row * d.ldc + col];
-            if (d.rgb_g) {
-              const float* gp = d.rgb_g + ((long long)bz * M + row) * 3;
-              v = fmaf(gp[0], rw0, fmaf(gp[1], rw1, fmaf(gp[2], rw2, v)));
-            }
-            if (d.C_unmasked) d.C_unmasked[cb + (long long)row * d.ldc + col] = v;
-            if (Mk) {
-              const u16 mb = Mk[pb + (long long)row * d.ldp + col];
-              const bool pos = ((mb & 0x8000u) == 0) && ((mb & 0x7fffu) != 0);
-              v *= pos ? 1.f : d.slope;
-            }
-            if (d.act) v = lrelu(v, d.slope);
-            if (Mout) Mout[pb + (long long)row * d.ldp + col] = f2bf(v);
-            if (Rhi) {
-              const long long o = pb + (long long)row * d.ldp + col;
-              v += bf2f(Rhi[o]) + bf2f(Rlo[o]);
-            }
-            if (C) C[cb + (long long)row * d.ldc + col] = v;
-            u16 h, l;
-            split2(v, h, l);
-            th[e] = h; tl[e] = l;
-            if (Phi) {
-              const long long o = pb + (long long)row * d.ldp + col;
-              Phi[o] = h; Plo[o] = l;
-            }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = (i * 32 + mfma_row(r, hf)) * PITCH + j * 32 + l31;
+          sc_hi[o] = vh[i][j][r]; sc_lo[o] = vl[i][j][r];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int id = lane + 64 * c;
+      const int rr = id >> 3, c8 = (id & 7) * 8;
+      const int row = wrow0 + rr, col = wcol0 + c8;
+      if (row < M && col < N) {
+        const long long o = pb + (long long)row * d.ldp + col;
+        if (vec_p && col + 7 < N) {
+          *reinterpret_cast<uint4*>(Phi + o) = *reinterpret_cast<const uint4*>(sc_hi + rr * PITCH + c8);
+          *reinterpret_cast<uint4*>(Plo + o) = *reinterpret_cast<const uint4*>(sc_lo + rr * PITCH + c8);
+        } else {
+          for (int e = 0; e < 8 && col + e < N; ++e) {
+            Phi[o + e] = sc_hi[rr * PITCH + c8 + e]; Plo[o + e] = sc_lo[rr * PITCH + c8 + e];
           }
         }
-        if (Thi && colok) {
-          // transposed planes: 4 consecutive rows of this column -> one 8-byte store per plane
-          const long long o = tb + (long long)col * d.ldt + row0;
-          if (row0 + 3 < M) {
-            *reinterpret_cast<uint2*>(Thi + o) = make_uint2(th[0] | ((unsigned)th[1] << 16), th[2] | ((unsigned)th[3] << 16));
-            *reinterpret_cast<uint2*>(Tlo + o) = make_uint2(tl[0] | ((unsigned)tl[1] << 16), tl[2] | ((unsigned)tl[3] << 16));
-          } else {
+      }
+    }
+  }
+  if (Thi) {
+    __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (row0 + e < M) { Thi[o + e] = th[e]; Tlo[o + e] = tl[e]; }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          // 4 consecutive rows (i*32 + 8*rg + 4*hf + 0..3) of column j*32+l31 -> one 8-byte LDS write
+          const int o = (j * 32 + l31) * PITCH + i * 32 + 8 * rg + 4 * hf;
+          *reinterpret_cast<uint2*>(sc_hi + o) = make_uint2(vh[i][j][4 * rg] | ((unsigned)vh[i][j][4 * rg + 1] << 16),
+                                                            vh[i][j][4 * rg + 2] | ((unsigned)vh[i][j][4 * rg + 3] << 16));
+          *reinterpret_cast<uint2*>(sc_lo + o) = make_uint2(vl[i][j][4 * rg] | ((unsigned)vl[i][j][4 * rg + 1] << 16),
+                                                            vl[i][j][4 * rg + 2] | ((unsigned)vl[i][j][4 * rg + 3] << 16));
+        }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int id = lane + 64 * c;
+      const int cc = id >> 3, r8 = (id & 7) * 8;      // transposed image: row = output column, 8 consecutive m
+      const int col = wcol0 + cc, row = wrow0 + r8;
+      if (col < N && row < M) {
+        const long long o = tb + (long long)col * d.ldt + row;
+        if (vec_t && row + 7 < M) {
+          *reinterpret_cast<uint4*>(Thi + o) = *reinterpret_cast<const uint4*>(sc_hi + cc * PITCH + r8);
+          *reinterpret_cast<uint4*>(Tlo + o) = *reinterpret_cast<const uint4*>(sc_lo + cc * PITCH + r8);
+        } else {
+          for (int e = 0; e < 8 && row + e < M; ++e) {
+            Thi[o + e] = sc_hi[cc * PITCH + r8 + e]; Tlo[o + e] = sc_lo[cc * PITCH + r8 + e];
           }
         }
       }
@@ -276,7 +341,6 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
   if ((d->K & 31) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
     return (int)hipErrorInvalidValue;
-  if (d->T_hi && ((d->ldt & 3) || (d->strideT & 3))) return (int)hipErrorInvalidValue;
   Args g;
   g.d = *d;
   g.tiles_m = (d->M + BM - 1) / BM;

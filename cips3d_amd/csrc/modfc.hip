@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const void* __restrict__
   }
 }
 
-constexpr int TORGB_ROWS = 64;  // rows per partial chunk
+constexpr int TORGB_ROWS = 128;  // rows per partial chunk
 
 // partial[chunk][c][k] = sum_{m in chunk} drgb[m][c] x[m][k] ; partial[chunk][3][0..2] = sum drgb
 // 256 threads: thread -> 4 consecutive k (float4) x row parity group; K <= 512 per pass.
@@ -287,17 +287,22 @@ __global__ __launch_bounds__(256) void torgb_bwd_w_partial_kernel(const void* __
   }
 }
 
+// sum the per-chunk partials: block -> 32 consecutive outputs x 8 chunk groups, fixed combine order
 __global__ __launch_bounds__(256) void torgb_bwd_w_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                                  float* __restrict__ dbias, int chunks, int K) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < 3 * K) {
-    float acc = 0.f;
-    for (int c = 0; c < chunks; ++c) acc += partial[(long long)c * 4 * K + idx];
-    dw[idx] = acc;
-  } else if (idx < 3 * K + 3) {
-    float acc = 0.f;
-    for (int c = 0; c < chunks; ++c) acc += partial[(long long)c * 4 * K + idx];
-    dbias[idx - 3 * K] = acc;
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, gi = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + c;
+  float acc = 0.f;
+  if (idx < 3 * K + 3)
+    for (int ch = gi; ch < chunks; ch += 8) acc += partial[(long long)ch * 4 * K + idx];
+  red[gi][c] = acc;
+  __syncthreads();
+  if (gi == 0 && idx < 3 * K + 3) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][c];
+    if (idx < 3 * K) dw[idx] = t; else dbias[idx - 3 * K] = t;
   }
 }
 
@@ -399,22 +404,22 @@ extern "C" int cips_torgb_bwd_w(const float* x, const float* drgb, float* partia
   if (M <= 0 || K <= 0) return (int)hipErrorInvalidValue;
   int chunks = cips_torgb_bwd_partials(M);
   hipStream_t st = (hipStream_t)stream;
-  if ((K & 3) || K > 2048) return (int)hipErrorInvalidValue;
+  if ((K & 3) || K > 512) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(torgb_bwd_w_partial_kernel<false>, dim3(chunks), dim3(256), 0, st, (const void*)x,
                      (const void*)nullptr, drgb, partials, M, K);
-  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 255) / 256), dim3(256), 0, st, partials, dw,
+  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 31) / 32), dim3(256), 0, st, partials, dw,
                      dbias, chunks, K);
   return CIPS_CHECK_LAUNCH();
 }
 
 extern "C" int cips_torgb_bwd_w_x3(const void* x_hi, const void* x_lo, const float* drgb, float* partials,
                                    float* dw, float* dbias, long long M, int K, cips_stream_t stream) {
-  if (M <= 0 || K <= 0 || (K & 3) || K > 2048) return (int)hipErrorInvalidValue;
+  if (M <= 0 || K <= 0 || (K & 3) || K > 512) return (int)hipErrorInvalidValue;
   int chunks = cips_torgb_bwd_partials(M);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(torgb_bwd_w_partial_kernel<true>, dim3(chunks), dim3(256), 0, st, x_hi, x_lo, drgb, partials,
                      M, K);
-  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 255) / 256), dim3(256), 0, st, partials, dw,
+  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 31) / 32), dim3(256), 0, st, partials, dw,
                      dbias, chunks, K);
   return CIPS_CHECK_LAUNCH();
 }
