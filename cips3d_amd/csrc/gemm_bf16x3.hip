@@ -26,21 +26,30 @@
 // k-tile.  Workgroup ids are remapped per XCD like the fp32 kernel.
 #include "common.h"
 #include "../../include/cips3d_hip.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
-constexpr int BM = 256, BN = 128, BK = 32;
+constexpr int BN = 128, BK = 32;
 constexpr int ROWB = 80;                     // padded LDS row pitch in bytes (32 bf16 = 64 B + 16 B pad)
-constexpr int OFF_AHI = 0;
-constexpr int OFF_ALO = OFF_AHI + BM * ROWB;
-constexpr int OFF_BHI = OFF_ALO + BM * ROWB;
-constexpr int OFF_BLO = OFF_BHI + BN * ROWB;
-constexpr int STAGE = OFF_BLO + BN * ROWB;   // 61440 B
-constexpr int SMEM_EPI = 8 * 2 * 64 * 72 * 2;   // per-wave epilogue scratch: 147456 B
-constexpr int SMEM_BYTES = (2 * STAGE > SMEM_EPI) ? 2 * STAGE : SMEM_EPI;
+// Workgroup tile (64*WM) x 128: WM = 4 -> 256x128, 8 waves, 1 workgroup per CU (120 KB LDS);
+//                               WM = 2 -> 128x128, 4 waves, 2 workgroups per CU (80 KB LDS each), so one
+// workgroup's barriers / prologue / epilogue overlap the other's MFMA phase.
+template <int WM> struct Cfg {
+  static constexpr int BM = 64 * WM;
+  static constexpr int THREADS = WM * 2 * 64;
+  static constexpr int NB = 512 / THREADS;              // B chunks per thread per plane
+  static constexpr int OFF_AHI = 0;
+  static constexpr int OFF_ALO = OFF_AHI + BM * ROWB;
+  static constexpr int OFF_BHI = OFF_ALO + BM * ROWB;
+  static constexpr int OFF_BLO = OFF_BHI + BN * ROWB;
+  static constexpr int STAGE = OFF_BLO + BN * ROWB;
+  static constexpr int SMEM_EPI = WM * 2 * 2 * 64 * 72 * 2;   // per-wave epilogue scratch
+  static constexpr int SMEM_BYTES = (2 * STAGE > SMEM_EPI) ? 2 * STAGE : SMEM_EPI;
+};
 
 struct Args {
   cips_gemm_x3_desc d;
@@ -58,7 +67,11 @@ __device__ __forceinline__ void split2(float v, u16& hi, u16& lo) {
   lo = f2bf(v - bf2f(hi));
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16x3_kernel(Args g) {
+template <int WM>
+__global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g) {
+  using CF = Cfg<WM>;
+  constexpr int BM = CF::BM, OFF_AHI = CF::OFF_AHI, OFF_ALO = CF::OFF_ALO, OFF_BHI = CF::OFF_BHI, OFF_BLO = CF::OFF_BLO,
+                STAGE = CF::STAGE, NB = CF::NB, THREADS = CF::THREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cips_gemm_x3_desc& d = g.d;
 
@@ -97,14 +110,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_kernel(Args g) {
   // staging map: 16-byte chunks (8 bf16); chunk c -> row c>>2, k-chunk c&3.
   // Two register sets: the loads for tile t+2 are issued while tile t is multiplied and tile t+1 sits in
   // the other LDS stage, i.e. every global load has two full MFMA phases (~3000 cycles) to land.
-  struct Regs { uint4 a[4], b[2]; };
+  struct Regs { uint4 a[4], b[2 * NB]; };
   Regs R0, R1;
   const int kc = tid & 3;
   auto load_tile = [&](Regs& R, int k0) {
     const int gk = k0 + kc * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = (tid >> 2) + 128 * i;
+      const int r = (tid >> 2) + (THREADS / 4) * i;
       const int gm = m0 + r;
       uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
       if (gm < M && gk < K) {
@@ -113,28 +126,32 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_kernel(Args g) {
       }
       R.a[2 * i] = vh; R.a[2 * i + 1] = vl;
     }
-    {
-      const int r = tid >> 2;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = (tid >> 2) + (THREADS / 4) * i;
       const int gn = n0 + r;
       uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
       if (gn < N && gk < K) {
         vh = *reinterpret_cast<const uint4*>(Bhi + (long long)gn * d.ldb + gk);
         vl = *reinterpret_cast<const uint4*>(Blo + (long long)gn * d.ldb + gk);
       }
-      R.b[0] = vh; R.b[1] = vl;
+      R.b[2 * i] = vh; R.b[2 * i + 1] = vl;
     }
   };
   auto store_tile = [&](const Regs& R, int stage) {
     unsigned char* s = smem + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = (tid >> 2) + 128 * i;
+      const int r = (tid >> 2) + (THREADS / 4) * i;
       *reinterpret_cast<uint4*>(s + OFF_AHI + r * ROWB + kc * 16) = R.a[2 * i];
       *reinterpret_cast<uint4*>(s + OFF_ALO + r * ROWB + kc * 16) = R.a[2 * i + 1];
     }
-    const int r = tid >> 2;
-    *reinterpret_cast<uint4*>(s + OFF_BHI + r * ROWB + kc * 16) = R.b[0];
-    *reinterpret_cast<uint4*>(s + OFF_BLO + r * ROWB + kc * 16) = R.b[1];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = (tid >> 2) + (THREADS / 4) * i;
+      *reinterpret_cast<uint4*>(s + OFF_BHI + r * ROWB + kc * 16) = R.b[2 * i];
+      *reinterpret_cast<uint4*>(s + OFF_BLO + r * ROWB + kc * 16) = R.b[2 * i + 1];
+    }
   };
   auto compute = [&](int stage) {
     const unsigned char* s = smem + stage * STAGE;
@@ -341,19 +358,26 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
   if ((d->K & 31) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
     return (int)hipErrorInvalidValue;
+  // tile choice: 128x128 (2 workgroups / CU) unless CIPS_X3_TILE=256 asks for the 256x128 single-workgroup form
+  static int tile = 0;
+  if (!tile) {
+    const char* e = getenv("CIPS_X3_TILE");
+    tile = (e && atoi(e) == 256) ? 256 : 128;
+    hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<4>::SMEM_BYTES);
+    hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<2>::SMEM_BYTES);
+  }
+  const int BMh = tile;
   Args g;
   g.d = *d;
-  g.tiles_m = (d->M + BM - 1) / BM;
+  g.tiles_m = (d->M + BMh - 1) / BMh;
   g.tiles_n = (d->N + BN - 1) / BN;
   long long total = (long long)g.tiles_m * g.tiles_n * d->batch;
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(g.total), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
+  if (tile == 256)
+    hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3(g.total), dim3(512), Cfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, dim3(g.total), dim3(256), Cfg<2>::SMEM_BYTES, (hipStream_t)stream, g);
   return CIPS_CHECK_LAUNCH();
 }
 

@@ -187,7 +187,7 @@ class SirenFunction(torch.autograd.Function):
         gemm(dac, h2, Gc, 64, 128, Kc, 64, 128, 128, batch=B * sp, strideA=Kc * 64, strideB=Kc * 128,
              strideC=64 * 128, a_kmajor=True)
         Gc = Gc.view(B, sp, 64, 128).sum(1)
-        spf = _split_k(BP, 64)
+        spf = _split_k(BP, 1024)
         Kf = BP // spf
         Gf = torch.empty(spf, 32, 64, device=dev)        # dfeat^T @ hc (no per-image scale)
         gemm(dfeat, hc, Gf, 32, 64, Kf, 32, 64, 64, batch=spf, strideA=Kf * 32, strideB=Kf * 64,
