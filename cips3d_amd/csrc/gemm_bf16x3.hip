@@ -200,127 +200,203 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   }
 
   // ---------------- epilogue ----------------
-  // Values are finalised per element (aux tensors read with plain coalesced loads), split into hi/lo and
-  // staged through a per-wave LDS scratch so that both orientations leave the CU as 16-byte stores:
-  // phase A row-major image [64 rows][72] -> P planes, phase B transposed image [64 cols][72] -> T planes.
+  // Every auxiliary tensor enters and every result leaves the CU through a per-wave LDS scratch tile
+  // (64x64, pitch 72) with 16-byte global accesses; the per-lane MFMA-layout values only ever touch LDS.
   const long long cb = (long long)bz * d.strideC;
   const long long pb = (long long)bz * d.strideP;
   const long long tb = (long long)bz * d.strideT;
-  float* C = d.C;
   u16* Phi = (u16*)d.P_hi; u16* Plo = (u16*)d.P_lo;
   u16* Thi = (u16*)d.T_hi; u16* Tlo = (u16*)d.T_lo;
-  u16* Mout = (u16*)d.mask_out;
-  const u16* Rhi = (const u16*)d.res_hi; const u16* Rlo = (const u16*)d.res_lo;
-  const u16* Mk = (const u16*)d.mask;
-  constexpr int PITCH = 72;                                    // bf16 elements per scratch row (144 B)
+  constexpr int PITCH = 72;
   u16* sc_hi = reinterpret_cast<u16*>(smem) + wave * (2 * 64 * PITCH);
   u16* sc_lo = sc_hi + 64 * PITCH;
+  float* sc_f = reinterpret_cast<float*>(sc_hi);               // same bytes viewed as one fp32 [64][72] image
   const int wrow0 = m0 + wm * 64, wcol0 = n0 + wn * 64;
-  u16 vh[2][2][16], vl[2][2][16];
+  const bool vec_c = ((d.ldc & 3) == 0) && ((d.strideC & 3) == 0);
+  const bool vec_p = ((d.ldp & 7) == 0) && ((d.strideP & 7) == 0);
+  const bool vec_t = ((d.ldt & 7) == 0) && ((d.strideT & 7) == 0);
+
+  float v[2][2][16];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[i][j][r] = acc[i][j][r];
+
+  // fp32 [M][ldc] tile <-> scratch (1024 float4 chunks per wave tile)
+  auto tile_in_f32 = [&](const float* base) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int id = lane + 64 * c, rr = id >> 4, c4 = (id & 15) * 4;
+      const int row = wrow0 + rr, col = wcol0 + c4;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < M && col < N) {
+        const float* p = base + cb + (long long)row * d.ldc + col;
+        if (vec_c && col + 3 < N) t = *reinterpret_cast<const float4*>(p);
+        else { t.x = p[0]; if (col + 1 < N) t.y = p[1]; if (col + 2 < N) t.z = p[2]; if (col + 3 < N) t.w = p[3]; }
+      }
+      *reinterpret_cast<float4*>(sc_f + rr * PITCH + c4) = t;
+    }
+  };
+  auto tile_out_f32 = [&](float* base) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int id = lane + 64 * c, rr = id >> 4, c4 = (id & 15) * 4;
+      const int row = wrow0 + rr, col = wcol0 + c4;
+      if (row < M && col < N) {
+        const float4 t = *reinterpret_cast<const float4*>(sc_f + rr * PITCH + c4);
+        float* p = base + cb + (long long)row * d.ldc + col;
+        if (vec_c && col + 3 < N) *reinterpret_cast<float4*>(p) = t;
+        else { p[0] = t.x; if (col + 1 < N) p[1] = t.y; if (col + 2 < N) p[2] = t.z; if (col + 3 < N) p[3] = t.w; }
+      }
+    }
+  };
+  // bf16 [M][ldp] tile <-> one scratch image (512 chunks of 8)
+  auto tile_in_bf16 = [&](const u16* base, u16* img) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int id = lane + 64 * c, rr = id >> 3, c8 = (id & 7) * 8;
+      const int row = wrow0 + rr, col = wcol0 + c8;
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (row < M && col < N) {
+        const u16* p = base + pb + (long long)row * d.ldp + col;
+        if (vec_p && col + 7 < N) t = *reinterpret_cast<const uint4*>(p);
+        else {
+          u16 e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int q = 0; q < 8 && col + q < N; ++q) e[q] = p[q];
+          t = make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                         e[6] | ((unsigned)e[7] << 16));
+        }
+      }
+      *reinterpret_cast<uint4*>(img + rr * PITCH + c8) = t;
+    }
+  };
+  auto tile_out_bf16 = [&](u16* base, const u16* img) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int id = lane + 64 * c, rr = id >> 3, c8 = (id & 7) * 8;
+      const int row = wrow0 + rr, col = wcol0 + c8;
+      if (row < M && col < N) {
+        u16* p = base + pb + (long long)row * d.ldp + col;
+        if (vec_p && col + 7 < N) *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(img + rr * PITCH + c8);
+        else for (int q = 0; q < 8 && col + q < N; ++q) p[q] = img[rr * PITCH + c8 + q];
+      }
+    }
+  };
+#define CIPS_FOR_ELEMS(BODY)                                              \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                            \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                            \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                         \
+    const int so = (i * 32 + mfma_row(r, hf)) * PITCH + j * 32 + l31;      \
+    BODY                                                                   \
+  }
+
+  __syncthreads();   // main-loop LDS reads are done everywhere; scratch regions are per wave from here on
+  if (d.add) {
+    tile_in_f32(d.add);
+    __syncthreads();
+    CIPS_FOR_ELEMS(v[i][j][r] += sc_f[so];)
+    __syncthreads();
+  }
+  if (d.rgb_g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = wcol0 + j * 32 + l31;
-      const bool colok = col < N;
       float rw0 = 0.f, rw1 = 0.f, rw2 = 0.f;
-      if (d.rgb_g && colok) { rw0 = d.rgb_w[col]; rw1 = d.rgb_w[N + col]; rw2 = d.rgb_w[2 * N + col]; }
+      if (col < N) { rw0 = d.rgb_w[col]; rw1 = d.rgb_w[N + col]; rw2 = d.rgb_w[2 * N + col]; }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wrow0 + i * 32 + mfma_row(r, hf);
-        float v = acc[i][j][r];
-        u16 h = 0, l = 0;
-        if (row < M && colok) {
-          if (d.add) v += d.add[cb + (long long)row * d.ldc + col];
-          if (d.rgb_g) {
-            const float* gp = d.rgb_g + ((long long)bz * M + row) * 3;
-            v = fmaf(gp[0], rw0, fmaf(gp[1], rw1, fmaf(gp[2], rw2, v)));
-          }
-          if (d.C_unmasked) d.C_unmasked[cb + (long long)row * d.ldc + col] = v;
-          if (Mk) {
-            const u16 mb = Mk[pb + (long long)row * d.ldp + col];
-            const bool pos = ((mb & 0x8000u) == 0) && ((mb & 0x7fffu) != 0);
-            v *= pos ? 1.f : d.slope;
-          }
-          if (d.act) v = lrelu(v, d.slope);
-          if (Mout) Mout[pb + (long long)row * d.ldp + col] = f2bf(v);
-          if (Rhi) {
-            const long long o = pb + (long long)row * d.ldp + col;
-            v += bf2f(Rhi[o]) + bf2f(Rlo[o]);
-          }
-          if (C) C[cb + (long long)row * d.ldc + col] = v;
-          split2(v, h, l);
-        }
-        vh[i][j][r] = h; vl[i][j][r] = l;
-      }
-    }
-  }
-  const bool vec_p = Phi && ((d.ldp & 7) == 0) && ((d.strideP & 7) == 0);
-  const bool vec_t = Thi && ((d.ldt & 7) == 0) && ((d.strideT & 7) == 0);
-  if (Phi) {
-    __syncthreads();   // main-loop LDS reads are done everywhere; scratch regions are per wave from here on
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int o = (i * 32 + mfma_row(r, hf)) * PITCH + j * 32 + l31;
-          sc_hi[o] = vh[i][j][r]; sc_lo[o] = vl[i][j][r];
+          const int row = wrow0 + i * 32 + mfma_row(r, hf);
+          if (row < M) {
+            const float* gp = d.rgb_g + ((long long)bz * M + row) * 3;
+            v[i][j][r] = fmaf(gp[0], rw0, fmaf(gp[1], rw1, fmaf(gp[2], rw2, v[i][j][r])));
+          }
         }
+    }
+  }
+  if (d.C_unmasked) {
+    CIPS_FOR_ELEMS(sc_f[so] = v[i][j][r];)
     __syncthreads();
+    tile_out_f32(d.C_unmasked);
+    __syncthreads();
+  }
+  if (d.mask) {
+    tile_in_bf16((const u16*)d.mask, sc_hi);
+    __syncthreads();
+    CIPS_FOR_ELEMS(
+      const u16 mb = sc_hi[so];
+      const bool pos = ((mb & 0x8000u) == 0) && ((mb & 0x7fffu) != 0);
+      v[i][j][r] *= pos ? 1.f : d.slope;)
+    __syncthreads();
+  }
+  if (d.act) { CIPS_FOR_ELEMS(v[i][j][r] = lrelu(v[i][j][r], d.slope); (void)so;) }
+  if (d.mask_out) {
+    CIPS_FOR_ELEMS(sc_hi[so] = f2bf(v[i][j][r]);)
+    __syncthreads();
+    tile_out_bf16((u16*)d.mask_out, sc_hi);
+    __syncthreads();
+  }
+  if (d.res_hi) {
+    tile_in_bf16((const u16*)d.res_hi, sc_hi);
+    tile_in_bf16((const u16*)d.res_lo, sc_lo);
+    __syncthreads();
+    CIPS_FOR_ELEMS(v[i][j][r] += bf2f(sc_hi[so]) + bf2f(sc_lo[so]);)
+    __syncthreads();
+  }
+  if (d.C) {
+    CIPS_FOR_ELEMS(sc_f[so] = v[i][j][r];)
+    __syncthreads();
+    tile_out_f32(d.C);
+    __syncthreads();
+  }
+  if (Phi || Thi) {
+    u16 vh[2][2][16], vl[2][2][16];
+    CIPS_FOR_ELEMS(split2(v[i][j][r], vh[i][j][r], vl[i][j][r]); (void)so;)
+    if (Phi) {
+      CIPS_FOR_ELEMS(sc_hi[so] = vh[i][j][r]; sc_lo[so] = vl[i][j][r];)
+      __syncthreads();
+      tile_out_bf16(Phi, sc_hi);
+      tile_out_bf16(Plo, sc_lo);
+      __syncthreads();
+    }
+    if (Thi) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int id = lane + 64 * c;
-      const int rr = id >> 3, c8 = (id & 7) * 8;
-      const int row = wrow0 + rr, col = wcol0 + c8;
-      if (row < M && col < N) {
-        const long long o = pb + (long long)row * d.ldp + col;
-        if (vec_p && col + 7 < N) {
-          *reinterpret_cast<uint4*>(Phi + o) = *reinterpret_cast<const uint4*>(sc_hi + rr * PITCH + c8);
-          *reinterpret_cast<uint4*>(Plo + o) = *reinterpret_cast<const uint4*>(sc_lo + rr * PITCH + c8);
-        } else {
-          for (int e = 0; e < 8 && col + e < N; ++e) {
-            Phi[o + e] = sc_hi[rr * PITCH + c8 + e]; Plo[o + e] = sc_lo[rr * PITCH + c8 + e];
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            // 4 consecutive rows (i*32 + 8*rg + 4*hf + 0..3) of column j*32+l31 -> one 8-byte LDS write
+            const int o = (j * 32 + l31) * PITCH + i * 32 + 8 * rg + 4 * hf;
+            *reinterpret_cast<uint2*>(sc_hi + o) = make_uint2(vh[i][j][4 * rg] | ((unsigned)vh[i][j][4 * rg + 1] << 16),
+                                                              vh[i][j][4 * rg + 2] | ((unsigned)vh[i][j][4 * rg + 3] << 16));
+            *reinterpret_cast<uint2*>(sc_lo + o) = make_uint2(vl[i][j][4 * rg] | ((unsigned)vl[i][j][4 * rg + 1] << 16),
+                                                              vl[i][j][4 * rg + 2] | ((unsigned)vl[i][j][4 * rg + 3] << 16));
+          }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int id = lane + 64 * c;
+        const int cc = id >> 3, r8 = (id & 7) * 8;      // transposed image: row = output column, 8 consecutive m
+        const int col = wcol0 + cc, row = wrow0 + r8;
+        if (col < N && row < M) {
+          const long long o = tb + (long long)col * d.ldt + row;
+          if (vec_t && row + 7 < M) {
+            *reinterpret_cast<uint4*>(Thi + o) = *reinterpret_cast<const uint4*>(sc_hi + cc * PITCH + r8);
+            *reinterpret_cast<uint4*>(Tlo + o) = *reinterpret_cast<const uint4*>(sc_lo + cc * PITCH + r8);
+          } else {
+            for (int e = 0; e < 8 && row + e < M; ++e) {
+              Thi[o + e] = sc_hi[cc * PITCH + r8 + e]; Tlo[o + e] = sc_lo[cc * PITCH + r8 + e];
+            }
           }
         }
       }
     }
   }
-  if (Thi) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          // 4 consecutive rows (i*32 + 8*rg + 4*hf + 0..3) of column j*32+l31 -> one 8-byte LDS write
-          const int o = (j * 32 + l31) * PITCH + i * 32 + 8 * rg + 4 * hf;
-          *reinterpret_cast<uint2*>(sc_hi + o) = make_uint2(vh[i][j][4 * rg] | ((unsigned)vh[i][j][4 * rg + 1] << 16),
-                                                            vh[i][j][4 * rg + 2] | ((unsigned)vh[i][j][4 * rg + 3] << 16));
-          *reinterpret_cast<uint2*>(sc_lo + o) = make_uint2(vl[i][j][4 * rg] | ((unsigned)vl[i][j][4 * rg + 1] << 16),
-                                                            vl[i][j][4 * rg + 2] | ((unsigned)vl[i][j][4 * rg + 3] << 16));
-        }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int id = lane + 64 * c;
-      const int cc = id >> 3, r8 = (id & 7) * 8;      // transposed image: row = output column, 8 consecutive m
-      const int col = wcol0 + cc, row = wrow0 + r8;
-      if (col < N && row < M) {
-        const long long o = tb + (long long)col * d.ldt + row;
-        if (vec_t && row + 7 < M) {
-          *reinterpret_cast<uint4*>(Thi + o) = *reinterpret_cast<const uint4*>(sc_hi + cc * PITCH + r8);
-          *reinterpret_cast<uint4*>(Tlo + o) = *reinterpret_cast<const uint4*>(sc_lo + cc * PITCH + r8);
-        } else {
-          for (int e = 0; e < 8 && row + e < M; ++e) {
-            Thi[o + e] = sc_hi[cc * PITCH + r8 + e]; Tlo[o + e] = sc_lo[cc * PITCH + r8 + e];
-          }
-        }
-      }
-    }
-  }
+#undef CIPS_FOR_ELEMS
 }
 
 // fp32 (rows, cols) row-major -> split planes row-major [rows][ldp] and/or transposed [cols][ldt]
