@@ -34,14 +34,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 constexpr int BN = 128, BK = 32;
-constexpr int ROWB = 80;                     // padded LDS row pitch in bytes (32 bf16 = 64 B + 16 B pad)
+constexpr int ROWB = 64;                     // LDS row pitch in bytes: 32 bf16, no padding; the four 16-byte k-chunks
+                                             // of a row are XOR-swizzled by (row>>2)&3 so that both the DMA image
+                                             // (lane-linear) and the ds_read_b128 fragment reads are conflict-free
 // Workgroup tile (64*WM) x 128: WM = 4 -> 256x128, 8 waves, 1 workgroup per CU (120 KB LDS);
 //                               WM = 2 -> 128x128, 4 waves, 2 workgroups per CU (80 KB LDS each), so one
 // workgroup's barriers / prologue / epilogue overlap the other's MFMA phase.
 template <int WM> struct Cfg {
   static constexpr int BM = 64 * WM;
   static constexpr int THREADS = WM * 2 * 64;
-  static constexpr int NB = 512 / THREADS;              // B chunks per thread per plane
+  static constexpr int NB = 8 / (2 * WM);               // B row groups (16 rows) per wave per plane
   static constexpr int OFF_AHI = 0;
   static constexpr int OFF_ALO = OFF_AHI + BM * ROWB;
   static constexpr int OFF_BHI = OFF_ALO + BM * ROWB;
@@ -71,7 +73,8 @@ template <int WM>
 __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g) {
   using CF = Cfg<WM>;
   constexpr int BM = CF::BM, OFF_AHI = CF::OFF_AHI, OFF_ALO = CF::OFF_ALO, OFF_BHI = CF::OFF_BHI, OFF_BLO = CF::OFF_BLO,
-                STAGE = CF::STAGE, NB = CF::NB, THREADS = CF::THREADS;
+                STAGE = CF::STAGE, NB = CF::NB;
+  (void)BM;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cips_gemm_x3_desc& d = g.d;
 
@@ -107,50 +110,36 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging map: 16-byte chunks (8 bf16); chunk c -> row c>>2, k-chunk c&3.
-  // Two register sets: the loads for tile t+2 are issued while tile t is multiplied and tile t+1 sits in
-  // the other LDS stage, i.e. every global load has two full MFMA phases (~3000 cycles) to land.
-  struct Regs { uint4 a[4], b[2 * NB]; };
-  Regs R0, R1;
-  const int kc = tid & 3;
-  auto load_tile = [&](Regs& R, int k0) {
-    const int gk = k0 + kc * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (tid >> 2) + (THREADS / 4) * i;
-      const int gm = m0 + r;
-      uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
-      if (gm < M && gk < K) {
-        vh = *reinterpret_cast<const uint4*>(Ahi + (long long)gm * d.lda + gk);
-        vl = *reinterpret_cast<const uint4*>(Alo + (long long)gm * d.lda + gk);
-      }
-      R.a[2 * i] = vh; R.a[2 * i + 1] = vl;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int r = (tid >> 2) + (THREADS / 4) * i;
-      const int gn = n0 + r;
-      uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
-      if (gn < N && gk < K) {
-        vh = *reinterpret_cast<const uint4*>(Bhi + (long long)gn * d.ldb + gk);
-        vl = *reinterpret_cast<const uint4*>(Blo + (long long)gn * d.ldb + gk);
-      }
-      R.b[2 * i] = vh; R.b[2 * i + 1] = vl;
-    }
+  // HBM -> LDS staging by LDS-DMA (global_load_lds_dwordx4): one wave instruction moves 16 rows x 64 B of one
+  // plane; its LDS image is lane-linear (base + lane*16), so lane L = (row L>>2, slot L&3) fetches the global
+  // chunk kc = slot ^ ((row>>2)&3) — the swizzle lives in the SOURCE address, the reads apply the same XOR.
+  // Rows past M / N are clamped (their products only reach outputs that are never stored); K % 32 == 0.
+  // Two LDS stages: the DMA for tile t+1 runs while tile t is multiplied; one barrier per k-tile.
+  const int drow = lane >> 2, dslot = lane & 3;
+  auto dma_group = [&](const u16* plane, int ld, int rows_total, int row_base, int k0, unsigned char* lds_base) {
+    const int row = row_base + drow;                                  // row inside the workgroup tile
+    const int kcsw = dslot ^ ((row >> 2) & 3);
+    int grow = rows_total - 1;
+    grow = (row < rows_total) ? row : grow;
+    const u16* src = plane + (long long)grow * ld + k0 + kcsw * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
   };
-  auto store_tile = [&](const Regs& R, int stage) {
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  auto issue_tile = [&](int stage, int k0) {
     unsigned char* s = smem + stage * STAGE;
+    constexpr int NW = 2 * WM;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (tid >> 2) + (THREADS / 4) * i;
-      *reinterpret_cast<uint4*>(s + OFF_AHI + r * ROWB + kc * 16) = R.a[2 * i];
-      *reinterpret_cast<uint4*>(s + OFF_ALO + r * ROWB + kc * 16) = R.a[2 * i + 1];
+    for (int i = 0; i < 2; ++i) {            // A: BM/16 row groups per plane, 2 per wave
+      const int gidx = uw + NW * i;
+      dma_group(Ahi + (long long)m0 * d.lda, d.lda, M - m0, gidx * 16, k0, s + OFF_AHI + gidx * 16 * ROWB);
+      dma_group(Alo + (long long)m0 * d.lda, d.lda, M - m0, gidx * 16, k0, s + OFF_ALO + gidx * 16 * ROWB);
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int r = (tid >> 2) + (THREADS / 4) * i;
-      *reinterpret_cast<uint4*>(s + OFF_BHI + r * ROWB + kc * 16) = R.b[2 * i];
-      *reinterpret_cast<uint4*>(s + OFF_BLO + r * ROWB + kc * 16) = R.b[2 * i + 1];
+    for (int i = 0; i < NB; ++i) {           // B: 8 row groups per plane
+      const int gidx = uw + NW * i;
+      dma_group(Bhi + (long long)n0 * d.ldb, d.ldb, N - n0, gidx * 16, k0, s + OFF_BHI + gidx * 16 * ROWB);
+      dma_group(Blo + (long long)n0 * d.ldb, d.ldb, N - n0, gidx * 16, k0, s + OFF_BLO + gidx * 16 * ROWB);
     }
   };
   auto compute = [&](int stage) {
@@ -160,13 +149,15 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
       bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int off = (wm * 64 + i * 32 + l31) * ROWB + ks * 32 + hf * 16;
+        const int R = wm * 64 + i * 32 + l31;
+        const int off = R * ROWB + (((ks * 2 + hf) ^ ((R >> 2) & 3)) << 4);
         ah[i] = *reinterpret_cast<const bf16x8*>(s + OFF_AHI + off);
         al[i] = *reinterpret_cast<const bf16x8*>(s + OFF_ALO + off);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int off = (wn * 64 + j * 32 + l31) * ROWB + ks * 32 + hf * 16;
+        const int R = wn * 64 + j * 32 + l31;
+        const int off = R * ROWB + (((ks * 2 + hf) ^ ((R >> 2) & 3)) << 4);
         bh[j] = *reinterpret_cast<const bf16x8*>(s + OFF_BHI + off);
         bl[j] = *reinterpret_cast<const bf16x8*>(s + OFF_BLO + off);
       }
@@ -181,22 +172,13 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
     }
   };
 
-  const int nk = (K + BK - 1) / BK;
-  load_tile(R0, 0);
-  store_tile(R0, 0);
-  if (nk > 1) load_tile(R1, BK);        // tile 1 -> R1 (in flight)
+  const int nk = K / BK;
+  issue_tile(0, 0);
   __syncthreads();
-  // invariant at the top of iteration kt: LDS[kt&1] = tile kt; tile kt+1 is in R1 (kt even) / R0 (kt odd)
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) load_tile(R0, (kt + 2) * BK);
-    compute(0);
-    if (kt + 1 < nk) store_tile(R1, 1);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) load_tile(R1, (kt + 3) * BK);
-    compute(1);
-    if (kt + 2 < nk) store_tile(R0, 0);
-    __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) issue_tile((kt + 1) & 1, (kt + 1) * BK);
+    compute(kt & 1);
+    __syncthreads();      // hipcc drains the LDS-DMA (vmcnt(0)) before this barrier: tile kt+1 is published
   }
 
   // ---------------- epilogue ----------------
