@@ -49,8 +49,10 @@ template <int WM> struct Cfg {
   static constexpr int OFF_BHI = OFF_ALO + BM * ROWB;
   static constexpr int OFF_BLO = OFF_BHI + BN * ROWB;
   static constexpr int STAGE = OFF_BLO + BN * ROWB;
+  static constexpr int NSTAGE = (WM == 4) ? 3 : 4;      // LDS ring depth (one workgroup per CU in both forms)
+  static constexpr int PIECES = 4 + 2 * NB;             // LDS-DMA instructions per wave per k-tile
   static constexpr int SMEM_EPI = WM * 2 * 2 * 64 * 72 * 2;   // per-wave epilogue scratch
-  static constexpr int SMEM_BYTES = (2 * STAGE > SMEM_EPI) ? 2 * STAGE : SMEM_EPI;
+  static constexpr int SMEM_BYTES = (NSTAGE * STAGE > SMEM_EPI) ? NSTAGE * STAGE : SMEM_EPI;
 };
 
 struct Args {
@@ -172,14 +174,25 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
     }
   };
 
+  // Ring of NSTAGE LDS stages, NSTAGE-1 tiles of LDS-DMA in flight across the (raw) barriers: the wait in
+  // front of tile kt is a COUNTED vmcnt that leaves the younger tiles' pieces outstanding
+  // (cdna_hip_programming.md T3/T4: never drain to 0 in the main loop).
+  constexpr int NSTAGE = CF::NSTAGE, PIECES = CF::PIECES, DIST = NSTAGE - 1;
   const int nk = K / BK;
-  issue_tile(0, 0);
-  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < DIST; ++t)
+    if (t < nk) issue_tile(t, t * BK);
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) issue_tile((kt + 1) & 1, (kt + 1) * BK);
-    compute(kt & 1);
-    __syncthreads();      // hipcc drains the LDS-DMA (vmcnt(0)) before this barrier: tile kt+1 is published
+    const int younger = min(DIST - 1, nk - 1 - kt);      // tiles issued after kt that may stay in flight
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // every wave's pieces of tile kt have landed;
+                                                          // every wave is done reading stage (kt-1) % NSTAGE
+    if (kt + DIST < nk) issue_tile((kt + DIST) % NSTAGE, (kt + DIST) * BK);
+    compute(kt % NSTAGE);
   }
+  __builtin_amdgcn_s_barrier();
 
   // ---------------- epilogue ----------------
   // Every auxiliary tensor enters and every result leaves the CU through a per-wave LDS scratch tile
