@@ -429,11 +429,11 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
   if ((d->K & 31) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
     return (int)hipErrorInvalidValue;
-  // tile choice: 128x128 (2 workgroups / CU) unless CIPS_X3_TILE=256 asks for the 256x128 single-workgroup form
+  // tile choice: 256x128 / 8 waves / 3-stage ring (default, measured fastest); CIPS_X3_TILE=128 selects 128x128 / 4 waves / 4 stages
   static int tile = 0;
   if (!tile) {
     const char* e = getenv("CIPS_X3_TILE");
-    tile = (e && atoi(e) == 256) ? 256 : 128;
+    tile = (e && atoi(e) == 128) ? 128 : 256;
     hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<4>::SMEM_BYTES);
     hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<2>::SMEM_BYTES);
   }
