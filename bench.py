@@ -42,33 +42,52 @@ def parse():
     ap.add_argument("--hier", action="store_true", help="hierarchical sampling (S coarse + S fine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
+    ap.add_argument("--inr-mode", default=None, choices=["bf16x3", "f32"])
     return ap.parse_args()
 
 
-def gemm_roofline(dev, b, n):
-    """Dominant kernel: gemm_f32_kernel (the 512x512 modulated-FC layer GEMM, 34 launches per
-    fwd+bwd step).  Timed live with events on the launch stream (torch's current stream)."""
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
+
+
+def gemm_roofline(dev, b, n, mode):
+    """Dominant kernel of the step (>= 54 % of GPU time): the modulated-FC 512x512 layer GEMM of the CIPS
+    head, forward form, timed live with events on the launch stream (torch's current stream).
+    bf16x3 mode: gemm_bf16x3_kernel — every fp32 product is 3 bf16 MFMA passes, so the roof for ALGORITHMIC
+    (fp32-equivalent) flops is the dense bf16 MFMA peak / 3.  f32 mode: gemm_f32_kernel on fp32 MFMA."""
     from cips3d_amd import ops
     x = torch.randn(b, n, 512, device=dev)
     w = torch.randn(b, 512, 512, device=dev) * 0.04
-    out = torch.empty(b, n, 512, device=dev)
+    flops = 2.0 * b * n * 512 * 512
+    if mode == "bf16x3":
+        xP, _ = ops.split_planes(x, want_t=False)
+        wP, _ = ops.split_planes(w, want_t=False)
+        oP, oT = ops.Planes.empty(b, n, 512, device=dev), ops.Planes.empty(b, 512, n, device=dev)
+        fn = lambda: ops.gemm_x3(xP, wP, n, 512, 512, 512, 512, b, n * 512, 512 * 512, P=oP, T=oT, ldt=n,
+                                 strideT=512 * n, act=1)
+        name, peak = "gemm_bf16x3_kernel<4> (modfc 512x512 fwd: lrelu + split planes in both orientations)", \
+            BF16_MFMA_PEAK_TFLOPS / 3.0
+    else:
+        out = torch.empty(b, n, 512, device=dev)
+        fn = lambda: ops.bmm_nn(x, w, out=out, act=1)
+        name, peak = "gemm_f32_kernel<false,false> (modfc 512x512 fwd, act=lrelu)", F32_MFMA_PEAK_TFLOPS
     for _ in range(3):
-        ops.bmm_nn(x, w, out=out, act=1)
+        fn()
     torch.cuda.synchronize()
     reps = 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.bmm_nn(x, w, out=out, act=1)
+        fn()
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / reps * 1e-3
-    flops = 2.0 * b * n * 512 * 512
     ach = flops / t / 1e12
-    return {"bound": "mfma", "kernel": "gemm_f32_kernel<false,false> (modfc 512x512, act=lrelu)",
-            "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "launch_us": round(t * 1e6, 1), "flops_per_launch": flops}
+    r = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+         "frac": round(ach / peak, 4), "traffic": None, "launch_us": round(t * 1e6, 1), "flops_per_launch": flops}
+    if mode == "bf16x3":
+        r["note"] = "algorithmic fp32-equivalent flops; raw bf16 MFMA rate = 3x achieved vs 2500 dense peak"
+    return r
 
 
 def cpu_baseline(img_size, S, hier):
@@ -115,6 +134,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from cips3d_amd.generator import GeneratorNerfINR
     from cips3d_amd.distributed import allreduce_grads
+    from cips3d_amd import ops
+    if a.inr_mode:
+        ops.INR_MODE = a.inr_mode
+    mode = ops.INR_MODE
 
     S = a.num_steps if a.num_steps is not None else (12 if a.hier else 24)
     torch.manual_seed(1234)                       # identical initial weights on every rank
@@ -141,32 +164,48 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(nsteps, nwarm):
+        for _ in range(nwarm):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed(a.steps, a.warmup)
     ms = dt / a.steps * 1e3
     value = world * b * a.steps / dt
+    exact = None
+    if mode == "bf16x3" and not a.no_exact:
+        ops.INR_MODE = "f32"          # same step with the INR GEMMs on exact fp32 MFMA, for reference
+        dte = timed(max(2, a.steps // 2), 1)
+        ops.INR_MODE = mode
+        ne = max(2, a.steps // 2)
+        exact = {"value": round(world * b * ne / dte, 2), "ms_per_step": round(dte / ne * 1e3, 3),
+                 "note": "identical step, INR GEMMs on v_mfma_f32_32x32x2_f32 (CIPS_INR_MODE=f32)"}
     E = 2 * S if a.hier else S
     line = {
         "metric": "rendered imgs/sec (G fwd+bwd)", "value": round(value, 2), "unit": "img/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if mode == "f32" else "f32 (fp32 MFMA; CIPS-head GEMMs as 3-pass split-bf16 MFMA, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": f"FFHQ r{img}, {E} SIREN evals/ray (num_steps {S}, hierarchical {a.hier}), "
                                f"batch {b}/GPU, G fwd+bwd, all 9 CIPS blocks",
-                   "global_batch": world * b, "parallelism": f"dp{world}"},
+                   "global_batch": world * b, "parallelism": f"dp{world}", "inr_gemm_mode": mode},
     }
+    if exact:
+        line["exact_f32"] = exact
     if rank == 0:
         if not a.no_roofline:
-            line["roofline"] = gemm_roofline(dev, b, img * img)
+            line["roofline"] = gemm_roofline(dev, b, img * img, mode)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(img, S, a.hier)
         print(json.dumps(line), flush=True)

@@ -11,8 +11,18 @@ TOL = 1e-3
 CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze"]
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def inr_mode(request):
+    """Run under both INR GEMM modes: exact fp32 MFMA and the 3-pass split-bf16 MFMA (default)."""
+    from cips3d_amd import ops
+    old = ops.INR_MODE
+    ops.INR_MODE = request.param
+    yield request.param
+    ops.INR_MODE = old
+
+
 @pytest.mark.parametrize("tag", CASES)
-def test_generator_matches_reference_golden(tag):
+def test_generator_matches_reference_golden(tag, inr_mode):
     fix = load_golden(tag)
     d = torch.device("cuda:0")
     G = seeded_generator(fix["seed"], freeze=fix["freeze"], device=d)
@@ -24,7 +34,7 @@ def test_generator_matches_reference_golden(tag):
     torch.cuda.synchronize()
     assert imgs.shape == fix["imgs"].shape
     e = max_rel(imgs, fix["imgs"])
-    print(f"{tag}: imgs max_rel vs reference {e:.3e}")
+    print(f"{tag} [{inr_mode}]: imgs max_rel vs reference {e:.3e}")
     assert e < TOL
     assert max_rel(pitch_yaw, fix["pitch_yaw"]) < 1e-5
     (imgs * fix["G0"].to(d)).sum().backward()
@@ -66,11 +76,16 @@ def test_generator_matches_reference_golden(tag):
         # weight gradient by ~0.8/sqrt(rows*512) relative; allow for it on the parameters behind the gates.
         rows_px = fix["b"] * fix["img_size"] ** 2
         gate_tol = 2.0 / (rows_px * 512) ** 0.5 if ("inr" in name) else 0.0
+        # bf16x3 carries pre-activations to ~5e-6 instead of ~3e-7: ~15x more ambiguous gates; measured
+        # gradient noise 0.5-1 % on every parameter upstream of the INR head, independent of problem size
+        # (forward agreement stays ~3e-6).  DESIGN.md §3 "numerics".
+        if inr_mode == "bf16x3":
+            gate_tol = max(3e-2, 3 * gate_tol)
         if e_hip > max(TOL, 3 * e_ref, gate_tol):
             bad.append((name, e_hip, e_ref))
     import os
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/gradtable_{tag}.txt", "w") as fh:
+    with open(f"gpurun_out/gradtable_{tag}_{inr_mode}.txt", "w") as fh:
         fh.write("name  err_hip_vs_fp64  err_ref32_vs_fp64  err_hip_vs_ref32  max_abs_diff/max_abs  argmax\n")
         for name, p in G.named_parameters():
             if fix["grads"][name] is None:
@@ -80,7 +95,7 @@ def test_generator_matches_reference_golden(tag):
             r = [x for x in rows if x[0] == name][0]
             fh.write(f"{name} {r[1]:.3e} {r[2]:.3e} {r[3]:.3e} {float(diff.max() / t64.abs().max()):.3e} {int(diff.argmax())}\n")
     worst = max(rows, key=lambda r: r[1])
-    print(f"{tag}: worst grad err vs fp64 {worst[1]:.3e} (reference fp32 vs fp64 {worst[2]:.3e}, hip vs ref32 "
+    print(f"{tag} [{inr_mode}]: worst grad err vs fp64 {worst[1]:.3e} (reference fp32 vs fp64 {worst[2]:.3e}, hip vs ref32 "
           f"{worst[3]:.3e}) at {worst[0]}; params checked {len(rows)}")
     assert not bad, bad
 
@@ -110,7 +125,7 @@ def test_generator_rng_draw_order_matches_reference_shapes():
                      ("randn", (2, 1)), ("randn", (2, 64, 4, 1)), ("rand", (128, 4)), ("randn", (2, 64, 8, 1))]
 
 
-def test_generator_r64_vs_oracle_forward():
+def test_generator_r64_vs_oracle_forward(inr_mode):
     """Headline geometry (64^2, S=24 flat and S=12 hierarchical) at b=1 against the CPU oracle."""
     d = torch.device("cuda:0")
     for S, hier in [(24, False), (12, True)]:
@@ -130,5 +145,5 @@ def test_generator_r64_vs_oracle_forward():
                           num_steps=S, h_stddev=0.3, v_stddev=0.155, hierarchical_sample=hier, sample_dist="gaussian",
                           rand_override={k: v.to(d) for k, v in rand.items()})
         e = max_rel(imgs, ref["imgs"])
-        print(f"r64 S={S} hier={hier}: imgs max_rel {e:.3e}")
+        print(f"r64 S={S} hier={hier} [{inr_mode}]: imgs max_rel {e:.3e}")
         assert e < TOL
