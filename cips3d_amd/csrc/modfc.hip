@@ -55,18 +55,18 @@ __global__ __launch_bounds__(256) void modfc_prep_kernel(const float* __restrict
   }
 }
 
-// same as modfc_prep_kernel but emits the bf16x3 operand planes (hi/lo) of Wb [in][out] and Wbt [out][in]
+// bf16x3 operand planes of Wb [in][out] and Wbt [out][in] (hi/lo each), in two launches:
+//   (1) demod[b][n] = rsqrt(sum_k (W[k][n] (s[b][k]+1))^2 + eps)          grid (out/32, B)
+//   (2) 32x32 tiles of v = W (s+1) demod, split to hi/lo, written row-major and (through LDS) transposed,
+//       both with coalesced accesses                                            grid (out/32, in/32, B)
 __device__ __forceinline__ unsigned short f2bf_rne(float v) {
   unsigned u = __float_as_uint(v);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
-__global__ __launch_bounds__(256) void modfc_prep_x3_kernel(const float* __restrict__ W, const float* __restrict__ s,
-                                                            unsigned short* __restrict__ wbh, unsigned short* __restrict__ wbl,
-                                                            unsigned short* __restrict__ wth, unsigned short* __restrict__ wtl,
-                                                            float* __restrict__ demod, int in_dim, int out_dim, float eps) {
+__global__ __launch_bounds__(256) void modfc_demod_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                          float* __restrict__ demod, int in_dim, int out_dim, float eps) {
   __shared__ float red[8][33];
-  __shared__ float dsh[32];
   const int b = blockIdx.y;
   const int c = threadIdx.x & 31, kg = threadIdx.x >> 5;
   const int n = blockIdx.x * 32 + c;
@@ -79,33 +79,41 @@ __global__ __launch_bounds__(256) void modfc_prep_x3_kernel(const float* __restr
     }
   red[kg][c] = q;
   __syncthreads();
-  if (kg == 0) {
+  if (kg == 0 && n < out_dim) {
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 8; ++g) t += red[g][c];
-    float d = rsqrtf(t + eps);
-    dsh[c] = d;
-    if (n < out_dim) demod[(long long)b * out_dim + n] = d;
+    demod[(long long)b * out_dim + n] = rsqrtf(t + eps);
+  }
+}
+__global__ __launch_bounds__(256) void modfc_planes_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                           const float* __restrict__ demod,
+                                                           unsigned short* __restrict__ wbh, unsigned short* __restrict__ wbl,
+                                                           unsigned short* __restrict__ wth, unsigned short* __restrict__ wtl,
+                                                           int in_dim, int out_dim) {
+  __shared__ unsigned short th[32][33], tl[32][33];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long base = (long long)b * in_dim * out_dim;
+  for (int kk = ty; kk < 32; kk += 8) {
+    const int k = k0 + kk, n = n0 + tx;
+    unsigned short h = 0, l = 0;
+    if (k < in_dim && n < out_dim) {
+      const float v = W[(long long)k * out_dim + n] * (s[(long long)b * in_dim + k] + 1.f) * demod[(long long)b * out_dim + n];
+      h = f2bf_rne(v);
+      l = f2bf_rne(v - __uint_as_float(((unsigned)h) << 16));
+      wbh[base + (long long)k * out_dim + n] = h;
+      wbl[base + (long long)k * out_dim + n] = l;
+    }
+    th[kk][tx] = h; tl[kk][tx] = l;
   }
   __syncthreads();
-  const long long base = (long long)b * in_dim * out_dim;
-  if (n < out_dim) {
-    const float d = dsh[c];
-    for (int k = kg; k < in_dim; k += 8) {
-      const float v = W[(long long)k * out_dim + n] * (sb[k] + 1.f) * d;
-      const unsigned short h = f2bf_rne(v);
-      wbh[base + (long long)k * out_dim + n] = h;
-      wbl[base + (long long)k * out_dim + n] = f2bf_rne(v - __uint_as_float(((unsigned)h) << 16));
-    }
-  }
-  for (int idx = threadIdx.x; idx < 32 * in_dim; idx += 256) {
-    const int k = idx % in_dim, cc = idx / in_dim;
-    const int nn = blockIdx.x * 32 + cc;
-    if (nn < out_dim) {
-      const float v = W[(long long)k * out_dim + nn] * (sb[k] + 1.f) * dsh[cc];
-      const unsigned short h = f2bf_rne(v);
-      wth[base + (long long)nn * in_dim + k] = h;
-      wtl[base + (long long)nn * in_dim + k] = f2bf_rne(v - __uint_as_float(((unsigned)h) << 16));
+  for (int nn = ty; nn < 32; nn += 8) {
+    const int n = n0 + nn, k = k0 + tx;
+    if (k < in_dim && n < out_dim) {
+      wth[base + (long long)n * in_dim + k] = th[tx][nn];
+      wtl[base + (long long)n * in_dim + k] = tl[tx][nn];
     }
   }
 }
@@ -390,10 +398,12 @@ extern "C" int cips_modfc_prep_x3(const float* weight, const float* s, void* wb_
                                   void* wbt_lo, float* demod, int B, int in_dim, int out_dim, float eps,
                                   cips_stream_t stream) {
   if (B <= 0 || in_dim <= 0 || out_dim <= 0) return (int)hipErrorInvalidValue;
-  dim3 grid((out_dim + 31) / 32, B);
-  hipLaunchKernelGGL(modfc_prep_x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, weight, s,
-                     (unsigned short*)wb_hi, (unsigned short*)wb_lo, (unsigned short*)wbt_hi,
-                     (unsigned short*)wbt_lo, demod, in_dim, out_dim, eps);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(modfc_demod_kernel, dim3((out_dim + 31) / 32, B), dim3(256), 0, st, weight, s, demod, in_dim,
+                     out_dim, eps);
+  hipLaunchKernelGGL(modfc_planes_kernel, dim3((out_dim + 31) / 32, (in_dim + 31) / 32, B), dim3(256), 0, st, weight,
+                     s, demod, (unsigned short*)wb_hi, (unsigned short*)wb_lo, (unsigned short*)wbt_hi,
+                     (unsigned short*)wbt_lo, in_dim, out_dim);
   return CIPS_CHECK_LAUNCH();
 }
 

@@ -557,21 +557,24 @@ class InrHeadX3Function(torch.autograd.Function):
             blocks.append(tuple(_c(p.detach()) for p in params[4 * k:4 * k + 4]))
         rgbp = [_c(p.detach()) for p in params[4 * nblocks:]]
         _chk(x0, *[t for blk in blocks for t in blk], *rgbp)
-        xP, xT = split_planes(x0)
+        train = any(ctx.needs_input_grad)       # no-grad / inference: no transposed planes, nothing kept
+        xP, xT = split_planes(x0, want_t=train)
         rgb = torch.empty(B, n, 3, device=dev)
         first_rgb = True
         saved = []
         for k, (W1, s1, W2, s2) in enumerate(blocks):
             cin, cout = W1.shape
             wb1, wbt1, d1 = modfc_prep_x3(W1, s1)
-            a1P, a1T = Planes.empty(B, n, cout, device=dev), Planes.empty(B, cout, n, device=dev)
+            a1P = Planes.empty(B, n, cout, device=dev)
+            a1T = Planes.empty(B, cout, n, device=dev) if train else None
             gemm_x3(xP, wbt1, n, cout, cin, cin, cin, B, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
                     act=1)
             wb2, wbt2, d2 = modfc_prep_x3(W2, s2)
             skip = (k >= 4) and (cin == cout)
-            oP, oT = Planes.empty(B, n, cout, device=dev), Planes.empty(B, cout, n, device=dev)
+            oP = Planes.empty(B, n, cout, device=dev)
+            oT = Planes.empty(B, cout, n, device=dev) if train else None
             if skip:
-                m2 = torch.empty(B, n, cout, device=dev, dtype=BF)
+                m2 = torch.empty(B, n, cout, device=dev, dtype=BF) if train else None
                 gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
                         strideT=cout * n, act=1, res=xP, mask_out=m2)
             else:
@@ -581,8 +584,9 @@ class InrHeadX3Function(torch.autograd.Function):
             if k >= 3:
                 torgb_fwd_x3(oP, rgbp[2 * (k - 3)], rgbp[2 * (k - 3) + 1], rgb.view(B * n, 3), accumulate=not first_rgb)
                 first_rgb = False
-            # keep for backward: xT (dW1), a1 gate + a1T (dW2), out planes (ToRGB grad), m2 gate, weights
-            saved.append(dict(xT=xT, a1m=a1P.hi, a1T=a1T, oP=oP, m2=m2, wb1=wb1, d1=d1, wb2=wb2, d2=d2, skip=skip))
+            if train:
+                # keep for backward: xT (dW1), a1 gate + a1T (dW2), out planes (ToRGB grad), m2 gate, weights
+                saved.append(dict(xT=xT, a1m=a1P.hi, a1T=a1T, oP=oP, m2=m2, wb1=wb1, d1=d1, wb2=wb2, d2=d2, skip=skip))
             xP, xT = oP, oT
         if first_rgb:
             rgb.zero_()
