@@ -80,7 +80,11 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cips_gemm_x3_desc& d = g.d;
 
-  int bid = blockIdx.x;
+  // Persistent workgroups: the grid is one workgroup per CU (or fewer); each walks the tile list with a
+  // stride of gridDim.x, which keeps it on its XCD (gridDim.x % 8 == 0) and saves the per-tile workgroup
+  // launch / LDS (re)allocation latency (~3 us against ~25 us of main loop at K = 512).
+  for (int tseq = blockIdx.x; tseq < g.total; tseq += gridDim.x) {
+  int bid = tseq;
   {
     const int nx = 8;
     int q = g.total / nx, r = g.total % nx;
@@ -279,6 +283,11 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
       }
     }
   };
+// The scratch regions are private to a wave and a wave's DS instructions execute in order, so a
+// write -> read hand-over inside one wave needs no workgroup barrier: only the compiler must keep the order
+// and the LDS queue must be drained before registers are reused.
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define CIPS_FOR_ELEMS(BODY)                                              \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                            \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                            \
@@ -290,9 +299,9 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   __syncthreads();   // main-loop LDS reads are done everywhere; scratch regions are per wave from here on
   if (d.add) {
     tile_in_f32(d.add);
-    __syncthreads();
+    WAVE_SYNC();
     CIPS_FOR_ELEMS(v[i][j][r] += sc_f[so];)
-    __syncthreads();
+    WAVE_SYNC();
   }
   if (d.rgb_g) {
 #pragma unroll
@@ -314,48 +323,48 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   }
   if (d.C_unmasked) {
     CIPS_FOR_ELEMS(sc_f[so] = v[i][j][r];)
-    __syncthreads();
+    WAVE_SYNC();
     tile_out_f32(d.C_unmasked);
-    __syncthreads();
+    WAVE_SYNC();
   }
   if (d.mask) {
     tile_in_bf16((const u16*)d.mask, sc_hi);
-    __syncthreads();
+    WAVE_SYNC();
     CIPS_FOR_ELEMS(
       const u16 mb = sc_hi[so];
       const bool pos = ((mb & 0x8000u) == 0) && ((mb & 0x7fffu) != 0);
       v[i][j][r] *= pos ? 1.f : d.slope;)
-    __syncthreads();
+    WAVE_SYNC();
   }
   if (d.act) { CIPS_FOR_ELEMS(v[i][j][r] = lrelu(v[i][j][r], d.slope); (void)so;) }
   if (d.mask_out) {
     CIPS_FOR_ELEMS(sc_hi[so] = f2bf(v[i][j][r]);)
-    __syncthreads();
+    WAVE_SYNC();
     tile_out_bf16((u16*)d.mask_out, sc_hi);
-    __syncthreads();
+    WAVE_SYNC();
   }
   if (d.res_hi) {
     tile_in_bf16((const u16*)d.res_hi, sc_hi);
     tile_in_bf16((const u16*)d.res_lo, sc_lo);
-    __syncthreads();
+    WAVE_SYNC();
     CIPS_FOR_ELEMS(v[i][j][r] += bf2f(sc_hi[so]) + bf2f(sc_lo[so]);)
-    __syncthreads();
+    WAVE_SYNC();
   }
   if (d.C) {
     CIPS_FOR_ELEMS(sc_f[so] = v[i][j][r];)
-    __syncthreads();
+    WAVE_SYNC();
     tile_out_f32(d.C);
-    __syncthreads();
+    WAVE_SYNC();
   }
   if (Phi || Thi) {
     u16 vh[2][2][16], vl[2][2][16];
     CIPS_FOR_ELEMS(split2(v[i][j][r], vh[i][j][r], vl[i][j][r]); (void)so;)
     if (Phi) {
       CIPS_FOR_ELEMS(sc_hi[so] = vh[i][j][r]; sc_lo[so] = vl[i][j][r];)
-      __syncthreads();
+      WAVE_SYNC();
       tile_out_bf16(Phi, sc_hi);
       tile_out_bf16(Plo, sc_lo);
-      __syncthreads();
+      WAVE_SYNC();
     }
     if (Thi) {
 #pragma unroll
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
             *reinterpret_cast<uint2*>(sc_lo + o) = make_uint2(vl[i][j][4 * rg] | ((unsigned)vl[i][j][4 * rg + 1] << 16),
                                                               vl[i][j][4 * rg + 2] | ((unsigned)vl[i][j][4 * rg + 3] << 16));
           }
-      __syncthreads();
+      WAVE_SYNC();
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const int id = lane + 64 * c;
@@ -391,7 +400,10 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
       }
     }
   }
+  __syncthreads();   // scratch is free again before the next tile's LDS-DMA lands in it
+  }  // persistent tile loop
 #undef CIPS_FOR_ELEMS
+#undef WAVE_SYNC
 }
 
 // fp32 (rows, cols) row-major -> split planes row-major [rows][ldp] and/or transposed [cols][ldt]
@@ -445,10 +457,20 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   long long total = (long long)g.tiles_m * g.tiles_n * d->batch;
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+    ncu = (ncu / 8) * 8;
+    const char* e = getenv("CIPS_X3_PERSIST");
+    if (e && atoi(e) == 0) ncu = 0x7fffffff;       // one workgroup per tile (non-persistent) for A/B runs
+  }
+  const int grid = g.total < ncu ? g.total : ncu;
   if (tile == 256)
-    hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3(g.total), dim3(512), Cfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3(grid), dim3(512), Cfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
   else
-    hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, dim3(g.total), dim3(256), Cfg<2>::SMEM_BYTES, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, dim3(grid), dim3(256), Cfg<2>::SMEM_BYTES, (hipStream_t)stream, g);
   return CIPS_CHECK_LAUNCH();
 }
 
