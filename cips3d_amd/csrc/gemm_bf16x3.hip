@@ -58,6 +58,7 @@ template <int WM> struct Cfg {
 struct Args {
   cips_gemm_x3_desc d;
   int tiles_m, tiles_n, total;
+  int stagger_cycles;   // start-phase quantum (shader cycles), 0 = no staggering
 };
 
 __device__ __forceinline__ u16 f2bf(float v) {
@@ -83,6 +84,14 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   // Persistent workgroups: the grid is one workgroup per CU (or fewer); each walks the tile list with a
   // stride of gridDim.x, which keeps it on its XCD (gridDim.x % 8 == 0) and saves the per-tile workgroup
   // launch / LDS (re)allocation latency (~3 us against ~25 us of main loop at K = 512).
+  // De-phase the persistent workgroups.  All tiles take the same time, so without this every CU reaches its
+  // store-heavy epilogue at the same moment: the chip alternates between "everyone computes, HBM idle" and
+  // "everyone writes at the ~3.7 TB/s write ceiling, matrix cores idle" (measured: 268 MB of fp32 C cost 72 us
+  // on top of a 211 us main loop).  Four start phases spread the write traffic under the other CUs' MFMA time.
+  if (g.stagger_cycles > 0) {
+    const int phase = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < phase * g.stagger_cycles; i += 64 * 100) __builtin_amdgcn_s_sleep(100);
+  }
   for (int tseq = blockIdx.x; tseq < g.total; tseq += gridDim.x) {
   int bid = tseq;
   {
@@ -467,6 +476,11 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
     if (e && atoi(e) == 0) ncu = 0x7fffffff;       // one workgroup per tile (non-persistent) for A/B runs
   }
   const int grid = g.total < ncu ? g.total : ncu;
+  // stagger quantum = a quarter of one tile's main-loop time (~3500 cycles per k-tile), only when every
+  // workgroup walks several tiles and the epilogue writes a lot (any plane / fp32 output)
+  static int stagger_on = -1;
+  if (stagger_on < 0) { const char* e = getenv("CIPS_X3_STAGGER"); stagger_on = (e && atoi(e) == 0) ? 0 : 1; }
+  g.stagger_cycles = (stagger_on && g.total >= 2 * grid) ? (d->K / BK) * 3500 / 4 : 0;
   if (tile == 256)
     hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3(grid), dim3(512), Cfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
   else

@@ -29,3 +29,11 @@ t = timeit(lambda: ops.gemm_x3(xP, wP, n, C, C, C, C, B, n*C, C*C, P=oP, T=oT, l
 gw = torch.empty(B, C, C, device=d)
 t = timeit(lambda: ops.gemm_x3(xT, oT, C, C, n, n, n, B, C*n, C*n, C=gw)); print(f"x3 W (fp32 out)   {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF")
 t = timeit(lambda: ops.gemm_x3(xP, wP, n, C, C, C, C, B, n*C, C*C, C=out)); print(f"x3 plain fp32 out {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF")
+t = timeit(lambda: ops.gemm_x3(xP, wP, n, C, C, C, C, B, n*C, C*C)); print(f"x3 F no output    {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF")
+# longer K at the F shape: A (B,n,2048), B (B,512,2048)
+K2 = 2048
+x2 = torch.randn(B, n, K2, device=d); w2 = torch.randn(B, C, K2, device=d) * 0.02
+x2P, _ = ops.split_planes(x2, want_t=False); w2P, _ = ops.split_planes(w2, want_t=False)
+f2 = 2.0 * B * n * C * K2
+t = timeit(lambda: ops.gemm_x3(x2P, w2P, n, C, K2, K2, K2, B, n*K2, C*K2), reps=5); print(f"x3 F K=2048 noout {t*1e6:8.1f} us {f2/t/1e12:7.1f} TF")
+t = timeit(lambda: ops.gemm_x3(x2P, w2P, n, C, K2, K2, K2, B, n*K2, C*K2, C=out), reps=5); print(f"x3 F K=2048 C out {t*1e6:8.1f} us {f2/t/1e12:7.1f} TF")
