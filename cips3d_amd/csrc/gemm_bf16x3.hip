@@ -49,7 +49,7 @@ template <int WM> struct Cfg {
   static constexpr int OFF_BHI = OFF_ALO + BM * ROWB;
   static constexpr int OFF_BLO = OFF_BHI + BN * ROWB;
   static constexpr int STAGE = OFF_BLO + BN * ROWB;
-  static constexpr int NSTAGE = (WM == 4) ? 3 : 4;      // LDS ring depth (one workgroup per CU in both forms)
+  static constexpr int NSTAGE = (WM == 4) ? 3 : 2;      // LDS ring depth: 256-row form 3 stages (1 WG / CU); 128-row form 2 stages, 72 KB -> 2 WGs / CU
   static constexpr int PIECES = 4 + 2 * NB;             // LDS-DMA instructions per wave per k-tile
   static constexpr int SMEM_EPI = WM * 2 * 2 * 64 * 72 * 2;   // per-wave epilogue scratch
   static constexpr int SMEM_BYTES = (NSTAGE * STAGE > SMEM_EPI) ? NSTAGE * STAGE : SMEM_EPI;
@@ -84,10 +84,10 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   // Persistent workgroups: the grid is one workgroup per CU (or fewer); each walks the tile list with a
   // stride of gridDim.x, which keeps it on its XCD (gridDim.x % 8 == 0) and saves the per-tile workgroup
   // launch / LDS (re)allocation latency (~3 us against ~25 us of main loop at K = 512).
-  // De-phase the persistent workgroups.  All tiles take the same time, so without this every CU reaches its
-  // store-heavy epilogue at the same moment: the chip alternates between "everyone computes, HBM idle" and
-  // "everyone writes at the ~3.7 TB/s write ceiling, matrix cores idle" (measured: 268 MB of fp32 C cost 72 us
-  // on top of a 211 us main loop).  Four start phases spread the write traffic under the other CUs' MFMA time.
+  // Optional de-phasing of the persistent workgroups (CIPS_X3_STAGGER=1): four start phases, so that not every
+  // CU reaches its store-heavy epilogue at the same moment.  Measured neutral on MI355X: the epilogue traffic adds
+  // to the main loop's time whatever the phase relation (268 MB of fp32 C cost ~75 us on top of a 205 us main
+  // loop), i.e. the kernel is bound by the memory system, not by MFMA issue.
   if (g.stagger_cycles > 0) {
     const int phase = (blockIdx.x >> 3) & 3;
     for (int i = 0; i < phase * g.stagger_cycles; i += 64 * 100) __builtin_amdgcn_s_sleep(100);
@@ -467,7 +467,7 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
   static int ncu = 0;
-  if (!ncu) {
+  if (!ncu) {   // persistent grid: one workgroup per CU for the 256-row form, two for the 128-row form
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     if (ncu <= 0) ncu = 256;
@@ -475,11 +475,12 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
     const char* e = getenv("CIPS_X3_PERSIST");
     if (e && atoi(e) == 0) ncu = 0x7fffffff;       // one workgroup per tile (non-persistent) for A/B runs
   }
-  const int grid = g.total < ncu ? g.total : ncu;
+  const long long want = (long long)ncu * (tile == 256 ? 1 : 2);
+  const int grid = (int)(g.total < want ? g.total : want);
   // stagger quantum = a quarter of one tile's main-loop time (~3500 cycles per k-tile), only when every
   // workgroup walks several tiles and the epilogue writes a lot (any plane / fp32 output)
   static int stagger_on = -1;
-  if (stagger_on < 0) { const char* e = getenv("CIPS_X3_STAGGER"); stagger_on = (e && atoi(e) == 0) ? 0 : 1; }
+  if (stagger_on < 0) { const char* e = getenv("CIPS_X3_STAGGER"); stagger_on = (e && atoi(e) == 1) ? 1 : 0; }   // measured: no effect (the F/D GEMMs are memory-system bound), off by default
   g.stagger_cycles = (stagger_on && g.total >= 2 * grid) ? (d->K / BK) * 3500 / 4 : 0;
   if (tile == 256)
     hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3(grid), dim3(512), Cfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
