@@ -87,6 +87,15 @@ def gemm_roofline(dev, b, n, mode):
          "frac": round(ach / peak, 4), "traffic": None, "launch_us": round(t * 1e6, 1), "flops_per_launch": flops}
     if mode == "bf16x3":
         r["note"] = "algorithmic fp32-equivalent flops; raw bf16 MFMA rate = 3x achieved vs 2500 dense peak"
+        # HBM bytes per launch of exactly this kernel/shape from the PMC counters, collected in their own
+        # rocprofv3 --pmc passes (scripts/pmc_roofline.sh -> profiles/r1_roofline_pmc.json); null if absent
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_roofline_pmc.json")))
+            if b == 32 and n == 4096:
+                r["traffic"] = pm["hbm_bytes"]
+                r["traffic_algorithmic_bytes"] = pm["algorithmic_bytes"]
+        except Exception:
+            pass
     return r
 
 

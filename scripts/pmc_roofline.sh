@@ -1,0 +1,30 @@
+#!/bin/bash
+# HBM traffic of the roofline kernel from PMC counters, separate passes (reads, writes), kernel-trace only.
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+REPO=$PWD
+for pass in "rd TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "wr TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+  set -- $pass; tag=$1; shift
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $REPO/gpurun_out/pmcroof_$tag -o p -- python $REPO/scripts/roofline_kernel.py > $REPO/gpurun_out/pmcroof_$tag.log 2>&1)
+done
+python - <<'PY'
+import csv, glob, json, collections
+vals = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/pmcroof_*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "gemm_bf16x3" in r["Kernel_Name"]:
+            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+m = {k: sum(v[1:]) / max(1, len(v) - 1) for k, v in vals.items()}     # skip the first (cold) launch
+# gfx950: wide reads are 128-B requests tallied once (MI355X_MICROARCH.md §HBM: FETCH_SIZE = RDREQ*64 B reads half);
+# 32-B requests are counted separately; writes: 64-B requests (WRREQ_64B) else 32 B.
+rd = (m.get("TCC_EA0_RDREQ_sum", 0) - m.get("TCC_EA0_RDREQ_32B_sum", 0)) * 128 + m.get("TCC_EA0_RDREQ_32B_sum", 0) * 32
+wr = m.get("TCC_EA0_WRREQ_64B_sum", 0) * 64 + (m.get("TCC_EA0_WRREQ_sum", 0) - m.get("TCC_EA0_WRREQ_64B_sum", 0)) * 32
+out = {"kernel": "gemm_bf16x3_kernel<4>, modfc 512x512 forward form, B=32, M=4096, N=512, K=512",
+       "counters_mean_per_launch": m, "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
+       "algorithmic_bytes": 32 * 4096 * 512 * 4 + 32 * 512 * 512 * 4 + 32 * 4096 * 512 * 8,
+       "method": "rocprofv3 --kernel-trace --pmc (separate passes for reads and writes); reads = RDREQ x 128 B "
+                 "(32-B requests x 32 B), writes = WRREQ_64B x 64 B; first launch dropped"}
+json.dump(out, open("gpurun_out/roofline_pmc.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
