@@ -20,10 +20,15 @@
 //
 // Tiling (wave64): 256x128x32 workgroup tile, 512 threads = 8 waves as 4(M) x 2(N), each wave a
 // 64x64 sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs), 24 MFMAs per k-tile per wave.
-// LDS: four planes per stage (A_hi, A_lo, B_hi, B_lo), rows padded to 80 bytes so that the
-// ds_read_b128 fragment reads are bank-conflict free (5r mod 16 is a bijection over each 16-lane
-// service group), two stages (120 KB) with a one-tile register prefetch and a single barrier per
-// k-tile.  Workgroup ids are remapped per XCD like the fp32 kernel.
+// Staging is LDS-DMA (global_load_lds_dwordx4, no VGPR round trip): four planes per stage (A_hi, A_lo,
+// B_hi, B_lo), 64-byte rows without padding, the four 16-byte k-chunks of a row XOR-swizzled by
+// (row>>2)&3 — applied to the per-lane SOURCE address of the DMA (its LDS image is lane-linear) and to the
+// ds_read_b128 fragment reads, which makes both conflict-free.  A 3-stage ring keeps two k-tiles of DMA in
+// flight across raw s_barriers with counted s_waitcnt vmcnt(N); one barrier per k-tile.  Workgroups are
+// persistent (one per CU) and walk the tile list XCD-contiguously.  The epilogue stages every auxiliary
+// input and every output through a per-wave LDS scratch so that HBM only sees 16-byte accesses.
+// A 128x128 / 4-wave / 2-stage form (two workgroups per CU) is selectable with CIPS_X3_TILE=128
+// (measured equal within noise).
 #include "common.h"
 #include "../../include/cips3d_hip.h"
 #include <stdlib.h>
