@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9" | head -4 > gpurun_out/device.txt
 nproc >> gpurun_out/device.txt
-for f in tests/test_gpu_kernels.py tests/test_gpu_generator.py tests/test_gpu_discriminator.py; do
+for f in tests/test_gpu_kernels.py tests/test_gpu_generator.py tests/test_gpu_discriminator.py tests/test_gpu_train_step.py; do
   n=$(basename $f .py)
   timeout 900 python -m pytest $f -m gpu -q -s --tb=short > gpurun_out/$n.log 2>&1
   echo "$n exit $?" | tee -a gpurun_out/summary.txt
