@@ -16,8 +16,8 @@ def test_one_gan_step_like_train_py():
     torch.manual_seed(0)
     G = GeneratorNerfINR(**G_CFG, device=d).to(d); G.device = d
     D = Discriminator_MultiScale_Aux(**D_CFG).to(d)
-    opt_G = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0, 0.999))
-    opt_D = torch.optim.Adam(D.parameters(), lr=2e-3, betas=(0, 0.999))
+    opt_G = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.0, 0.999))
+    opt_D = torch.optim.Adam(D.parameters(), lr=2e-3, betas=(0.0, 0.999))
     kw = dict(fov=12, ray_start=0.88, ray_end=1.12, num_steps=6, h_stddev=0.3, v_stddev=0.155,
               hierarchical_sample=True, psi=1., sample_dist="gaussian")
     b, img = 2, 16
