@@ -64,6 +64,7 @@ struct Args {
   cips_gemm_x3_desc d;
   int tiles_m, tiles_n, total;
   int stagger_cycles;   // start-phase quantum (shader cycles), 0 = no staggering
+  int ncu;
 };
 
 __device__ __forceinline__ u16 f2bf(float v) {
@@ -94,7 +95,10 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   // to the main loop's time whatever the phase relation (268 MB of fp32 C cost ~75 us on top of a 205 us main
   // loop), i.e. the kernel is bound by the memory system, not by MFMA issue.
   if (g.stagger_cycles > 0) {
-    const int phase = (blockIdx.x >> 3) & 3;
+    // 256-row form: four phases across CUs.  128-row form (two workgroups per CU): the second half of the grid
+    // (the co-resident partner of workgroup b is b + #CUs) starts half a tile later, so that one workgroup's
+    // store drain overlaps its partner's MFMA phase.
+    const int phase = (WM == 4) ? ((blockIdx.x >> 3) & 3) : (blockIdx.x >= g.ncu ? 2 : 0);
     for (int i = 0; i < phase * g.stagger_cycles; i += 64 * 100) __builtin_amdgcn_s_sleep(100);
   }
   for (int tseq = blockIdx.x; tseq < g.total; tseq += gridDim.x) {
@@ -486,7 +490,8 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   // workgroup walks several tiles and the epilogue writes a lot (any plane / fp32 output)
   static int stagger_on = -1;
   if (stagger_on < 0) { const char* e = getenv("CIPS_X3_STAGGER"); stagger_on = (e && atoi(e) == 1) ? 1 : 0; }   // measured: no effect (the F/D GEMMs are memory-system bound), off by default
-  g.stagger_cycles = (stagger_on && g.total >= 2 * grid) ? (d->K / BK) * 3500 / 4 : 0;
+  g.stagger_cycles = (stagger_on && g.total >= 2 * grid) ? (d->K / BK) * (tile == 256 ? 3500 : 1800) / 4 : 0;
+  g.ncu = ncu;
   if (tile == 256)
     hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3(grid), dim3(512), Cfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
   else
