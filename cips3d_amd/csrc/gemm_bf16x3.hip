@@ -424,6 +424,171 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
 #undef WAVE_SYNC
 }
 
+// ------------------------------------------------------------------------------------------------
+// K-major form ("TN"):  C[m][n] = sum_k A[k][m] * B[k][n], both operands stored with the contraction
+// index as the ROW (A planes [K][lda], B planes [K][ldb]) — i.e. the row-major activation / gradient planes
+// themselves, so the weight-gradient GEMMs (dW = X^T G) need no transposed copies in HBM.
+// The MFMA fragments want 8 consecutive k per lane; they are produced by the LDS transpose read
+// ds_read_b64_tr_b16 (semantics probed on hardware, scripts/probe/tr_probe.hip: within a 16-lane group lane t
+// receives, for j = 0..3, element (t & 3) of the 8-byte chunk addressed by lane 4j + (t >> 2)): lane s of a
+// group points at row kb + (s>>2), columns mb + 4(s&3).. of the k-major tile and gets column mb + s, rows
+// kb..kb+3.  LDS image per stage: A [32 k][256 m], B [32 k][128 n] bf16 per plane, rows unpadded; 32-byte
+// column pairs XOR-swizzled by 2*(k&3) (in the DMA source address and in the reads) so that the 32 lanes of a
+// service group hit 8 distinct 32-byte segments.  Pipeline, ring and persistence as in the NT kernel.
+// ------------------------------------------------------------------------------------------------
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_km_kernel(Args g) {
+  constexpr int BM = 256, NSTAGE = 3, PIECES = 6, DIST = NSTAGE - 1;
+  constexpr int AROW = 512, BROW = 256;                 // bytes per k-row of the A / B image
+  constexpr int OFF_AHI = 0, OFF_ALO = 32 * AROW, OFF_BHI = 2 * 32 * AROW, OFF_BLO = OFF_BHI + 32 * BROW;
+  constexpr int STAGE = OFF_BLO + 32 * BROW;            // 49152
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const cips_gemm_x3_desc& d = g.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int s16 = lane & 15, mhalf = (lane >> 4) & 1;
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+
+  for (int tseq = blockIdx.x; tseq < g.total; tseq += gridDim.x) {
+  int bid = tseq;
+  {
+    const int nx = 8;
+    int q = g.total / nx, r = g.total % nx;
+    int xcd = bid % nx, idx = bid / nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + idx;
+  }
+  const int tn = bid % g.tiles_n;
+  const int tm = (bid / g.tiles_n) % g.tiles_m;
+  const int bz = bid / (g.tiles_n * g.tiles_m);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = d.M, N = d.N, K = d.K;
+  const u16* Ahi = (const u16*)d.A_hi + (long long)bz * d.strideA;
+  const u16* Alo = (const u16*)d.A_lo + (long long)bz * d.strideA;
+  const u16* Bhi = (const u16*)d.B_hi + (long long)bz * d.strideB;
+  const u16* Blo = (const u16*)d.B_lo + (long long)bz * d.strideB;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto issue_tile = [&](int stage, int k0) {
+    unsigned char* s = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                        // A: 16 pieces per plane (2 k-rows each), 2 per wave
+      const int idx = uw + 8 * i;
+      const int k = 2 * idx + (lane >> 5), c16 = lane & 31;
+      const int pr = (c16 >> 1) ^ (2 * (k & 3));
+      int m = m0 + (pr * 2 + (c16 & 1)) * 8;
+      m = (m < M) ? m : 0;                               // clamped columns only feed outputs that are never stored
+      const long long so = (long long)(k0 + k) * d.lda + m;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ahi + so),
+                                       (__attribute__((address_space(3))) void*)(s + OFF_AHI + idx * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Alo + so),
+                                       (__attribute__((address_space(3))) void*)(s + OFF_ALO + idx * 1024), 16, 0, 0);
+    }
+    {                                                    // B: 8 pieces per plane (4 k-rows each), 1 per wave
+      const int idx = uw;
+      const int k = 4 * idx + (lane >> 4), c16 = lane & 15;
+      const int pr = (c16 >> 1) ^ (2 * (k & 3));
+      int n = n0 + (pr * 2 + (c16 & 1)) * 8;
+      n = (n < N) ? n : 0;
+      const long long so = (long long)(k0 + k) * d.ldb + n;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bhi + so),
+                                       (__attribute__((address_space(3))) void*)(s + OFF_BHI + idx * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Blo + so),
+                                       (__attribute__((address_space(3))) void*)(s + OFF_BLO + idx * 1024), 16, 0, 0);
+    }
+  };
+  // transpose-read one 32(m) x 16(k) fragment: two ds_read_b64_tr_b16 (rows kb.. and kb+4..)
+  auto frag = [&](const unsigned char* plane, int rowbytes, int col0, int ks) -> bf16x8 {
+    const int kb = 16 * ks + 8 * hf + (s16 >> 2);                     // this lane's source row for the first read
+    const int col = col0 + 16 * mhalf + 4 * (s16 & 3);
+    const int pr = (col >> 4) ^ (2 * (kb & 3));                       // (kb+4)&3 == kb&3
+    const unsigned char* p0 = plane + kb * rowbytes + pr * 32 + (col & 15) * 2;
+    short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p0);
+    short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p0 + 4 * rowbytes));
+    short8v v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto compute = [&](int stage) {
+    const unsigned char* s = smem + stage * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = frag(s + OFF_AHI, AROW, wm * 64 + i * 32, ks);
+        al[i] = frag(s + OFF_ALO, AROW, wm * 64 + i * 32, ks);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = frag(s + OFF_BHI, BROW, wn * 64 + j * 32, ks);
+        bl[j] = frag(s + OFF_BLO, BROW, wn * 64 + j * 32, ks);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int nk = K / BK;
+#pragma unroll
+  for (int t = 0; t < DIST; ++t)
+    if (t < nk) issue_tile(t, t * BK);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int younger = min(DIST - 1, nk - 1 - kt);
+    if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + DIST < nk) issue_tile((kt + DIST) % NSTAGE, (kt + DIST) * BK);
+    compute(kt % NSTAGE);
+  }
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: fp32 C through the per-wave LDS scratch, 16-byte stores ----
+  constexpr int PITCH = 72;
+  float* sc_f = reinterpret_cast<float*>(smem) + wave * (64 * PITCH);
+  const int wrow0 = m0 + wm * 64, wcol0 = n0 + wn * 64;
+  const long long cb = (long long)bz * d.strideC;
+  const bool vec_c = ((d.ldc & 3) == 0) && ((d.strideC & 3) == 0);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc_f[(i * 32 + mfma_row(r, hf)) * PITCH + j * 32 + l31] = acc[i][j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int id = lane + 64 * c, rr = id >> 4, c4 = (id & 15) * 4;
+    const int row = wrow0 + rr, col = wcol0 + c4;
+    if (row < M && col < N) {
+      const float4 t = *reinterpret_cast<const float4*>(sc_f + rr * PITCH + c4);
+      float* p = d.C + cb + (long long)row * d.ldc + col;
+      if (vec_c && col + 3 < N) *reinterpret_cast<float4*>(p) = t;
+      else { p[0] = t.x; if (col + 1 < N) p[1] = t.y; if (col + 2 < N) p[2] = t.z; if (col + 3 < N) p[3] = t.w; }
+    }
+  }
+  __syncthreads();
+  }  // persistent tile loop
+}
+
 // fp32 (rows, cols) row-major -> split planes row-major [rows][ldp] and/or transposed [cols][ldt]
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, u16* __restrict__ phi,
                                                            u16* __restrict__ plo, u16* __restrict__ thi,
@@ -496,6 +661,33 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
     hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3(grid), dim3(512), Cfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
   else
     hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, dim3(grid), dim3(256), Cfg<2>::SMEM_BYTES, (hipStream_t)stream, g);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t stream) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || !d->C) return (int)hipErrorInvalidValue;
+  if ((d->K & 31) || (d->M & 7) || (d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
+    return (int)hipErrorInvalidValue;
+  if (d->P_hi || d->T_hi || d->mask || d->add || d->rgb_g || d->C_unmasked || d->mask_out || d->res_hi || d->act)
+    return (int)hipErrorNotSupported;            // the K-major form has the plain fp32 epilogue only
+  Args g;
+  g.d = *d;
+  g.tiles_m = (d->M + 255) / 256;
+  g.tiles_n = (d->N + BN - 1) / BN;
+  long long total = (long long)g.tiles_m * g.tiles_n * d->batch;
+  if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  g.total = (int)total;
+  g.stagger_cycles = 0; g.ncu = 0;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+    ncu = (ncu / 8) * 8;
+    hipFuncSetAttribute((const void*)gemm_bf16x3_km_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  }
+  const int grid = g.total < ncu ? g.total : ncu;
+  hipLaunchKernelGGL(gemm_bf16x3_km_kernel, dim3(grid), dim3(512), 147456, (hipStream_t)stream, g);
   return CIPS_CHECK_LAUNCH();
 }
 

@@ -493,6 +493,18 @@ def gemm_x3(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, T
     check(lib.cips_gemm_bf16x3(_ct.byref(d), _stream()), "cips_gemm_bf16x3")
 
 
+def gemm_x3_km(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C):
+    """C[b][m][n] = sum_k A[b][k][m] * B[b][k][n]; A, B: Planes stored [K][ld] (k-major), C fp32 (M,N)."""
+    lib = _lib.load()
+    d = GemmX3Desc()
+    d.A_hi, d.A_lo, d.B_hi, d.B_lo = _p(A.hi), _p(A.lo), _p(Bm.hi), _p(Bm.lo)
+    d.M, d.N, d.K, d.lda, d.ldb = M, N, K, lda, ldb
+    d.strideA, d.strideB, d.batch = strideA, strideB, batch
+    d.C, d.ldc, d.strideC = _p(C), N, M * N
+    d.slope = LRELU_SLOPE
+    check(lib.cips_gemm_bf16x3_km(_ct.byref(d), _stream()), "cips_gemm_bf16x3_km")
+
+
 def split_planes(x, want_p=True, want_t=True):
     """x (B, rows, cols) fp32 -> Planes row-major (B,rows,cols) and transposed (B,cols,rows)."""
     lib = _lib.load()

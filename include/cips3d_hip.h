@@ -200,6 +200,9 @@ typedef struct cips_gemm_x3_desc {
 } cips_gemm_x3_desc;
 
 int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream);
+/* K-major form: C[b][m][n] = sum_k A[b][k][m] * B[b][k][n] (A planes [K][lda], B planes [K][ldb]: the row-major
+ * activation / gradient planes themselves; LDS transpose reads build the fragments).  fp32 C output only. */
+int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t stream);
 
 /* fp32 (rows, cols) [ldx] -> split bf16 planes row-major [rows][ldp] and/or transposed [cols][ldt]. */
 int cips_split_planes(const float* x, void* p_hi, void* p_lo, void* t_hi, void* t_lo, int rows, int cols,

@@ -37,3 +37,4 @@ x2P, _ = ops.split_planes(x2, want_t=False); w2P, _ = ops.split_planes(w2, want_
 f2 = 2.0 * B * n * C * K2
 t = timeit(lambda: ops.gemm_x3(x2P, w2P, n, C, K2, K2, K2, B, n*K2, C*K2), reps=5); print(f"x3 F K=2048 noout {t*1e6:8.1f} us {f2/t/1e12:7.1f} TF")
 t = timeit(lambda: ops.gemm_x3(x2P, w2P, n, C, K2, K2, K2, B, n*K2, C*K2, C=out), reps=5); print(f"x3 F K=2048 C out {t*1e6:8.1f} us {f2/t/1e12:7.1f} TF")
+t = timeit(lambda: ops.gemm_x3_km(xP, oP, C, C, n, C, C, B, n*C, n*C, gw)); print(f"x3 W k-major (tr) {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF")

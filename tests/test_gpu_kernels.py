@@ -280,6 +280,24 @@ def test_gemm_bf16x3_accuracy_and_outputs(M, N, K, batch):
     assert rel_err(T.float()[:, :, :M].transpose(1, 2), C) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,batch", [(256, 128, 32, 1), (512, 512, 4096, 2), (32, 512, 256, 3), (128, 128, 3072, 4),
+                                         (64, 128, 1024, 2), (200, 72, 64, 2)])
+def test_gemm_bf16x3_kmajor(M, N, K, batch):
+    """K-major (TN) form through LDS transpose reads: C = A^T B with A (K,M), B (K,N) row-major planes."""
+    from cips3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = torch.randn(batch, K, M, generator=g); B = torch.randn(batch, K, N, generator=g)
+    ref = torch.bmm(A.double().transpose(1, 2), B.double())
+    Ap = ops.Planes(*[t.to(d) for t in _planes(A)]); Bp = ops.Planes(*[t.to(d) for t in _planes(B)])
+    C = torch.full((batch, M, N), float("nan"), device=d)
+    ops.gemm_x3_km(Ap, Bp, M, N, K, M, N, batch, K * M, K * N, C)
+    torch.cuda.synchronize()
+    e = rel_err(C, ref)
+    print(f"bf16x3 k-major gemm {M}x{N}x{K}: rel err vs fp64 {e:.3e}")
+    assert torch.isfinite(C).all() and e < 3e-5
+
+
 def test_gemm_bf16x3_epilogues():
     from cips3d_amd import ops
     d = dev()
