@@ -456,6 +456,8 @@ class InrHeadFunction(torch.autograd.Function):
 import os as _os
 INR_MODE = _os.environ.get("CIPS_INR_MODE", "bf16x3")   # "bf16x3" (default, ~1e-5 rel. per layer) or "f32" (exact fp32 MFMA)
 BF = torch.bfloat16
+INR_W_KMAJOR = _os.environ.get("CIPS_INR_W_KMAJOR", "1") == "1"   # dW GEMMs read the row-major planes through LDS
+                                                                 # transpose reads: no transposed planes in HBM
 
 
 class Planes:
@@ -570,7 +572,8 @@ class InrHeadX3Function(torch.autograd.Function):
         rgbp = [_c(p.detach()) for p in params[4 * nblocks:]]
         _chk(x0, *[t for blk in blocks for t in blk], *rgbp)
         train = any(ctx.needs_input_grad)       # no-grad / inference: no transposed planes, nothing kept
-        xP, xT = split_planes(x0, want_t=train)
+        want_t = train and not INR_W_KMAJOR     # K-major dW form reads the row-major planes: no transposed copies
+        xP, xT = split_planes(x0, want_t=want_t)
         rgb = torch.empty(B, n, 3, device=dev)
         first_rgb = True
         saved = []
@@ -578,13 +581,13 @@ class InrHeadX3Function(torch.autograd.Function):
             cin, cout = W1.shape
             wb1, wbt1, d1 = modfc_prep_x3(W1, s1)
             a1P = Planes.empty(B, n, cout, device=dev)
-            a1T = Planes.empty(B, cout, n, device=dev) if train else None
+            a1T = Planes.empty(B, cout, n, device=dev) if want_t else None
             gemm_x3(xP, wbt1, n, cout, cin, cin, cin, B, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
                     act=1)
             wb2, wbt2, d2 = modfc_prep_x3(W2, s2)
             skip = (k >= 4) and (cin == cout)
             oP = Planes.empty(B, n, cout, device=dev)
-            oT = Planes.empty(B, cout, n, device=dev) if train else None
+            oT = Planes.empty(B, cout, n, device=dev) if want_t else None
             if skip:
                 m2 = torch.empty(B, n, cout, device=dev, dtype=BF) if train else None
                 gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
@@ -598,12 +601,14 @@ class InrHeadX3Function(torch.autograd.Function):
                 first_rgb = False
             if train:
                 # keep for backward: xT (dW1), a1 gate + a1T (dW2), out planes (ToRGB grad), m2 gate, weights
-                saved.append(dict(xT=xT, a1m=a1P.hi, a1T=a1T, oP=oP, m2=m2, wb1=wb1, d1=d1, wb2=wb2, d2=d2, skip=skip))
+                saved.append(dict(xT=xT, xP=xP, a1P=a1P, a1m=a1P.hi, a1T=a1T, oP=oP, m2=m2, wb1=wb1, d1=d1, wb2=wb2, d2=d2,
+                                  skip=skip))
             xP, xT = oP, oT
         if first_rgb:
             rgb.zero_()
         ctx.nblocks, ctx.blocks, ctx.rgbp, ctx.saved = nblocks, blocks, rgbp, saved
         ctx.dims = (B, n)
+        ctx.kmajor = INR_W_KMAJOR
         return rgb
 
     @staticmethod
@@ -617,7 +622,9 @@ class InrHeadX3Function(torch.autograd.Function):
         grads_rgb = [None] * len(rgbp)
         width = blocks[-1][2].shape[1]
         k = nblocks - 1
-        gP, gT = Planes.empty(B, n, width, device=dev), Planes.empty(B, width, n, device=dev)
+        km = ctx.kmajor
+        PT = (lambda c: None) if km else (lambda c: Planes.empty(B, c, n, device=dev))
+        gP, gT = Planes.empty(B, n, width, device=dev), PT(width)
         Dout = None
         if k >= 3:
             # grad wrt out_k = drgb @ T_k as a K=32 zero-padded bf16x3 GEMM (gate of a2_k fused)
@@ -630,7 +637,9 @@ class InrHeadX3Function(torch.autograd.Function):
             gemm_x3(dP, tP, n, width, 32, 32, 32, B, n * 32, 0, P=gP, T=gT, ldt=n, strideT=width * n,
                     C_unmasked=Dout, mask=saved[k]["m2"])
         else:
-            gP.hi.zero_(); gP.lo.zero_(); gT.hi.zero_(); gT.lo.zero_()
+            gP.hi.zero_(); gP.lo.zero_()
+            if gT is not None:
+                gT.hi.zero_(); gT.lo.zero_()
             Dout = torch.zeros(B, n, width, device=dev) if saved[k]["skip"] else None
         dx0 = None
         for k in range(nblocks - 1, -1, -1):
@@ -642,14 +651,20 @@ class InrHeadX3Function(torch.autograd.Function):
                 grads_rgb[2 * (k - 3)], grads_rgb[2 * (k - 3) + 1] = dT, dtau
             # ---- mod2 ----
             gwb2 = torch.empty(B, cout, cout, device=dev)
-            gemm_x3(sv["a1T"], gT, cout, cout, n, n, n, B, cout * n, cout * n, C=gwb2)
+            if km:
+                gemm_x3_km(sv["a1P"], gP, cout, cout, n, cout, cout, B, n * cout, n * cout, gwb2)
+            else:
+                gemm_x3(sv["a1T"], gT, cout, cout, n, n, n, B, cout * n, cout * n, C=gwb2)
             dW2, ds2 = modfc_prep_bwd(W2, s2, sv["d2"], gwb2)
-            g1P, g1T = Planes.empty(B, n, cout, device=dev), Planes.empty(B, cout, n, device=dev)
+            g1P, g1T = Planes.empty(B, n, cout, device=dev), PT(cout)
             gemm_x3(gP, sv["wb2"], n, cout, cout, cout, cout, B, n * cout, cout * cout, P=g1P, T=g1T, ldt=n,
                     strideT=cout * n, mask=sv["a1m"])
             # ---- mod1 ----
             gwb1 = torch.empty(B, cin, cout, device=dev)
-            gemm_x3(sv["xT"], g1T, cin, cout, n, n, n, B, cin * n, cout * n, C=gwb1)
+            if km:
+                gemm_x3_km(sv["xP"], g1P, cin, cout, n, cin, cout, B, n * cin, n * cout, gwb1)
+            else:
+                gemm_x3(sv["xT"], g1T, cin, cout, n, n, n, B, cin * n, cout * n, C=gwb1)
             dW1, ds1 = modfc_prep_bwd(W1, s1, sv["d1"], gwb1)
             grads_blocks[k] = (dW1, ds1, dW2, ds2)
             if k == 0:
@@ -658,7 +673,7 @@ class InrHeadX3Function(torch.autograd.Function):
             else:
                 pv = saved[k - 1]
                 newD = torch.empty(B, n, cin, device=dev) if pv["skip"] else None
-                gP, gT = Planes.empty(B, n, cin, device=dev), Planes.empty(B, cin, n, device=dev)
+                gP, gT = Planes.empty(B, n, cin, device=dev), PT(cin)
                 gemm_x3(g1P, sv["wb1"], n, cin, cout, cout, cout, B, n * cout, cin * cout, P=gP, T=gT, ldt=n,
                         strideT=cin * n, add=Dout if sv["skip"] else None,
                         rgb_g=drgb2 if k - 1 >= 3 else None, rgb_w=rgbp[2 * (k - 1 - 3)] if k - 1 >= 3 else None,
