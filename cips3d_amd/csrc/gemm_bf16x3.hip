@@ -439,11 +439,29 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef short short8v __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16x3_km_kernel(Args g) {
-  constexpr int BM = 256, NSTAGE = 3, PIECES = 6, DIST = NSTAGE - 1;
-  constexpr int AROW = 512, BROW = 256;                 // bytes per k-row of the A / B image
-  constexpr int OFF_AHI = 0, OFF_ALO = 32 * AROW, OFF_BHI = 2 * 32 * AROW, OFF_BLO = OFF_BHI + 32 * BROW;
-  constexpr int STAGE = OFF_BLO + 32 * BROW;            // 49152
+template <int WM>   // WM = 4: 256x128 tile, 8 waves, 3-stage ring (1 WG/CU); WM = 2: 128x128 tile, 4 waves, 2 stages (2 WGs/CU)
+struct KmCfg {
+  static constexpr int BM = 64 * WM, NW = 2 * WM, THREADS = 64 * NW;
+  static constexpr int NSTAGE = (WM == 4) ? 3 : 2;
+  static constexpr int AROW = 2 * BM, BROW = 256;                       // bytes per k-row of the A / B image
+  static constexpr int A_ROWS_PER_PIECE = 1024 / AROW;                  // 2 (WM=4) or 4 (WM=2)
+  static constexpr int A_PIECES = 32 / A_ROWS_PER_PIECE;                // per plane: 16 or 8
+  static constexpr int A_PER_WAVE = A_PIECES / NW;                      // 2
+  static constexpr int B_PER_WAVE = 8 / NW;                             // 1 or 2
+  static constexpr int PIECES = 2 * A_PER_WAVE + 2 * B_PER_WAVE;        // 6 or 8
+  static constexpr int OFF_AHI = 0, OFF_ALO = 32 * AROW, OFF_BHI = 2 * 32 * AROW, OFF_BLO = OFF_BHI + 32 * BROW;
+  static constexpr int STAGE = OFF_BLO + 32 * BROW;                     // 49152 or 32768
+  static constexpr int SMEM_EPI = NW * 64 * 72 * 4;
+  static constexpr int SMEM_BYTES = (NSTAGE * STAGE > SMEM_EPI) ? NSTAGE * STAGE : SMEM_EPI;
+};
+
+template <int WM>
+__global__ __launch_bounds__(KmCfg<WM>::THREADS, 2) void gemm_bf16x3_km_kernel(Args g) {
+  using KC = KmCfg<WM>;
+  constexpr int BM = KC::BM, NSTAGE = KC::NSTAGE, PIECES = KC::PIECES, DIST = NSTAGE - 1, NW = KC::NW;
+  constexpr int AROW = KC::AROW, BROW = KC::BROW;
+  constexpr int OFF_AHI = KC::OFF_AHI, OFF_ALO = KC::OFF_ALO, OFF_BHI = KC::OFF_BHI, OFF_BLO = KC::OFF_BLO;
+  constexpr int STAGE = KC::STAGE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cips_gemm_x3_desc& d = g.d;
   const int tid = threadIdx.x;
@@ -483,9 +501,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_km_kernel(Args g) {
   auto issue_tile = [&](int stage, int k0) {
     unsigned char* s = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {                        // A: 16 pieces per plane (2 k-rows each), 2 per wave
-      const int idx = uw + 8 * i;
-      const int k = 2 * idx + (lane >> 5), c16 = lane & 31;
+    for (int i = 0; i < KC::A_PER_WAVE; ++i) {           // A: A_PIECES 1-KiB pieces per plane
+      const int idx = uw + NW * i;
+      constexpr int LPR = 64 / KC::A_ROWS_PER_PIECE;     // lanes per k-row of a piece
+      const int k = KC::A_ROWS_PER_PIECE * idx + lane / LPR, c16 = lane % LPR;
       const int pr = (c16 >> 1) ^ (2 * (k & 3));
       int m = m0 + (pr * 2 + (c16 & 1)) * 8;
       m = (m < M) ? m : 0;                               // clamped columns only feed outputs that are never stored
@@ -495,8 +514,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_km_kernel(Args g) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Alo + so),
                                        (__attribute__((address_space(3))) void*)(s + OFF_ALO + idx * 1024), 16, 0, 0);
     }
-    {                                                    // B: 8 pieces per plane (4 k-rows each), 1 per wave
-      const int idx = uw;
+#pragma unroll
+    for (int i = 0; i < KC::B_PER_WAVE; ++i) {           // B: 8 pieces per plane (4 k-rows each)
+      const int idx = uw + NW * i;
       const int k = 4 * idx + (lane >> 4), c16 = lane & 15;
       const int pr = (c16 >> 1) ^ (2 * (k & 3));
       int n = n0 + (pr * 2 + (c16 & 1)) * 8;
@@ -670,9 +690,11 @@ extern "C" int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t str
     return (int)hipErrorInvalidValue;
   if (d->P_hi || d->T_hi || d->mask || d->add || d->rgb_g || d->C_unmasked || d->mask_out || d->res_hi || d->act)
     return (int)hipErrorNotSupported;            // the K-major form has the plain fp32 epilogue only
+  // 256-row tiles when M fills them, else the 128-row form (SIREN weight gradients: M = 128 / 64)
+  const int bm = (d->M > 128) ? 256 : 128;
   Args g;
   g.d = *d;
-  g.tiles_m = (d->M + 255) / 256;
+  g.tiles_m = (d->M + bm - 1) / bm;
   g.tiles_n = (d->N + BN - 1) / BN;
   long long total = (long long)g.tiles_m * g.tiles_n * d->batch;
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -684,10 +706,16 @@ extern "C" int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t str
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     if (ncu <= 0) ncu = 256;
     ncu = (ncu / 8) * 8;
-    hipFuncSetAttribute((const void*)gemm_bf16x3_km_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    hipFuncSetAttribute((const void*)gemm_bf16x3_km_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, KmCfg<4>::SMEM_BYTES);
+    hipFuncSetAttribute((const void*)gemm_bf16x3_km_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, KmCfg<2>::SMEM_BYTES);
   }
-  const int grid = g.total < ncu ? g.total : ncu;
-  hipLaunchKernelGGL(gemm_bf16x3_km_kernel, dim3(grid), dim3(512), 147456, (hipStream_t)stream, g);
+  if (bm == 256) {
+    const int grid = g.total < ncu ? g.total : ncu;
+    hipLaunchKernelGGL(gemm_bf16x3_km_kernel<4>, dim3(grid), dim3(512), KmCfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
+  } else {
+    const int grid = g.total < 2 * ncu ? g.total : 2 * ncu;
+    hipLaunchKernelGGL(gemm_bf16x3_km_kernel<2>, dim3(grid), dim3(256), KmCfg<2>::SMEM_BYTES, (hipStream_t)stream, g);
+  }
   return CIPS_CHECK_LAUNCH();
 }
 

@@ -250,7 +250,8 @@ struct BwdArgs {
   const float* points;
   const float* dfeat;
   const float* dsigma;
-  float *h1, *h2, *hc, *da2, *dac, *red;
+  unsigned short *h1h, *h1l, *h2h, *h2l, *hch, *hcl, *da2h, *da2l, *dach, *dacl;
+  float* red;
   int B, P, chunk, chunks;
 };
 
@@ -272,15 +273,32 @@ __device__ __forceinline__ float reduce32(float (&v)[32], int lane) {
   return v[0];
 }
 
-template <int Q>  // store Q*16 per-lane features of layout "N" into a [rows][Q*32] row-major matrix
-__device__ __forceinline__ void store_layoutN(float* base, long long row, int hf, const float (&v)[Q][16]) {
-  float* p = base + row * (Q * 32) + 4 * hf;
+__device__ __forceinline__ unsigned short f2bf_rne(float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+// store Q*16 per-lane features of layout "N" into [rows][Q*32] row-major split-bf16 planes (x = hi + lo):
+// the k-major operands of the bf16x3 weight-gradient GEMMs (cips_gemm_bf16x3_km), 8 bytes per plane per store
+template <int Q>
+__device__ __forceinline__ void store_layoutN(unsigned short* base_hi, unsigned short* base_lo, long long row, int hf,
+                                              const float (&v)[Q][16]) {
+  unsigned short* ph = base_hi + row * (Q * 32) + 4 * hf;
+  unsigned short* pl = base_lo + row * (Q * 32) + 4 * hf;
 #pragma unroll
   for (int q = 0; q < Q; ++q)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<float4*>(p + q * 32 + 8 * g) =
-          make_float4(v[q][4 * g + 0], v[q][4 * g + 1], v[q][4 * g + 2], v[q][4 * g + 3]);
+    for (int g = 0; g < 4; ++g) {
+      unsigned short h[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = v[q][4 * g + e];
+        h[e] = f2bf_rne(x);
+        l[e] = f2bf_rne(x - __uint_as_float(((unsigned)h[e]) << 16));
+      }
+      *reinterpret_cast<uint2*>(ph + q * 32 + 8 * g) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+      *reinterpret_cast<uint2*>(pl + q * 32 + 8 * g) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+    }
 }
 
 template <bool HW>
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     // ---- recompute layer 0 ----
     float h[4][16];
     layer0<HW, false>(L0, hf, px, py, pz, h, h);   // cos of layer 0 is recomputed at the end (saves 64 live VGPRs)
-    if (valid) store_layoutN<4>(a.h1, gp, hf, h);
+    if (valid) store_layoutN<4>(a.h1h, a.h1l, gp, hf, h);
 
     // ---- recompute layer 1 ----
     f32x16 acc[4];
@@ -323,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     mfma_layer<4, 4>(W1s, 32 * LD1, 1, h, acc);
     float cs2[4][16];
     film_act<HW, true, 4>(acc, sm + OFF_G1, sm + OFF_C1, hf, h, cs2);
-    if (valid) store_layoutN<4>(a.h2, gp, hf, h);
+    if (valid) store_layoutN<4>(a.h2h, a.h2l, gp, hf, h);
     // sum_p dsigma * h2  (gradient of final_layer.weight)
 #pragma unroll
     for (int gI = 0; gI < 2; ++gI) {
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     mfma_layer<2, 4>(Wcs, 32 * LDC, 1, h, accc);
     float hc[2][16], csc[2][16];
     film_act<HW, true, 2>(accc, sm + OFF_GC, sm + OFF_CC, hf, hc, csc);
-    if (valid) store_layoutN<2>(a.hc, gp, hf, hc);
+    if (valid) store_layoutN<2>(a.hch, a.hcl, gp, hf, hc);
 
     // ---- d hc = Wf^T dfeat   (K = 32 channels, M = 64) ----
     float df[1][16];
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
           dpc[q][r] = sm[OFF_GC + featidx(q, r, 0) + 4 * hf] * d;
           if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-      if (valid) store_layoutN<2>(a.dac, gp, hf, hc);
+      if (valid) store_layoutN<2>(a.dach, a.dacl, gp, hf, hc);
       r_dac += reduce32(v, lane);
     }
 
@@ -394,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
         dp2[q][r] = sm[OFF_G1 + f] * d;
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
-    if (valid) store_layoutN<4>(a.da2, gp, hf, h);
+    if (valid) store_layoutN<4>(a.da2h, a.da2l, gp, hf, h);
 #pragma unroll
     for (int gI = 0; gI < 2; ++gI) {
       float v[32];
@@ -481,13 +499,15 @@ extern "C" int cips_siren_bwd_rows(int B, int P) {
 }
 
 extern "C" int cips_siren_bwd_data(const cips_siren_weights* w, const float* points,
-                                   const float* dfeat, const float* dsigma, float* h1, float* h2,
-                                   float* hc, float* da2, float* dac, float* red, int B, int P,
-                                   cips_stream_t stream) {
+                                   const float* dfeat, const float* dsigma, void* h1_hi, void* h1_lo, void* h2_hi,
+                                   void* h2_lo, void* hc_hi, void* hc_lo, void* da2_hi, void* da2_lo, void* dac_hi,
+                                   void* dac_lo, float* red, int B, int P, cips_stream_t stream) {
   if (!w || B <= 0 || P <= 0) return (int)hipErrorInvalidValue;
   BwdArgs a;
   a.w = *w; a.points = points; a.dfeat = dfeat; a.dsigma = dsigma;
-  a.h1 = h1; a.h2 = h2; a.hc = hc; a.da2 = da2; a.dac = dac; a.red = red;
+  a.h1h = (unsigned short*)h1_hi; a.h1l = (unsigned short*)h1_lo; a.h2h = (unsigned short*)h2_hi; a.h2l = (unsigned short*)h2_lo;
+  a.hch = (unsigned short*)hc_hi; a.hcl = (unsigned short*)hc_lo; a.da2h = (unsigned short*)da2_hi; a.da2l = (unsigned short*)da2_lo;
+  a.dach = (unsigned short*)dac_hi; a.dacl = (unsigned short*)dac_lo; a.red = red;
   a.B = B; a.P = P; a.chunk = BWD_CHUNK; a.chunks = (P + BWD_CHUNK - 1) / BWD_CHUNK;
   dim3 grid(a.chunks, B);
   size_t smem = SMEM_FLOATS * sizeof(float);

@@ -165,32 +165,29 @@ class SirenFunction(torch.autograd.Function):
         dfeat = _c(dfeat) if dfeat is not None else torch.zeros(B, P, 32, device=dev)
         dsigma = _c(dsigma) if dsigma is not None else torch.zeros(B, P, device=dev)
         BP = B * P
-        h1 = torch.empty(BP, 128, device=dev)
-        h2 = torch.empty(BP, 128, device=dev)
-        hc = torch.empty(BP, 64, device=dev)
-        da2 = torch.empty(BP, 128, device=dev)
-        dac = torch.empty(BP, 64, device=dev)
+        h1, h2, da2 = (Planes.empty(BP, 128, device=dev) for _ in range(3))
+        hc, dac = (Planes.empty(BP, 64, device=dev) for _ in range(2))
         rows = lib.cips_siren_bwd_rows(B, P)
         red = torch.empty(rows, 868, device=dev)
         sw = _siren_struct(t)
-        check(lib.cips_siren_bwd_data(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(h1), _p(h2), _p(hc),
-                                      _p(da2), _p(dac), _p(red), B, P, _stream()), "cips_siren_bwd_data")
+        check(lib.cips_siren_bwd_data(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(h1.hi), _p(h1.lo), _p(h2.hi),
+                                      _p(h2.lo), _p(hc.hi), _p(hc.lo), _p(da2.hi), _p(da2.lo), _p(dac.hi), _p(dac.lo),
+                                      _p(red), B, P, _stream()), "cips_siren_bwd_data")
         R = red.view(B, rows // B, 868).sum(1)          # (B, 868) deterministic reduction of partial rows
-        # weight-gradient contractions over the points (K = P per image, split-K)
-        sp = _split_k(P, 32)
+        # weight-gradient contractions over the points (K = P per image, split-K) on the bf16x3 K-major GEMM
+        sp = _split_k(P, 16)
         Kc = P // sp
         G1 = torch.empty(B * sp, 128, 128, device=dev)   # da2^T @ h1
-        gemm(da2, h1, G1, 128, 128, Kc, 128, 128, 128, batch=B * sp, strideA=Kc * 128, strideB=Kc * 128,
-             strideC=128 * 128, a_kmajor=True)
+        gemm_x3_km(da2, h1, 128, 128, Kc, 128, 128, B * sp, Kc * 128, Kc * 128, G1)
         G1 = G1.view(B, sp, 128, 128).sum(1)
         Gc = torch.empty(B * sp, 64, 128, device=dev)    # dac^T @ h2
-        gemm(dac, h2, Gc, 64, 128, Kc, 64, 128, 128, batch=B * sp, strideA=Kc * 64, strideB=Kc * 128,
-             strideC=64 * 128, a_kmajor=True)
+        gemm_x3_km(dac, h2, 64, 128, Kc, 64, 128, B * sp, Kc * 64, Kc * 128, Gc)
         Gc = Gc.view(B, sp, 64, 128).sum(1)
+        hcf = hc.float()                                 # the 32x64 colour-linear gradient stays on the fp32 GEMM
         spf = _split_k(BP, 1024)
         Kf = BP // spf
         Gf = torch.empty(spf, 32, 64, device=dev)        # dfeat^T @ hc (no per-image scale)
-        gemm(dfeat, hc, Gf, 32, 64, Kf, 32, 64, 64, batch=spf, strideA=Kf * 32, strideB=Kf * 64,
+        gemm(dfeat, hcf, Gf, 32, 64, Kf, 32, 64, 64, batch=spf, strideA=Kf * 32, strideB=Kf * 64,
              strideC=32 * 64, a_kmajor=True)
         dwf = Gf.sum(0)
         # ---- assemble parameter / FiLM gradients (tiny tensors) ----

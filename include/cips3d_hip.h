@@ -79,19 +79,21 @@ int cips_siren_fwd(const cips_siren_weights* w, const float* points,
 
 /* Backward, stage 1 ("data" pass; recomputes the forward in-kernel, saves no
  * forward activations).  In: upstream grads dfeat (B,P,32), dsigma (B,P).
- * Out (HBM staging for the weight-gradient GEMMs, all [B*P][F] row-major):
- *   h1 (B*P,128), h2 (B*P,128), hc (B*P,64)       recomputed activations
- *   da2 (B*P,128), dac (B*P,64)                    d loss / d sine-argument of layer 1 / colour layer
+ * Out (HBM staging for the weight-gradient GEMMs; split-bf16 planes x = hi + lo, [B*P][F] row-major,
+ *      i.e. the k-major operands of cips_gemm_bf16x3_km with K = points):
+ *   h1, h2 (B*P,128), hc (B*P,64)         recomputed activations
+ *   da2 (B*P,128), dac (B*P,64)           d loss / d sine-argument of layer 1 / colour layer
  * Out (per-partial-row reductions, partial rows = cips_siren_bwd_rows(B,P),
  *      each row belongs to one image: image = row / (rows/B)):
- *   red (rows, 832): [0,128) sum_p da1 | [128,512) sum_p da1*x_c (c=0..2, 128 each)
- *                    | [512,640) sum_p da2 | [640,704) sum_p dac
- *                    | [704,832) sum_p dsigma*h2
+ *   red (rows, 868): [0,128) sum_p da1 | [128,512) sum_p da1*x_c (c=0..2, 128 each)
+ *                    | [512,640) sum_p da2 | [640,704) sum_p dac | [704,832) sum_p dsigma*h2
+ *                    | [832,864) sum_p dfeat | [864] sum_p dsigma
  */
 int cips_siren_bwd_rows(int B, int P);
 int cips_siren_bwd_data(const cips_siren_weights* w, const float* points,
                         const float* dfeat, const float* dsigma,
-                        float* h1, float* h2, float* hc, float* da2, float* dac,
+                        void* h1_hi, void* h1_lo, void* h2_hi, void* h2_lo, void* hc_hi, void* hc_lo,
+                        void* da2_hi, void* da2_lo, void* dac_hi, void* dac_lo,
                         float* red, int B, int P, cips_stream_t stream);
 
 /* ------------------------------------------------------------------ */
