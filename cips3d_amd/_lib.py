@@ -56,6 +56,9 @@ SIGNATURES = {
     "cips_rays_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_siren_fwd": (i32, [C.POINTER(SirenWeights), vp, vp, vp, i32, i32, vp]),
     "cips_siren_bwd_rows": (i32, [i32, i32]),
+    "cips_siren_bwd_x3_chunks": (i32, [i32, i32]),
+    "cips_siren_bwd_x3_gpart": (i32, []),
+    "cips_siren_bwd_x3": (i32, [C.POINTER(SirenWeights), vp, vp, vp, vp, vp, i32, i32, vp]),
     "cips_siren_bwd_data": (i32, [C.POINTER(SirenWeights)] + [vp] * 14 + [i32, i32, vp]),
     "cips_resample_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_composite_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

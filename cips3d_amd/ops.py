@@ -130,6 +130,9 @@ def _split_k(P, target=8):
     return 1
 
 
+SIREN_BWD_MODE = __import__("os").environ.get("CIPS_SIREN_BWD", "x3")   # "x3": fused bf16x3 backward; "staged": data pass + GEMMs
+
+
 class SirenFunction(torch.autograd.Function):
     """feat (B,P,32), sigma (B,P) = siren(points; weights, per-image FiLM vectors).
 
@@ -164,32 +167,46 @@ class SirenFunction(torch.autograd.Function):
         dev = points.device
         dfeat = _c(dfeat) if dfeat is not None else torch.zeros(B, P, 32, device=dev)
         dsigma = _c(dsigma) if dsigma is not None else torch.zeros(B, P, device=dev)
-        BP = B * P
-        h1, h2, da2 = (Planes.empty(BP, 128, device=dev) for _ in range(3))
-        hc, dac = (Planes.empty(BP, 64, device=dev) for _ in range(2))
-        rows = lib.cips_siren_bwd_rows(B, P)
-        red = torch.empty(rows, 868, device=dev)
         sw = _siren_struct(t)
-        check(lib.cips_siren_bwd_data(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(h1.hi), _p(h1.lo), _p(h2.hi),
-                                      _p(h2.lo), _p(hc.hi), _p(hc.lo), _p(da2.hi), _p(da2.lo), _p(dac.hi), _p(dac.lo),
-                                      _p(red), B, P, _stream()), "cips_siren_bwd_data")
-        R = red.view(B, rows // B, 868).sum(1)          # (B, 868) deterministic reduction of partial rows
-        # weight-gradient contractions over the points (K = P per image, split-K) on the bf16x3 K-major GEMM
-        sp = _split_k(P, 16)
-        Kc = P // sp
-        G1 = torch.empty(B * sp, 128, 128, device=dev)   # da2^T @ h1
-        gemm_x3_km(da2, h1, 128, 128, Kc, 128, 128, B * sp, Kc * 128, Kc * 128, G1)
-        G1 = G1.view(B, sp, 128, 128).sum(1)
-        Gc = torch.empty(B * sp, 64, 128, device=dev)    # dac^T @ h2
-        gemm_x3_km(dac, h2, 64, 128, Kc, 64, 128, B * sp, Kc * 64, Kc * 128, Gc)
-        Gc = Gc.view(B, sp, 64, 128).sum(1)
-        hcf = hc.float()                                 # the 32x64 colour-linear gradient stays on the fp32 GEMM
-        spf = _split_k(BP, 1024)
-        Kf = BP // spf
-        Gf = torch.empty(spf, 32, 64, device=dev)        # dfeat^T @ hc (no per-image scale)
-        gemm(dfeat, hcf, Gf, 32, 64, Kf, 32, 64, 64, batch=spf, strideA=Kf * 32, strideB=Kf * 64,
-             strideC=32 * 64, a_kmajor=True)
-        dwf = Gf.sum(0)
+        if SIREN_BWD_MODE == "x3":
+            # fused kernel: recompute + data gradients + weight-gradient contractions, nothing staged in HBM
+            chunks = lib.cips_siren_bwd_x3_chunks(B, P)
+            gw = lib.cips_siren_bwd_x3_gpart()
+            red = torch.empty(B * chunks * 4, 868, device=dev)
+            gpart = torch.empty(B * chunks, gw, device=dev)
+            check(lib.cips_siren_bwd_x3(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(red), _p(gpart), B, P,
+                                        _stream()), "cips_siren_bwd_x3")
+            R = red.view(B, chunks * 4, 868).sum(1)
+            Gp = gpart.view(B, chunks, gw).sum(1)
+            G1 = Gp[:, :16384].view(B, 128, 128)                    # da2^T @ h1
+            Gc = Gp[:, 16384:24576].view(B, 64, 128)                # dac^T @ h2
+            dwf = (Gp[:, 24576:26624] + Gp[:, 26624:28672]).sum(0).view(32, 64)   # dfeat^T @ hc
+        else:
+            BP = B * P
+            h1, h2, da2 = (Planes.empty(BP, 128, device=dev) for _ in range(3))
+            hc, dac = (Planes.empty(BP, 64, device=dev) for _ in range(2))
+            rows = lib.cips_siren_bwd_rows(B, P)
+            red = torch.empty(rows, 868, device=dev)
+            check(lib.cips_siren_bwd_data(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(h1.hi), _p(h1.lo),
+                                          _p(h2.hi), _p(h2.lo), _p(hc.hi), _p(hc.lo), _p(da2.hi), _p(da2.lo),
+                                          _p(dac.hi), _p(dac.lo), _p(red), B, P, _stream()), "cips_siren_bwd_data")
+            R = red.view(B, rows // B, 868).sum(1)          # (B, 868) deterministic reduction of partial rows
+            # weight-gradient contractions over the points (K = P per image, split-K) on the bf16x3 K-major GEMM
+            sp = _split_k(P, 16)
+            Kc = P // sp
+            G1 = torch.empty(B * sp, 128, 128, device=dev)   # da2^T @ h1
+            gemm_x3_km(da2, h1, 128, 128, Kc, 128, 128, B * sp, Kc * 128, Kc * 128, G1)
+            G1 = G1.view(B, sp, 128, 128).sum(1)
+            Gc = torch.empty(B * sp, 64, 128, device=dev)    # dac^T @ h2
+            gemm_x3_km(dac, h2, 64, 128, Kc, 64, 128, B * sp, Kc * 64, Kc * 128, Gc)
+            Gc = Gc.view(B, sp, 64, 128).sum(1)
+            hcf = hc.float()                                 # the 32x64 colour-linear gradient stays on the fp32 GEMM
+            spf = _split_k(BP, 1024)
+            Kf = BP // spf
+            Gf = torch.empty(spf, 32, 64, device=dev)        # dfeat^T @ hc (no per-image scale)
+            gemm(dfeat, hcf, Gf, 32, 64, Kf, 32, 64, 64, batch=spf, strideA=Kf * 32, strideB=Kf * 64,
+                 strideC=32 * 64, a_kmajor=True)
+            dwf = Gf.sum(0)
         # ---- assemble parameter / FiLM gradients (tiny tensors) ----
         g0, g1, gc = t["g0"], t["g1"], t["gc"]
         w0, b0, w1, b1, wc, bc = t["w0"], t["b0"], t["w1"], t["b1"], t["wc"], t["bc"]

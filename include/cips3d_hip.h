@@ -96,6 +96,20 @@ int cips_siren_bwd_data(const cips_siren_weights* w, const float* points,
                         void* da2_hi, void* da2_lo, void* dac_hi, void* dac_lo,
                         float* red, int B, int P, cips_stream_t stream);
 
+/* Backward, fused bf16x3 form (default): forward recompute, data gradients and all three weight-gradient
+ * contractions in one kernel on v_mfma_f32_32x32x16_bf16 with 3-pass split operands (fp32 accumulate);
+ * no activation staging in HBM.  chunks = cips_siren_bwd_x3_chunks(B,P) workgroups per image.
+ *   red   (B*chunks*4, 868)  per-wave reduction rows, same column layout as cips_siren_bwd_data
+ *   gpart (B*chunks, cips_siren_bwd_x3_gpart()) per-workgroup partial weight gradients, floats:
+ *         [0,16384)  da2^T h1 (128,128) | [16384,24576) dac^T h2 (64,128)
+ *         | [24576,26624) and [26624,28672) two partial dfeat^T hc (32,64)
+ * Rows / partials of image b are [b*chunks*4, (b+1)*chunks*4) and [b*chunks, (b+1)*chunks).
+ */
+int cips_siren_bwd_x3_chunks(int B, int P);
+int cips_siren_bwd_x3_gpart(void);
+int cips_siren_bwd_x3(const cips_siren_weights* w, const float* points, const float* dfeat,
+                      const float* dsigma, float* red, float* gpart, int B, int P, cips_stream_t stream);
+
 /* ------------------------------------------------------------------ */
 /* H3  hierarchical resampling + merge + alpha-composite               */
 /* ------------------------------------------------------------------ */

@@ -1,0 +1,33 @@
+"""SIREN forward + backward microbench at the headline shape (b=32, P=64*64*24 points): HIP-event timings."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cips3d_amd import ops
+
+def main():
+    b = int(os.environ.get("B", 32)); P = int(os.environ.get("P", 64 * 64 * 24)); reps = int(os.environ.get("REPS", 5))
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    def r(*s, scale=1.0): return (torch.randn(*s, generator=g) * scale).to(d).requires_grad_(True)
+    pts = ((torch.rand(b, P, 3, generator=g) - 0.5) * 0.24).to(d)
+    g0, g1, gc = [(30 + 5 * torch.randn(b, n, generator=g)).to(d).requires_grad_(True) for n in (128, 128, 64)]
+    p0, p1, pc = r(b, 128), r(b, 128), r(b, 64)
+    w0 = r(128, 3, scale=0.3); b0 = r(128, scale=0.1); w1 = r(128, 128, scale=0.01); b1 = r(128, scale=0.1)
+    ws = r(1, 128, scale=0.01); bs = r(1, scale=0.1); wc = r(64, 128, scale=0.01)
+    bc = r(64, scale=0.1); wf = r(32, 64, scale=0.05); bf = r(32, scale=0.1)
+    ops.TRIG_MODE = 1
+    args = (pts, g0, p0, g1, p1, gc, pc, w0, b0, w1, b1, ws, bs, wc, bc, wf, bf)
+    df = torch.randn(b, P, 32, device=d); ds = torch.randn(b, P, device=d)
+    def step():
+        feat, sig = ops.SirenFunction.apply(*args)
+        torch.autograd.backward([feat, sig], [df, ds])
+    for _ in range(2): step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): step()
+    e1.record(); torch.cuda.synchronize()
+    print(f"siren fwd+bwd b={b} P={P} mode={ops.SIREN_BWD_MODE}: {e0.elapsed_time(e1) / reps:.3f} ms/iter")
+
+if __name__ == "__main__":
+    main()

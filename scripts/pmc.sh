@@ -1,12 +1,12 @@
 #!/bin/bash
-# PMC pass over the GEMM microbench (counters in their own run, kernel-trace only).
+# PMC pass over a microbench (counters in their own run, kernel-trace only).  usage: pmc.sh TAG counters...; BENCH=script.py
 cd "$(dirname "$0")/.." || exit 1
 TAG=${1:-pmc}; shift
 COUNTERS="$@"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 REPO=$PWD
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $COUNTERS --output-format csv -d $REPO/gpurun_out/pmc_$TAG -o p -- python $REPO/scripts/bench_gemm.py > $REPO/gpurun_out/pmc_$TAG.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $COUNTERS --output-format csv -d $REPO/gpurun_out/pmc_$TAG -o p -- python $REPO/scripts/${BENCH:-bench_gemm.py} > $REPO/gpurun_out/pmc_$TAG.log 2>&1)
 f=$(find gpurun_out/pmc_$TAG -name "*counter_collection.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, collections

@@ -106,10 +106,12 @@ def test_siren_forward(trig, b, P):
     assert e_f < TOL and e_s < TOL
 
 
-@pytest.mark.parametrize("trig", [0, 1])
-def test_siren_backward(trig):
+@pytest.mark.parametrize("trig,mode,b,P", [(0, "x3", 2, 2048 + 96), (1, "x3", 2, 2048 + 96), (1, "x3", 3, 128 * 7 + 5),
+                                             (1, "x3", 1, 4096 * 3), (0, "staged", 2, 2048 + 96), (1, "staged", 2, 2048 + 96)])
+def test_siren_backward(trig, mode, b, P, monkeypatch):
+    """fused bf16x3 backward ("x3", default) and the staged data-pass + GEMM form, vs the fp32 CPU oracle's autograd"""
     from cips3d_amd import ops
-    b, P = 2, 2048 + 96
+    monkeypatch.setattr(ops, "SIREN_BWD_MODE", mode)
     G, pts, style = _siren_inputs(4, b, P)
     g = torch.Generator().manual_seed(9)
     up = torch.randn(b, P, 33, generator=g)
@@ -133,7 +135,7 @@ def test_siren_backward(trig):
     for n, p in Gd.siren.named_parameters():
         e = rel_err(p.grad, ref[n])
         worst = max(worst, e)
-        print(f"  siren bwd trig={trig} {n}: rel {e:.3e}")
+        print(f"  siren bwd trig={trig} {mode} {n}: rel {e:.3e}")
         assert e < TOL, n
     e = rel_err(st.grad, ref_style)
     print(f"  siren bwd trig={trig} style: rel {e:.3e}")
