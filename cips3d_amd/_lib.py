@@ -58,6 +58,8 @@ SIGNATURES = {
     "cips_siren_bwd_rows": (i32, [i32, i32]),
     "cips_siren_bwd_x3_chunks": (i32, [i32, i32]),
     "cips_siren_bwd_x3_gpart": (i32, []),
+    "cips_siren_bwd_x3_sred": (i32, []),
+    "cips_siren_bwd_x3_prof": (i32, [vp]),
     "cips_siren_bwd_x3": (i32, [C.POINTER(SirenWeights), vp, vp, vp, vp, vp, i32, i32, vp]),
     "cips_siren_bwd_data": (i32, [C.POINTER(SirenWeights)] + [vp] * 14 + [i32, i32, vp]),
     "cips_resample_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -22,13 +22,19 @@
 //     fixed set of output tiles (112 accumulator registers) for the whole chunk.  Nothing but the final
 //     per-workgroup partial dW (112 KiB) goes to HBM.
 //
-// LDS (156.5 KiB of 160): W1, Wc, Wf as bf16 hi/lo images (104 KiB), the per-image FiLM vectors (4.5 KiB),
-// a 48 KiB staging buffer.  One image serves both orientations: forward fragments are two ds_read_b64 per
+//   * the per-feature sums over points (FiLM phase/bias gradients, layer-0 weight gradient, sigma-head
+//     weight gradient) ride on the same staged operands as one extra 32x32 accumulator tile per wave against
+//     an 8-column "aux" operand [1, x, y, z, 1, dsigma, 1, 1] per point, each contraction masked to its own
+//     columns — no cross-lane shuffles anywhere in the loop.
+//
+// LDS (all 160 KiB): W1, Wc, Wf as bf16 hi/lo images (104 KiB), the per-image FiLM vectors (4 KiB), the aux
+// image (4 KiB), a 48 KiB staging buffer.  One image serves both orientations: forward fragments are two ds_read_b64 per
 // plane, transposed fragments (dh = W^T d) two ds_read_b64_tr_b16.  Every image (weights and staging) is
 // XOR-swizzled at 8-byte granularity by a bijection of the row index chosen so that (a) 32 lanes touching
 // 32 consecutive rows at one column and (b) the transpose read's 4 rows x 64 B both cover all 64 banks.
 #include "common.h"
 #include "../../include/cips3d_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -40,7 +46,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned char uchar;
 
 constexpr int H = 128, HC = 64, CF = 32;
-constexpr int RED_W = 868;
 
 // ---- LDS carve (bytes) ----
 constexpr int O_W1H = 0, O_W1L = 32768;                 // [128 out][128 in] bf16, 256 B rows
@@ -49,10 +54,11 @@ constexpr int O_WFH = 98304, O_WFL = 102400;            // [32 out][64 in], 128 
 constexpr int O_L0 = 106496;                            // float4[128]
 constexpr int O_G1 = O_L0 + 2048, O_C1 = O_G1 + 512, O_WS = O_C1 + 512;
 constexpr int O_GC = O_WS + 512, O_CC = O_GC + 256;
-constexpr int O_STG = 111616;                           // 48 KiB staging, 1 KiB aligned
+constexpr int O_AUX = O_CC + 256;                        // [128 points][8 bf16] hi plane, then lo plane (2 KiB each)
+constexpr int O_STG = O_AUX + 4096;                      // 48 KiB staging
 constexpr int STG_BYTES = 49152;
-constexpr int SMEM_BYTES = O_STG + STG_BYTES;           // 160768
-static_assert(O_CC + 256 <= O_STG, "LDS carve overlap");
+constexpr int SMEM_BYTES = O_STG + STG_BYTES;            // 163840 = the whole LDS of a CU
+static_assert(O_AUX == 110592 && SMEM_BYTES == 163840, "LDS carve");
 
 // A wave's activations in "register-chain" layout (lane = point; tile q, register r <-> feature
 // 32q + (r&3) + 8(r>>2) + 4hf), packed to split bf16: dword j of tile q holds registers 2j, 2j+1, so dwords
@@ -77,6 +83,15 @@ __device__ __forceinline__ void pack32(const float (&v)[32], Act<Q>& o, int q0) 
 #pragma unroll
     for (int j = 0; j < 8; ++j) split2(v[16 * qq + 2 * j], v[16 * qq + 2 * j + 1], o.hi[q0 + qq][j], o.lo[q0 + qq][j]);
 }
+// Pin packed values where they are computed: hipcc otherwise sinks the whole producing computation into the
+// `if (wave == turn)` staging blocks, serialising it across the workgroup's waves.
+template <int Q>
+__device__ __forceinline__ void pin(Act<Q>& o) {
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { asm volatile("" : "+v"(o.hi[q][j])); asm volatile("" : "+v"(o.lo[q][j])); }
+}
 __device__ __forceinline__ bf16x8 mk8(unsigned a, unsigned b, unsigned c, unsigned d) {
   u32x4 v = {a, b, c, d};
   return __builtin_bit_cast(bf16x8, v);
@@ -88,30 +103,36 @@ __device__ __forceinline__ f32x16 x3(f32x16 acc, bf16x8 ah, bf16x8 al, bf16x8 bh
   return acc;
 }
 
-// Long-lived per-point values are parked in accumulation registers by hand: the data path needs ~250 arch
-// VGPRs at its widest, hipcc will not move plain floats to AGPRs before it starts spilling to scratch, and a
-// scratch reload on a one-wave-per-SIMD kernel is a fully exposed ~1 us stall.
-#ifndef CIPS_PARK_AGPR
-__device__ __forceinline__ float park(float v) { return v; }
-__device__ __forceinline__ float unpark(float a) { return a; }
-#else
-__device__ __forceinline__ float park(float v) { float a; asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
-__device__ __forceinline__ float unpark(float a) { float v; asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
-#endif
-
-// 8-byte-unit XOR swizzle of an image whose rows hold 2^N units (N = 5: 128 features, 4: 64, 3: 32)
-template <int N> __device__ __forceinline__ int swz(int r);
-template <> __device__ __forceinline__ int swz<5>(int r) { return ((r & 3) << 3) | ((r >> 2) & 7); }
-template <> __device__ __forceinline__ int swz<4>(int r) { return (((r >> 1) & 1) << 3) | ((r >> 2) & 7); }
-template <> __device__ __forceinline__ int swz<3>(int r) { return (r >> 2) & 7; }
-template <int N> __device__ __forceinline__ int img_off(int row, int unit) {
-  return row * (8 << N) + ((unit ^ swz<N>(row)) << 3);
+// LDS image layout (weights and staging alike): [column/32][row][32 columns] — 64-byte rows of 8 units
+// (unit = 4 bf16 = 8 B), column blocks R*64 bytes apart, the unit index XORed with 3 bits of the row:
+//   weights  (SH = 2): unit ^ ((row >> 2) & 7)     staging (SH = 1): unit ^ ((row >> 1) & 7)
+// Probed on hardware (scripts/probe/lds_layout_probe.hip, SQ_LDS_BANK_CONFLICT = 0 for all three patterns):
+//  * ds_read_b64_tr_b16 — a 32-lane group covers 4 rows x 64 B = one 256-B bank row whatever the in-row order;
+//  * forward fragments, ds_read_b64 — 32 consecutive rows at one unit: (row & 3) picks the 64-B quarter,
+//    (row >> 2) & 7 the unit inside it;
+//  * staging stores, ds_write_b64 (16-lane groups, 128-B bank row) — (row & 1) picks the half, (row >> 1) & 7
+//    the unit.
+// and every fragment address is  lane base + compile-time immediate  (LaneAddr below).
+template <int SH> __device__ __forceinline__ int img_addr(int row, int unit, int R) {
+  return (unit >> 3) * R * 64 + row * 64 + (((unit & 7) ^ ((row >> SH) & 7)) << 3);
 }
 
-__device__ __forceinline__ uint2 lds_tr(const uchar* p) {
-  short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+// All LDS traffic goes through 32-bit LDS byte addresses (lane base + compile-time constant), so that the
+// constant lands in the instruction's 16-bit offset field; arithmetic on generic pointers does not fold.
+#define LDS_PTR(T, a) ((__attribute__((address_space(3))) T*)(uintptr_t)(a))
+__device__ __forceinline__ uint2 lds_tr(unsigned a) {
+  short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, a));
   return __builtin_bit_cast(uint2, v);
 }
+// plain 8-byte LDS read that the load/store optimizer must not fuse into ds_read2st64_b64 (half the
+// bandwidth and 2-way conflicts on this layout)
+__device__ __forceinline__ uint2 lds_b64(unsigned a) {
+  const unsigned long long v = *LDS_PTR(const volatile unsigned long long, a);
+  return make_uint2((unsigned)v, (unsigned)(v >> 32));
+}
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_st64(unsigned a, unsigned x, unsigned y) { u32x2 v = {x, y}; *LDS_PTR(u32x2, a) = v; }
+__device__ __forceinline__ float4 lds_ld4(unsigned a) { const f32x4 v = *LDS_PTR(const f32x4, a); return make_float4(v[0], v[1], v[2], v[3]); }
 
 __device__ __forceinline__ constexpr int featidx(int q, int r, int hf) { return q * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf; }
 
@@ -149,62 +170,95 @@ __device__ __forceinline__ void run_layer(LoadF load, const Act<(KS + 1) / 2>& i
   }
 }
 
-// Forward-orientation dense layer: acc[m] += W[32m + i][k] * in[k][pt], W image rows = out features.
-// wl = image base + (lane&31)*256 (hi plane), gx = (swz5(lane&31) ^ hf) << 3.
-template <int NM, int Q, int PLANE>
-__device__ __forceinline__ void layer_fwd(const uchar* wl, int gx, const Act<Q>& in, f32x16 (&acc)[NM]) {
-  auto load = [&](int s, int m, Frag& f) {
-    const int o0 = ((4 * s) << 3) ^ gx, o1 = o0 ^ 16;     // k-step s = 2q+t: units 8q+4t+hf and +2
-    const uchar* p = wl + m * 32 * 256;
-    put(f.h, 0, *reinterpret_cast<const uint2*>(p + o0));
-    put(f.h, 2, *reinterpret_cast<const uint2*>(p + o1));
-    put(f.l, 0, *reinterpret_cast<const uint2*>(p + PLANE + o0));
-    put(f.l, 2, *reinterpret_cast<const uint2*>(p + PLANE + o1));
+// The DS offset field is 16 bits and the carve is 160 KiB: a region base (lane base + image offset) is made
+// opaque with this so that hipcc keeps it in one register and folds only the in-region constant.
+__device__ __forceinline__ unsigned opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+
+// Per-lane LDS address bases (bytes, including the kernel's LDS base), recomputed every round from the
+// laundered lane id.
+struct LaneAddr {
+  unsigned fb[2][2];   // forward fragments: [k-step parity t][second half]
+  unsigned tb[2][2];   // transposed fragments, register-chain k order: [k-step parity][second half]
+  unsigned sb[2];      // staging fragments, natural k order: [second half]; includes O_STG
+  unsigned ab;         // aux fragments; includes O_AUX
+  unsigned v16, v64;   // per-feature vectors, relative to O_L0: + 16*hf (float4 of 4 features), + 64*hf (4 float4 L0 packs)
+};
+__device__ __forceinline__ LaneAddr lane_addr(int lane, unsigned sbase) {
+  const int l31 = lane & 31, hf = lane >> 5, s16 = lane & 15, mhalf = (lane >> 4) & 1;
+  const int ul = 4 * mhalf + (s16 & 3);
+  LaneAddr A;
+  const int e = hf ^ ((l31 >> 2) & 7);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int sec = 0; sec < 2; ++sec) {
+      A.fb[t][sec] = sbase + l31 * 64 + ((e ^ (4 * t) ^ (2 * sec)) << 3);
+      A.tb[t][sec] = sbase + (4 * hf + (s16 >> 2)) * 64 + (((ul ^ hf) ^ (4 * t) ^ (2 * sec)) << 3);
+    }
+  const int gs = 4 * hf + (s16 >> 3);
+  A.sb[0] = opaque(sbase + O_STG + (8 * hf + (s16 >> 2)) * 64 + ((ul ^ gs) << 3));
+  A.sb[1] = opaque(sbase + O_STG + (8 * hf + (s16 >> 2)) * 64 + ((ul ^ gs ^ 2) << 3));
+  A.ab = opaque(sbase + O_AUX + (8 * hf + (s16 >> 2)) * 16 + (s16 & 1) * 8);
+  A.v16 = opaque(sbase + O_L0 + 16 * hf);
+  A.v64 = opaque(sbase + O_L0 + 64 * hf);
+  return A;
+}
+
+// Forward-orientation dense layer: acc[m] += W[32m + i][k] * in[k][pt]; W image (R rows = out features) at
+// LDS offset IMG, lo plane PLANE bytes after the hi plane.
+template <int NM, int Q, int R, int IMG, int PLANE>
+__device__ __forceinline__ void layer_fwd(const LaneAddr& A, const Act<Q>& in, f32x16 (&acc)[NM]) {
+  const unsigned b[2][2] = {{opaque(A.fb[0][0] + IMG), opaque(A.fb[0][1] + IMG)}, {opaque(A.fb[1][0] + IMG), opaque(A.fb[1][1] + IMG)}};
+  auto load = [&](int s, int m, Frag& f) {            // k-step s = 2q+t: units 8q+4t+hf and +2 of row 32m + lane
+    const int c = (s >> 1) * R * 64 + m * 2048;
+    put(f.h, 0, lds_b64(b[s & 1][0] + c));
+    put(f.h, 2, lds_b64(b[s & 1][1] + c));
+    put(f.l, 0, lds_b64(b[s & 1][0] + c + PLANE));
+    put(f.l, 2, lds_b64(b[s & 1][1] + c + PLANE));
   };
   run_layer<NM, 2 * Q>(load, in, acc);
 }
 
 // Transposed dense layer: acc[m] += W[k][32m + i] * in[k][pt]  (dh = W^T d), same image, transpose reads.
-// N = log2(units per image row), KS = k-steps (16 rows each).  The B operand's k order is the register
-// chain's: k-step ks, element e of half hf <-> row 16ks + 4hf + (e&3) + 8(e>>2).
-template <int N, int NM, int KS, int PLANE>
-__device__ __forceinline__ void layer_tr(const uchar* img, int lane, const Act<(KS + 1) / 2>& in, f32x16 (&acc)[NM]) {
-  const int hf = lane >> 5, s16 = lane & 15, mhalf = (lane >> 4) & 1;
-  const int rl = 4 * hf + (s16 >> 2), ul = 4 * mhalf + (s16 & 3);
+// KS = k-steps (16 rows each).  The B operand's k order is the register chain's: k-step ks, element e of half
+// hf <-> row 16ks + 4hf + (e&3) + 8(e>>2).
+template <int NM, int KS, int R, int IMG, int PLANE>
+__device__ __forceinline__ void layer_tr(const LaneAddr& A, const Act<(KS + 1) / 2>& in, f32x16 (&acc)[NM]) {
+  const unsigned b[2][2] = {{opaque(A.tb[0][0] + IMG), opaque(A.tb[0][1] + IMG)}, {opaque(A.tb[1][0] + IMG), opaque(A.tb[1][1] + IMG)}};
   auto load = [&](int ks, int m, Frag& f) {
-    const int r0 = 16 * ks + rl, r1 = r0 + 8;
-    const int o0 = img_off<N>(r0, 8 * m + ul), o1 = img_off<N>(r1, 8 * m + ul);
-    put(f.h, 0, lds_tr(img + o0));
-    put(f.h, 2, lds_tr(img + o1));
-    put(f.l, 0, lds_tr(img + PLANE + o0));
-    put(f.l, 2, lds_tr(img + PLANE + o1));
+    const int c = m * R * 64 + ks * 1024;
+    put(f.h, 0, lds_tr(b[ks & 1][0] + c));
+    put(f.h, 2, lds_tr(b[ks & 1][1] + c + 512));
+    put(f.l, 0, lds_tr(b[ks & 1][0] + c + PLANE));
+    put(f.l, 2, lds_tr(b[ks & 1][1] + c + 512 + PLANE));
   };
   run_layer<NM, KS>(load, in, acc);
 }
 
-// write a wave's packed activations (layout: lane = point, units of 4 features) into a staging image row
-template <int N, int Q>
-__device__ __forceinline__ void stage(uchar* img_hi, uchar* img_lo, int row, int hf, const Act<Q>& v) {
-  const int rb = row * (8 << N), g = swz<N>(row);
+// write a wave's packed activations (lane = point `row` of an R-row staging image, units of 4 features);
+// HI / LO: offsets of the two planes inside the staging buffer
+template <int Q, int R, int HI, int LO>
+__device__ __forceinline__ void stage(unsigned sbase, int row, int hf, const Act<Q>& v) {
+  const unsigned rb = opaque(sbase + O_STG + row * 64);
+  const int g = (row >> 1) & 7;
 #pragma unroll
-  for (int q = 0; q < Q; ++q)
+  for (int gg = 0; gg < 4; ++gg) {
+    const unsigned o = rb + (((2 * gg + hf) ^ g) << 3);
 #pragma unroll
-    for (int gg = 0; gg < 4; ++gg) {
-      const int o = rb + (((8 * q + 2 * gg + hf) ^ g) << 3);
-      *reinterpret_cast<uint2*>(img_hi + o) = make_uint2(v.hi[q][2 * gg], v.hi[q][2 * gg + 1]);
-      *reinterpret_cast<uint2*>(img_lo + o) = make_uint2(v.lo[q][2 * gg], v.lo[q][2 * gg + 1]);
+    for (int q = 0; q < Q; ++q) {
+      lds_st64(o + HI + q * R * 64, v.hi[q][2 * gg], v.hi[q][2 * gg + 1]);
+      lds_st64(o + LO + q * R * 64, v.lo[q][2 * gg], v.lo[q][2 * gg + 1]);
     }
+  }
 }
 
-// k-major fragment of a staging image: lane i = feature col0 + (lane&31), k = points 16ks + 8hf + {0..7}
-template <int N>
-__device__ __forceinline__ void stg_frag(const uchar* img_hi, const uchar* img_lo, int lane, int col0, int ks, Frag& f) {
-  const int hf = lane >> 5, s16 = lane & 15, mhalf = (lane >> 4) & 1;
-  const int r0 = 16 * ks + 8 * hf + (s16 >> 2), r1 = r0 + 4;
-  const int u = (col0 >> 2) + 4 * mhalf + (s16 & 3);
-  const int o0 = img_off<N>(r0, u), o1 = img_off<N>(r1, u);
-  put(f.h, 0, lds_tr(img_hi + o0)); put(f.h, 2, lds_tr(img_hi + o1));
-  put(f.l, 0, lds_tr(img_lo + o0)); put(f.l, 2, lds_tr(img_lo + o1));
+// k-major fragment of an R-row staging image (planes at offsets HI / LO of the staging buffer; sb0 / sb1 include O_STG): lane i = feature col0 + (lane&31),
+// k = points 16ks + 8hf + {0..7}
+template <int R, int HI, int LO>
+__device__ __forceinline__ void stg_frag(unsigned sb0, unsigned sb1, int col0, int ks, Frag& f) {
+  const int c = (col0 >> 5) * R * 64 + ks * 1024;
+  put(f.h, 0, lds_tr(sb0 + HI + c)); put(f.h, 2, lds_tr(sb1 + HI + c + 256));
+  put(f.l, 0, lds_tr(sb0 + LO + c)); put(f.l, 2, lds_tr(sb1 + LO + c + 256));
 }
 __device__ __forceinline__ f32x16 x3f(f32x16 acc, const Frag& a, const Frag& b) {
   return x3(acc, mk8(a.h[0], a.h[1], a.h[2], a.h[3]), mk8(a.l[0], a.l[1], a.l[2], a.l[3]),
@@ -226,33 +280,37 @@ __device__ __forceinline__ void bsincos(float x, float* s, float* c) {
   }
 }
 
-// Transpose-reduce 32 registers across the 32 lanes of each wave half (see siren.hip).
-__device__ __forceinline__ float reduce32(float (&v)[32], int lane) {
+// B fragment of the aux image [point][8 columns] (16 B rows per plane, no swizzle): lane j supplies column
+// j & 7 of points 16ks + 8hf + {0..7}; masked to the columns one contraction owns.
+__device__ __forceinline__ void aux_frag(unsigned ab, int ks, unsigned mask, Frag& f) {
+  const int c = ks * 256;
+  put(f.h, 0, lds_tr(ab + c)); put(f.h, 2, lds_tr(ab + c + 64));
+  put(f.l, 0, lds_tr(ab + c + 2048)); put(f.l, 2, lds_tr(ab + c + 2048 + 64));
 #pragma unroll
-  for (int off = 16, n = 32; off >= 1; off >>= 1, n >>= 1) {
-    const bool up = (lane & off) != 0;
-#pragma unroll
-    for (int i = 0; i < n / 2; ++i) {
-      float lo = v[i], hi = v[i + n / 2];
-      float send = up ? lo : hi;
-      float keep = up ? hi : lo;
-      v[i] = keep + __shfl_xor(send, off);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  return v[0];
+  for (int i = 0; i < 4; ++i) { f.h[i] &= mask; f.l[i] &= mask; }
 }
+// A x B with an exact-in-bf16 B (lo plane zero, e.g. a column of ones): two passes suffice
+__device__ __forceinline__ f32x16 x2f(f32x16 acc, const Frag& a, const Frag& b) {
+  const bf16x8 bh = mk8(b.h[0], b.h[1], b.h[2], b.h[3]);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk8(a.l[0], a.l[1], a.l[2], a.l[3]), bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk8(a.h[0], a.h[1], a.h[2], a.h[3]), bh, acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 struct BwdX3Args {
   cips_siren_weights w;
   const float* points;
   const float* dfeat;
   const float* dsigma;
-  float* red;     // [B*chunks*4][868]
+  float* sred;    // [B*chunks][SRED]
   float* gpart;   // [B*chunks][GPART]
   int B, P, chunk, chunks;
+  unsigned long long* prof;
+  int dbg;        // timing attribution only (env CIPS_X3_DBG): bit0/1/2 skip the dWf / dWc / dW1 phases
 };
 constexpr int GP_G1 = 0, GP_GC = H * H, GP_GF0 = GP_GC + HC * H, GP_GF1 = GP_GF0 + CF * HC, GPART = GP_GF1 + CF * HC;
+constexpr int SRED = 4 * 32 * 8 + 8;   // per wave a 32x8 tile of column sums, then 4 per-wave sums of dsigma (+ pad)
 
 __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_weights& w, int b) {
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -261,7 +319,7 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
     const float4 v = *reinterpret_cast<const float4*>(w.w1 + row * H + 4 * u);
     uint2 ph, pl;
     split2(v.x, v.y, ph.x, pl.x); split2(v.z, v.w, ph.y, pl.y);
-    const int o = img_off<5>(row, u);
+    const int o = img_addr<2>(row, u, H);
     *reinterpret_cast<uint2*>(sm + O_W1H + o) = ph;
     *reinterpret_cast<uint2*>(sm + O_W1L + o) = pl;
   }
@@ -270,7 +328,7 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
     const float4 v = *reinterpret_cast<const float4*>(w.wc + row * H + 4 * u);
     uint2 ph, pl;
     split2(v.x, v.y, ph.x, pl.x); split2(v.z, v.w, ph.y, pl.y);
-    const int o = img_off<5>(row, u);
+    const int o = img_addr<2>(row, u, HC);
     *reinterpret_cast<uint2*>(sm + O_WCH + o) = ph;
     *reinterpret_cast<uint2*>(sm + O_WCL + o) = pl;
   }
@@ -279,7 +337,7 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
     const float4 v = *reinterpret_cast<const float4*>(w.wf + row * HC + 4 * u);
     uint2 ph, pl;
     split2(v.x, v.y, ph.x, pl.x); split2(v.z, v.w, ph.y, pl.y);
-    const int o = img_off<4>(row, u);
+    const int o = img_addr<2>(row, u, CF);
     *reinterpret_cast<uint2*>(sm + O_WFH + o) = ph;
     *reinterpret_cast<uint2*>(sm + O_WFL + o) = pl;
   }
@@ -302,6 +360,14 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
   }
 }
 
+// phase timestamps for tuning (host passes a buffer only when CIPS_X3_PROF is set): workgroup (0,0), lane 0 of
+// each wave, first 8 rounds, s_memtime at each phase boundary
+#define X3_TS(i)                                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                               \
+  if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && lane0 == 0 && rnd < 8)                       \
+    a.prof[(rnd * 4 + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime();                            \
+  __builtin_amdgcn_sched_barrier(0);
+
 template <bool HW>
 __global__ __launch_bounds__(256, 1) void siren_bwd_x3_kernel(BwdX3Args a) {
   extern __shared__ __attribute__((aligned(1024))) uchar smem[];
@@ -312,285 +378,387 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_x3_kernel(BwdX3Args a) {
   const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cstart = blockIdx.x * a.chunk;
   const int cend = min(cstart + a.chunk, a.P);
-  const float4* L0 = reinterpret_cast<const float4*>(smem + O_L0);
-  const float* G1v = reinterpret_cast<const float*>(smem + O_G1);
-  const float* C1v = reinterpret_cast<const float*>(smem + O_C1);
-  const float* WSv = reinterpret_cast<const float*>(smem + O_WS);
-  const float* GCv = reinterpret_cast<const float*>(smem + O_GC);
-  const float* CCv = reinterpret_cast<const float*>(smem + O_CC);
-  uchar* stg = smem + O_STG;
+  const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uchar*)smem);
 
-  // weight-gradient accumulators, owned per wave for the whole chunk
-  f32x16 aG1[4], aGc[2], aGf[1];
-  zero_acc(aG1); zero_acc(aGc); zero_acc(aGf);
-  float r_da1[2] = {0.f, 0.f}, r_x[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-  float r_da2[2] = {0.f, 0.f}, r_dac = 0.f, r_ws[2] = {0.f, 0.f}, r_df = 0.f;
+  // weight-gradient accumulators, owned per wave for the whole chunk; aS: column sums (see SRED)
+  f32x16 aG1[4], aGc[2], aGf[1], aS[1];
+  zero_acc(aG1); zero_acc(aGc); zero_acc(aGf); zero_acc(aS);
+  float r_dsg = 0.f;
 
+  // inputs of the first round
+  float px, py, pz, dsg;
+  {
+    const int p = cstart + wave * 32 + (lane0 & 31);
+    const bool valid = p < cend;
+    const long long gp = (long long)b * a.P + (valid ? p : cend - 1);
+    px = a.points[gp * 3 + 0]; py = a.points[gp * 3 + 1]; pz = a.points[gp * 3 + 2];
+    dsg = valid ? a.dsigma[gp] : 0.f;
+  }
+
+  int rnd = -1;
   for (int pbase = cstart; pbase < cend; pbase += 128) {
+    ++rnd;
+    X3_TS(0)
     // every LDS address below is loop-invariant; laundering the lane id keeps hipcc from hoisting a few hundred
     // of them out of the loop into live registers
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int l31 = lane & 31, hf = lane >> 5;
-    const int gx = (swz<5>(l31) ^ hf) << 3;
-    const uchar* W1l = smem + O_W1H + l31 * 256;
-    const uchar* Wcl = smem + O_WCH + l31 * 256;
-    const int p = pbase + wave * 32 + l31;
-    const bool valid = p < cend;
-    const long long gp = (long long)b * a.P + (valid ? p : cend - 1);
-    const float px = a.points[gp * 3 + 0], py = a.points[gp * 3 + 1], pz = a.points[gp * 3 + 2];
-    const float dsg = valid ? a.dsigma[gp] : 0.f;
+    const LaneAddr LA = lane_addr(lane, sbase);
     const int prow = wave * 32 + l31;
+    const unsigned c7 = l31 & 7;
+    const unsigned m_d1 = c7 < 4 ? ~0u : 0u, m_d2 = c7 == 4 ? ~0u : 0u, m_h2 = c7 == 5 ? ~0u : 0u;
+    const unsigned m_dc = c7 == 6 ? ~0u : 0u, m_df = c7 == 7 ? ~0u : 0u;
+
+    // ---- upstream gradient of the 32 colour features: requested now, consumed after two layers ----
+    float4 df4[4];
+    {
+      const int p = pbase + prow;
+      const bool valid = p < cend;
+      const float* dp = a.dfeat + ((long long)b * a.P + (valid ? p : cend - 1)) * CF + 4 * hf;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) df4[g] = valid ? ld4(dp + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- aux row of this point: [1, x, y, z, 1, dsigma, 1, 1] ----
+    if (hf == 0) {
+      uint4 ah, al;
+      split2(1.f, px, ah.x, al.x); split2(py, pz, ah.y, al.y); split2(1.f, dsg, ah.z, al.z); split2(1.f, 1.f, ah.w, al.w);
+      const u32x4 vh = {ah.x, ah.y, ah.z, ah.w}, vl = {al.x, al.y, al.z, al.w};
+      *LDS_PTR(u32x4, sbase + O_AUX + prow * 16) = vh;
+      *LDS_PTR(u32x4, sbase + O_AUX + 2048 + prow * 16) = vl;
+      r_dsg += dsg;
+    }
 
     // ---- layer 0 (VALU); only the packed sines are kept, and only until layer 1 has consumed them ----
     f32x16 acc[4];
     zero_acc(acc);
     {
       Act<4> h1p;
+      float4 pn[4];
 #pragma unroll
-      for (int gI = 0; gI < 2; ++gI) {
-        float hv[32];
+      for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 16 * e);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-          const float4 pk = L0[featidx(2 * gI + (i >> 4), i & 15, 0) + 4 * hf];
-          float cs;
-          bsincos<HW>(fmaf(pk.x, px, fmaf(pk.y, py, fmaf(pk.z, pz, pk.w))), &hv[i], &cs);
-          if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int grp = 0; grp < 16; ++grp) {          // grp = 4q + g: features 32q + 8g + 4hf + {0..3}
+        float4 pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = pn[e];
+        if (grp + 1 < 16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 128 * (grp + 1) + 16 * e);
         }
-        pack32(hv, h1p, 2 * gI);
+        __builtin_amdgcn_sched_barrier(0);
+        float sn[4], cs;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          bsincos<HW>(fmaf(pk[e].x, px, fmaf(pk[e].y, py, fmaf(pk[e].z, pz, pk[e].w))), &sn[e], &cs);
+        const int q = grp >> 2, g = grp & 3;
+        split2(sn[0], sn[1], h1p.hi[q][2 * g], h1p.lo[q][2 * g]);
+        split2(sn[2], sn[3], h1p.hi[q][2 * g + 1], h1p.lo[q][2 * g + 1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // ---- recompute layer 1 ----
-      layer_fwd<4, 4, O_W1L - O_W1H>(W1l, gx, h1p, acc);
+      layer_fwd<4, 4, H, O_W1H, O_W1L - O_W1H>(LA, h1p, acc);
     }
+    X3_TS(1)
     float cs2[4][16];
     Act<4> h2p;
+    {
+      float4 gn = lds_ld4(LA.v16 + (O_G1 - O_L0)), cn = lds_ld4(LA.v16 + (O_C1 - O_L0));
 #pragma unroll
-    for (int gI = 0; gI < 2; ++gI) {
-      float hv[32];
+      for (int grp = 0; grp < 16; ++grp) {
+        const float4 g4 = gn, c4 = cn;
+        if (grp + 1 < 16) { gn = lds_ld4(LA.v16 + (O_G1 - O_L0) + 32 * (grp + 1)); cn = lds_ld4(LA.v16 + (O_C1 - O_L0) + 32 * (grp + 1)); }
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = grp >> 2, g = grp & 3;
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
+        float sn[4];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const int q = 2 * gI + (i >> 4), r = i & 15, f = featidx(q, r, 0) + 4 * hf;
-        float cs;
-        bsincos<HW>(fmaf(G1v[f], acc[q][r], C1v[f]), &hv[i], &cs);
-        cs2[q][r] = park(cs);
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < 4; ++e) bsincos<HW>(fmaf(gg[e], acc[q][4 * g + e], cc[e]), &sn[e], &cs2[q][4 * g + e]);
+        split2(sn[0], sn[1], h2p.hi[q][2 * g], h2p.lo[q][2 * g]);
+        split2(sn[2], sn[3], h2p.hi[q][2 * g + 1], h2p.lo[q][2 * g + 1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      pack32(hv, h2p, 2 * gI);
-#pragma unroll
-      for (int i = 0; i < 32; ++i) hv[i] *= dsg;       // sum_p dsigma * h2  (gradient of final_layer.weight)
-      r_ws[gI] += reduce32(hv, lane);
     }
 
-    // ---- recompute colour sine layer  ----
+    X3_TS(2)
+    // ---- recompute colour sine layer ----
     f32x16 accc[2];
     zero_acc(accc);
-    layer_fwd<2, 4, O_WCL - O_WCH>(Wcl, gx, h2p, accc);
+    layer_fwd<2, 4, HC, O_WCH, O_WCL - O_WCH>(LA, h2p, accc);
     float csc[2][16];
     Act<2> hcp;
     {
-      float hv[32];
+      float4 gn = lds_ld4(LA.v16 + (O_GC - O_L0)), cn = lds_ld4(LA.v16 + (O_CC - O_L0));
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const int q = i >> 4, r = i & 15, f = featidx(q, r, 0) + 4 * hf;
-        bsincos<HW>(fmaf(GCv[f], accc[q][r], CCv[f]), &hv[i], &csc[q][r]);
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int grp = 0; grp < 8; ++grp) {
+        const float4 g4 = gn, c4 = cn;
+        if (grp + 1 < 8) { gn = lds_ld4(LA.v16 + (O_GC - O_L0) + 32 * (grp + 1)); cn = lds_ld4(LA.v16 + (O_CC - O_L0) + 32 * (grp + 1)); }
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = grp >> 2, g = grp & 3;
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
+        float sn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsincos<HW>(fmaf(gg[e], accc[q][4 * g + e], cc[e]), &sn[e], &csc[q][4 * g + e]);
+        split2(sn[0], sn[1], hcp.hi[q][2 * g], hcp.lo[q][2 * g]);
+        split2(sn[2], sn[3], hcp.hi[q][2 * g + 1], hcp.lo[q][2 * g + 1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      pack32(hv, hcp, 0);
     }
 
-    // ---- upstream gradient of the 32 colour features ----
+    X3_TS(3)
     Act<1> dfp;
-    {
-      float v[32];
-      const float* dp = a.dfeat + gp * CF + 4 * hf;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 t4 = valid ? *reinterpret_cast<const float4*>(dp + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-        v[4 * g + 0] = t4.x; v[4 * g + 1] = t4.y; v[4 * g + 2] = t4.z; v[4 * g + 3] = t4.w;
-        split2(t4.x, t4.y, dfp.hi[0][2 * g], dfp.lo[0][2 * g]);
-        split2(t4.z, t4.w, dfp.hi[0][2 * g + 1], dfp.lo[0][2 * g + 1]);
-      }
-      v[16] = (hf == 0) ? dsg : 0.f;
-#pragma unroll
-      for (int i = 17; i < 32; ++i) v[i] = 0.f;
-      r_df += reduce32(v, lane);
+    for (int g = 0; g < 4; ++g) {
+      split2(df4[g].x, df4[g].y, dfp.hi[0][2 * g], dfp.lo[0][2 * g]);
+      split2(df4[g].z, df4[g].w, dfp.hi[0][2 * g + 1], dfp.lo[0][2 * g + 1]);
     }
 
-    // ---- dWf += dfeat^T hc over the workgroup's 128 points: wave -> (hc column tile w&1, point half w>>1) ----
-    {
-      uchar* dfH = stg, *dfL = stg + 8192, *hcH = stg + 16384, *hcL = stg + 32768;
-      stage<3, 1>(dfH, dfL, prow, hf, dfp);
-      stage<4, 2>(hcH, hcL, prow, hf, hcp);
+    // ---- dWf += dfeat^T hc over the workgroup's 128 points: wave -> (hc column tile w&1, point half w>>1);
+    //      waves 0 and 2 also take sum_p dfeat (aux column 7) ----
+    if (!(a.dbg & 1)) {
+      constexpr int DFH = 0, DFL = 8192, HCH = 16384, HCL = 32768;
+      stage<1, 128, DFH, DFL>(sbase, prow, hf, dfp);
+      stage<2, 128, HCH, HCL>(sbase, prow, hf, hcp);
       __syncthreads();
       const int jt = wave & 1, kh = wave >> 1;
+      const unsigned mdf = jt == 0 ? m_df : 0u;          // waves 1 and 3 add zeros: no wave-dependent branches here
+      Frag fa[2], fb[2], fx[2];
+      // this wave's k-steps (4kh + k) and hc column block are folded into the lane bases
+      const unsigned d0 = opaque(LA.sb[0] + kh * 4096), d1 = opaque(LA.sb[1] + kh * 4096);      // dfeat: k-steps 4kh..
+      const unsigned h0 = opaque(d0 + jt * 8192), h1_ = opaque(d1 + jt * 8192);                  // hc: same k-steps, column block jt
+      const unsigned ax = opaque(LA.ab + kh * 1024);
+      stg_frag<128, DFH, DFL>(d0, d1, 0, 0, fa[0]);
+      stg_frag<128, HCH, HCL>(h0, h1_, 0, 0, fb[0]);
+      aux_frag(ax, 0, mdf, fx[0]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        Frag fa, fb;
-        stg_frag<3>(dfH, dfL, lane, 0, 4 * kh + k, fa);
-        stg_frag<4>(hcH, hcL, lane, 32 * jt, 4 * kh + k, fb);
-        aGf[0] = x3f(aGf[0], fa, fb);
+        if (k + 1 < 4) {
+          stg_frag<128, DFH, DFL>(d0, d1, 0, k + 1, fa[(k + 1) & 1]);
+          stg_frag<128, HCH, HCL>(h0, h1_, 0, k + 1, fb[(k + 1) & 1]);
+          aux_frag(ax, k + 1, mdf, fx[(k + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        aGf[0] = x3f(aGf[0], fa[k & 1], fb[k & 1]);
+        aS[0] = x2f(aS[0], fa[k & 1], fx[k & 1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
     }
 
+    X3_TS(4)
     // ---- d hc = Wf^T dfeat  (K = 32, M = 64);  dac = d hc * cos;  dpc = gc * dac ----
     zero_acc(accc);
-    layer_tr<4, 2, 2, O_WFL - O_WFH>(smem + O_WFH, lane, dfp, accc);
+    layer_tr<2, 2, CF, O_WFH, O_WFL - O_WFH>(LA, dfp, accc);
     Act<2> dacp, dpcp;
     {
-      float v[32];
+      float4 gn = lds_ld4(LA.v16 + (O_GC - O_L0));
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int grp = 0; grp < 8; ++grp) {
+        const float4 g4 = gn;
+        if (grp + 1 < 8) gn = lds_ld4(LA.v16 + (O_GC - O_L0) + 32 * (grp + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = grp >> 2, g = grp & 3;
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+        float v[4], w_[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float w_[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            v[16 * q + r] = accc[q][r] * csc[q][r];
-            w_[e] = GCv[featidx(q, r, 0) + 4 * hf] * v[16 * q + r];
-          }
-          split2(v[16 * q + 4 * g], v[16 * q + 4 * g + 1], dacp.hi[q][2 * g], dacp.lo[q][2 * g]);
-          split2(v[16 * q + 4 * g + 2], v[16 * q + 4 * g + 3], dacp.hi[q][2 * g + 1], dacp.lo[q][2 * g + 1]);
-          split2(w_[0], w_[1], dpcp.hi[q][2 * g], dpcp.lo[q][2 * g]);
-          split2(w_[2], w_[3], dpcp.hi[q][2 * g + 1], dpcp.lo[q][2 * g + 1]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      r_dac += reduce32(v, lane);
+        for (int e = 0; e < 4; ++e) { v[e] = accc[q][4 * g + e] * csc[q][4 * g + e]; w_[e] = gg[e] * v[e]; }
+        split2(v[0], v[1], dacp.hi[q][2 * g], dacp.lo[q][2 * g]);
+        split2(v[2], v[3], dacp.hi[q][2 * g + 1], dacp.lo[q][2 * g + 1]);
+        split2(w_[0], w_[1], dpcp.hi[q][2 * g], dpcp.lo[q][2 * g]);
+        split2(w_[2], w_[3], dpcp.hi[q][2 * g + 1], dpcp.lo[q][2 * g + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 
-    // ---- dWc += dac^T h2: two sub-phases of 64 points; wave -> (dac row tile w&1, h2 column tiles 2(w>>1)+{0,1}) ----
-    {
-      uchar* daH = stg, *daL = stg + 8192, *h2H = stg + 16384, *h2L = stg + 32768;
+    pin(dacp); pin(h2p);
+    X3_TS(5)
+    // ---- dWc += dac^T h2: two sub-phases of 64 points; wave -> (dac row tile w&1, h2 column tiles 2(w>>1)+{0,1});
+    //      plus sum_p dsigma*h2 (h2 row tile w, aux column 5) and, on waves 0 and 1, sum_p dac (aux column 6).
+    //      Fragment reads run half a k-step ahead of their MFMAs. ----
+    if (!(a.dbg & 2)) {
+      constexpr int DAH = 0, DAL = 8192, H2H = 16384, H2L = 32768;
       const int it = wave & 1, jt0 = 2 * (wave >> 1);
+      const unsigned mdc = wave < 2 ? m_dc : 0u;         // waves 2 and 3 add zeros: no wave-dependent branches here
+      // wave-dependent column blocks folded into the lane bases (block stride of a 64-row image: 4096 B)
+      const unsigned i0 = opaque(LA.sb[0] + it * 4096), i1 = opaque(LA.sb[1] + it * 4096);
+      const unsigned j0 = opaque(LA.sb[0] + jt0 * 4096), j1 = opaque(LA.sb[1] + jt0 * 4096);
+      const unsigned w0 = opaque(LA.sb[0] + wave * 4096), w1 = opaque(LA.sb[1] + wave * 4096);
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
         if ((wave >> 1) == sp) {
-          stage<4, 2>(daH, daL, (wave & 1) * 32 + l31, hf, dacp);
-          stage<5, 4>(h2H, h2L, (wave & 1) * 32 + l31, hf, h2p);
+          stage<2, 64, DAH, DAL>(sbase, (wave & 1) * 32 + l31, hf, dacp);
+          stage<4, 64, H2H, H2L>(sbase, (wave & 1) * 32 + l31, hf, h2p);
         }
         __syncthreads();
+        Frag fa, fb0, fb1, fh, fx, fy;
+        stg_frag<64, DAH, DAL>(i0, i1, 0, 0, fa);
+        stg_frag<64, H2H, H2L>(j0, j1, 0, 0, fb0);
+        stg_frag<64, H2H, H2L>(j0, j1, 32, 0, fb1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          Frag fa, fb0, fb1;
-          stg_frag<4>(daH, daL, lane, 32 * it, k, fa);
-          stg_frag<5>(h2H, h2L, lane, 32 * jt0, k, fb0);
-          stg_frag<5>(h2H, h2L, lane, 32 * jt0 + 32, k, fb1);
+          stg_frag<64, H2H, H2L>(w0, w1, 0, k, fh);
+          aux_frag(LA.ab, 4 * sp + k, m_h2, fx);
+          aux_frag(LA.ab, 4 * sp + k, mdc, fy);
           __builtin_amdgcn_sched_barrier(0);
           aGc[0] = x3f(aGc[0], fa, fb0);
           aGc[1] = x3f(aGc[1], fa, fb1);
+          aS[0] = x2f(aS[0], fa, fy);
+          __builtin_amdgcn_sched_barrier(0);
+          if (k + 1 < 4) {
+            stg_frag<64, DAH, DAL>(i0, i1, 0, k + 1, fa);
+            stg_frag<64, H2H, H2L>(j0, j1, 0, k + 1, fb0);
+            stg_frag<64, H2H, H2L>(j0, j1, 32, k + 1, fb1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          aS[0] = x3f(aS[0], fh, fx);
           __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
       }
     }
 
+    X3_TS(6)
     // ---- d h2 = Wc^T dpc + ws * dsigma  (K = 64, M = 128);  da2 = d h2 * cos;  dp2 = g1 * da2 ----
     zero_acc(acc);
-    layer_tr<5, 4, 4, O_WCL - O_WCH>(smem + O_WCH, lane, dpcp, acc);
+    layer_tr<4, 4, HC, O_WCH, O_WCL - O_WCH>(LA, dpcp, acc);
     Act<4> da2p;
     {
       Act<4> dp2p;
+      float4 gn = lds_ld4(LA.v16 + (O_G1 - O_L0)), wn = lds_ld4(LA.v16 + (O_WS - O_L0));
 #pragma unroll
-      for (int gI = 0; gI < 2; ++gI) {
-        float v[32];
+      for (int grp = 0; grp < 16; ++grp) {
+        const float4 g4 = gn, w4 = wn;
+        if (grp + 1 < 16) { gn = lds_ld4(LA.v16 + (O_G1 - O_L0) + 32 * (grp + 1)); wn = lds_ld4(LA.v16 + (O_WS - O_L0) + 32 * (grp + 1)); }
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = grp >> 2, g = grp & 3;
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+        float v[4], w_[4];
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int q = 2 * gI + qq;
-            float w_[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * g + e, f = featidx(q, r, 0) + 4 * hf;
-              v[16 * qq + r] = fmaf(WSv[f], dsg, acc[q][r]) * unpark(cs2[q][r]);
-              w_[e] = G1v[f] * v[16 * qq + r];
-            }
-            split2(v[16 * qq + 4 * g], v[16 * qq + 4 * g + 1], da2p.hi[q][2 * g], da2p.lo[q][2 * g]);
-            split2(v[16 * qq + 4 * g + 2], v[16 * qq + 4 * g + 3], da2p.hi[q][2 * g + 1], da2p.lo[q][2 * g + 1]);
-            split2(w_[0], w_[1], dp2p.hi[q][2 * g], dp2p.lo[q][2 * g]);
-            split2(w_[2], w_[3], dp2p.hi[q][2 * g + 1], dp2p.lo[q][2 * g + 1]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        r_da2[gI] += reduce32(v, lane);
+        for (int e = 0; e < 4; ++e) {
+          v[e] = fmaf(ww[e], dsg, acc[q][4 * g + e]) * cs2[q][4 * g + e];
+          w_[e] = gg[e] * v[e];
+        }
+        split2(v[0], v[1], da2p.hi[q][2 * g], da2p.lo[q][2 * g]);
+        split2(v[2], v[3], da2p.hi[q][2 * g + 1], da2p.lo[q][2 * g + 1]);
+        split2(w_[0], w_[1], dp2p.hi[q][2 * g], dp2p.lo[q][2 * g]);
+        split2(w_[2], w_[3], dp2p.hi[q][2 * g + 1], dp2p.lo[q][2 * g + 1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // ---- d h1 = W1^T dp2  (K = 128, M = 128) ----
       zero_acc(acc);
-      layer_tr<5, 4, 8, O_W1L - O_W1H>(smem + O_W1H, lane, dp2p, acc);
+      layer_tr<4, 8, H, O_W1H, O_W1L - O_W1H>(LA, dp2p, acc);
     }
+    X3_TS(7)
     // ---- da1 = d h1 * cos(layer-0 argument); the layer-0 sines are recomputed alongside for dW1 ----
-    Act<4> h1p;
+    Act<4> h1p, da1p;
+    {
+      float4 pn[4];
 #pragma unroll
-    for (int gI = 0; gI < 2; ++gI) {
-      float v[32], t[32];
+      for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 16 * e);
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const float4 pk = L0[featidx(2 * gI + (i >> 4), i & 15, 0) + 4 * hf];
-        float cs;
-        bsincos<HW>(fmaf(pk.x, px, fmaf(pk.y, py, fmaf(pk.z, pz, pk.w))), &t[i], &cs);
-        v[i] = acc[2 * gI + (i >> 4)][i & 15] * cs;
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int grp = 0; grp < 16; ++grp) {
+        float4 pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = pn[e];
+        if (grp + 1 < 16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 128 * (grp + 1) + 16 * e);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = grp >> 2, g = grp & 3;
+        float sn[4], v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float cs;
+          bsincos<HW>(fmaf(pk[e].x, px, fmaf(pk[e].y, py, fmaf(pk[e].z, pz, pk[e].w))), &sn[e], &cs);
+          v[e] = acc[q][4 * g + e] * cs;
+        }
+        split2(sn[0], sn[1], h1p.hi[q][2 * g], h1p.lo[q][2 * g]);
+        split2(sn[2], sn[3], h1p.hi[q][2 * g + 1], h1p.lo[q][2 * g + 1]);
+        split2(v[0], v[1], da1p.hi[q][2 * g], da1p.lo[q][2 * g]);
+        split2(v[2], v[3], da1p.hi[q][2 * g + 1], da1p.lo[q][2 * g + 1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      pack32(t, h1p, 2 * gI);
-#pragma unroll
-      for (int i = 0; i < 32; ++i) t[i] = v[i];
-      r_da1[gI] += reduce32(t, lane);
-#pragma unroll
-      for (int i = 0; i < 32; ++i) t[i] = v[i] * px;
-      r_x[0][gI] += reduce32(t, lane);
-#pragma unroll
-      for (int i = 0; i < 32; ++i) t[i] = v[i] * py;
-      r_x[1][gI] += reduce32(t, lane);
-#pragma unroll
-      for (int i = 0; i < 32; ++i) t[i] = v[i] * pz;
-      r_x[2][gI] += reduce32(t, lane);
     }
 
-    // ---- dW1 += da2^T h1: four sub-phases of 32 points; wave -> da2 row tile w, all four h1 column tiles ----
+    pin(da2p); pin(h1p); pin(da1p);
+    X3_TS(8)
+    // ---- inputs of the next round (latency hidden behind the dW1 phase) ----
     {
-      uchar* daH = stg, *daL = stg + 8192, *h1H = stg + 16384, *h1L = stg + 24576;
+      const int p = pbase + 128 + prow;
+      const bool valid = p < cend;
+      const long long gp = (long long)b * a.P + (valid ? p : cend - 1);
+      px = a.points[gp * 3 + 0]; py = a.points[gp * 3 + 1]; pz = a.points[gp * 3 + 2];
+      dsg = valid ? a.dsigma[gp] : 0.f;
+    }
+
+    // ---- dW1 += da2^T h1: four sub-phases of 32 points; wave -> da2 row tile w, all four h1 column tiles;
+    //      plus sum_p da2 (aux column 4) and sum_p da1 * [1, x, y, z] (aux columns 0..3) for row tile w ----
+    if (!(a.dbg & 4)) {
+      constexpr int DAH = 0, DAL = 8192, H1H = 16384, H1L = 24576, D1H = 32768, D1L = 40960;
+      const unsigned w0 = opaque(LA.sb[0] + wave * 2048), w1 = opaque(LA.sb[1] + wave * 2048);   // row tile w
 #pragma unroll 1
       for (int sp = 0; sp < 4; ++sp) {
+        if (sp == 1) { X3_TS(10) }
         if (wave == sp) {
-          stage<5, 4>(daH, daL, l31, hf, da2p);
-          stage<5, 4>(h1H, h1L, l31, hf, h1p);
+          stage<4, 32, DAH, DAL>(sbase, l31, hf, da2p);
+          stage<4, 32, H1H, H1L>(sbase, l31, hf, h1p);
+          stage<4, 32, D1H, D1L>(sbase, l31, hf, da1p);
         }
+        if (sp == 1) { X3_TS(11) }
         __syncthreads();
+        if (sp == 1) { X3_TS(12) }
+        const unsigned ax = opaque(LA.ab + sp * 512);      // aux k-steps 2sp + k
+        Frag fa, fb0, fb1, fb2, fb3, fd, fx, fy;
+        stg_frag<32, DAH, DAL>(w0, w1, 0, 0, fa);
+        stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 0, 0, fb0);
+        stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 32, 0, fb1);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          Frag fa;
-          stg_frag<5>(daH, daL, lane, 32 * wave, k, fa);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            Frag fb;
-            stg_frag<5>(h1H, h1L, lane, 32 * j, k, fb);
-            aG1[j] = x3f(aG1[j], fa, fb);
+          stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 64, k, fb2);
+          stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 96, k, fb3);
+          aux_frag(ax, k, m_d2, fx);
+          __builtin_amdgcn_sched_barrier(0);
+          aG1[0] = x3f(aG1[0], fa, fb0);
+          aG1[1] = x3f(aG1[1], fa, fb1);
+          __builtin_amdgcn_sched_barrier(0);
+          stg_frag<32, D1H, D1L>(w0, w1, 0, k, fd);
+          aux_frag(ax, k, m_d1, fy);
+          __builtin_amdgcn_sched_barrier(0);
+          aG1[2] = x3f(aG1[2], fa, fb2);
+          aG1[3] = x3f(aG1[3], fa, fb3);
+          aS[0] = x2f(aS[0], fa, fx);
+          __builtin_amdgcn_sched_barrier(0);
+          if (k + 1 < 2) {
+            stg_frag<32, DAH, DAL>(w0, w1, 0, k + 1, fa);
+            stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 0, k + 1, fb0);
+            stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 32, k + 1, fb1);
           }
           __builtin_amdgcn_sched_barrier(0);
+          aS[0] = x3f(aS[0], fd, fy);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if (sp == 1) { X3_TS(13) }
         __syncthreads();
+        if (sp == 1) { X3_TS(14) }
       }
     }
+    X3_TS(9)
   }
 
-  // ---- write this wave's partial reductions (same row format as the fp32 data pass) ----
   const int lane = lane0, l31 = lane & 31, hf = lane >> 5;
+  // ---- per-wave column sums and sum of dsigma ----
   {
-    float* row = a.red + ((long long)(b * a.chunks + blockIdx.x) * 4 + wave) * RED_W;
+    float* sr = a.sred + (long long)(b * a.chunks + blockIdx.x) * SRED;
+    if (l31 < 8) {
 #pragma unroll
-    for (int gI = 0; gI < 2; ++gI) {
-      const int f = featidx(2 * gI + (l31 >> 4), l31 & 15, hf);
-      row[f] = r_da1[gI];
-      row[128 + f] = r_x[0][gI];
-      row[256 + f] = r_x[1][gI];
-      row[384 + f] = r_x[2][gI];
-      row[512 + f] = r_da2[gI];
-      row[704 + f] = r_ws[gI];
+      for (int r = 0; r < 16; ++r) sr[wave * 256 + mfma_row(r, hf) * 8 + l31] = aS[0][r];
     }
-    row[640 + featidx(l31 >> 4, l31 & 15, hf)] = r_dac;
-    if (l31 < 16) row[832 + mfma_row(l31, hf)] = r_df;
-    if (l31 == 16 && hf == 0) row[864] = r_df;
-    if (l31 >= 17 && l31 < 20 && hf == 0) row[864 + (l31 - 16)] = 0.f;
+    float t = r_dsg;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+    if (lane == 0) sr[1024 + wave] = t;
+    if (lane == 1) sr[1028 + wave] = 0.f;
   }
   // ---- write the workgroup's partial weight gradients ----
   {
@@ -623,14 +791,30 @@ extern "C" int cips_siren_bwd_x3_chunks(int B, int P) {
   return (P + chunk - 1) / chunk;
 }
 extern "C" int cips_siren_bwd_x3_gpart(void) { return GPART; }
+static unsigned long long* g_prof = nullptr;
+extern "C" int cips_siren_bwd_x3_prof(unsigned long long* host_out) {   // tuning aid: copies the 8x4x16 timestamps
+  if (!g_prof) return (int)hipErrorNotReady;
+  return (int)hipMemcpy(host_out, g_prof, 8 * 4 * 16 * 8, hipMemcpyDeviceToHost);
+}
+extern "C" int cips_siren_bwd_x3_sred(void) { return SRED; }
 
 extern "C" int cips_siren_bwd_x3(const cips_siren_weights* w, const float* points, const float* dfeat,
-                                 const float* dsigma, float* red, float* gpart, int B, int P,
+                                 const float* dsigma, float* sred, float* gpart, int B, int P,
                                  cips_stream_t stream) {
-  if (!w || !points || !dfeat || !dsigma || !red || !gpart || B <= 0 || P <= 0) return (int)hipErrorInvalidValue;
+  if (!w || !points || !dfeat || !dsigma || !sred || !gpart || B <= 0 || P <= 0) return (int)hipErrorInvalidValue;
   BwdX3Args a;
-  a.w = *w; a.points = points; a.dfeat = dfeat; a.dsigma = dsigma; a.red = red; a.gpart = gpart;
+  a.w = *w; a.points = points; a.dfeat = dfeat; a.dsigma = dsigma; a.sred = sred; a.gpart = gpart;
   a.B = B; a.P = P;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("CIPS_X3_DBG"); dbg = e ? atoi(e) : 0; }
+  a.dbg = dbg;
+  static unsigned long long* prof = nullptr;
+  static int want_prof = -1;
+  if (want_prof < 0) {
+    want_prof = getenv("CIPS_X3_PROF") ? 1 : 0;
+    if (want_prof && hipMalloc(&prof, 8 * 4 * 16 * 8) != hipSuccess) prof = nullptr;
+  }
+  a.prof = prof; g_prof = prof;
   a.chunk = x3_chunk(B, P);
   a.chunks = (P + a.chunk - 1) / a.chunk;
   dim3 grid(a.chunks, B);

@@ -172,11 +172,21 @@ class SirenFunction(torch.autograd.Function):
             # fused kernel: recompute + data gradients + weight-gradient contractions, nothing staged in HBM
             chunks = lib.cips_siren_bwd_x3_chunks(B, P)
             gw = lib.cips_siren_bwd_x3_gpart()
-            red = torch.empty(B * chunks * 4, 868, device=dev)
+            sw_ = lib.cips_siren_bwd_x3_sred()
+            sred = torch.empty(B * chunks, sw_, device=dev)
             gpart = torch.empty(B * chunks, gw, device=dev)
-            check(lib.cips_siren_bwd_x3(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(red), _p(gpart), B, P,
+            check(lib.cips_siren_bwd_x3(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(sred), _p(gpart), B, P,
                                         _stream()), "cips_siren_bwd_x3")
-            R = red.view(B, chunks * 4, 868).sum(1)
+            SR = sred.view(B, chunks, sw_).sum(1)
+            T = SR[:, :1024].view(B, 4, 32, 8)                     # [wave][row][column sums], see cips3d_hip.h
+            R = torch.zeros(B, 868, device=dev)                    # same row format as the staged data pass
+            R[:, 0:128] = T[..., 0].reshape(B, 128)
+            R[:, 128:512] = T[..., 1:4].reshape(B, 128, 3).transpose(1, 2).reshape(B, 384)
+            R[:, 512:640] = T[..., 4].reshape(B, 128)
+            R[:, 640:704] = T[:, 0:2, :, 6].reshape(B, 64)
+            R[:, 704:832] = T[..., 5].reshape(B, 128)
+            R[:, 832:864] = T[:, 0, :, 7] + T[:, 2, :, 7]
+            R[:, 864] = SR[:, 1024:1028].sum(1)
             Gp = gpart.view(B, chunks, gw).sum(1)
             G1 = Gp[:, :16384].view(B, 128, 128)                    # da2^T @ h1
             Gc = Gp[:, 16384:24576].view(B, 64, 128)                # dac^T @ h2

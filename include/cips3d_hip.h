@@ -96,19 +96,27 @@ int cips_siren_bwd_data(const cips_siren_weights* w, const float* points,
                         void* da2_hi, void* da2_lo, void* dac_hi, void* dac_lo,
                         float* red, int B, int P, cips_stream_t stream);
 
-/* Backward, fused bf16x3 form (default): forward recompute, data gradients and all three weight-gradient
- * contractions in one kernel on v_mfma_f32_32x32x16_bf16 with 3-pass split operands (fp32 accumulate);
- * no activation staging in HBM.  chunks = cips_siren_bwd_x3_chunks(B,P) workgroups per image.
- *   red   (B*chunks*4, 868)  per-wave reduction rows, same column layout as cips_siren_bwd_data
- *   gpart (B*chunks, cips_siren_bwd_x3_gpart()) per-workgroup partial weight gradients, floats:
+/* Backward, fused bf16x3 form (default): forward recompute, data gradients, all three weight-gradient
+ * contractions and every per-feature sum over points in one kernel on v_mfma_f32_32x32x16_bf16 with 3-pass
+ * split operands (fp32 accumulate); no activation staging in HBM.
+ * chunks = cips_siren_bwd_x3_chunks(B,P) workgroups per image; partials of image b are rows
+ * [b*chunks, (b+1)*chunks) of both outputs:
+ *   sred  (B*chunks, cips_siren_bwd_x3_sred())  floats [wave w=0..3][row 0..31][col 0..7], then 4 per-wave
+ *         sums of dsigma (+4 pad).  Row r of wave w is feature 32w + r; columns:
+ *           0 sum_p da1 | 1..3 sum_p da1 * (x, y, z) | 4 sum_p da2 | 5 sum_p dsigma * h2
+ *           | 6 sum_p dac (waves 0,1: 64 features) | 7 sum_p dfeat (waves 0 and 2: partial sums, 32 channels)
+ *   gpart (B*chunks, cips_siren_bwd_x3_gpart()) floats:
  *         [0,16384)  da2^T h1 (128,128) | [16384,24576) dac^T h2 (64,128)
  *         | [24576,26624) and [26624,28672) two partial dfeat^T hc (32,64)
- * Rows / partials of image b are [b*chunks*4, (b+1)*chunks*4) and [b*chunks, (b+1)*chunks).
+ * (da1, da2, dac = d loss / d sine argument of layer 0, layer 1, colour layer.)
  */
 int cips_siren_bwd_x3_chunks(int B, int P);
 int cips_siren_bwd_x3_gpart(void);
+int cips_siren_bwd_x3_sred(void);
+/* tuning aid: with CIPS_X3_PROF set, phase timestamps (s_memtime) of workgroup (0,0), [round 0..7][wave 0..3][16] */
+int cips_siren_bwd_x3_prof(unsigned long long* host_out);
 int cips_siren_bwd_x3(const cips_siren_weights* w, const float* points, const float* dfeat,
-                      const float* dsigma, float* red, float* gpart, int B, int P, cips_stream_t stream);
+                      const float* dsigma, float* sred, float* gpart, int B, int P, cips_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* H3  hierarchical resampling + merge + alpha-composite               */

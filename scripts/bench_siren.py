@@ -28,6 +28,18 @@ def main():
     for _ in range(reps): step()
     e1.record(); torch.cuda.synchronize()
     print(f"siren fwd+bwd b={b} P={P} mode={ops.SIREN_BWD_MODE}: {e0.elapsed_time(e1) / reps:.3f} ms/iter")
+    if os.environ.get("CIPS_X3_PROF"):
+        import ctypes, numpy as np
+        from cips3d_amd import _lib
+        buf = np.zeros((8, 4, 16), dtype=np.uint64)
+        _lib.load().cips_siren_bwd_x3_prof(buf.ctypes.data_as(ctypes.c_void_p))
+        names = ["L0+L1", "film2", "Lc+filmc", "Gf", "dhc+dac", "Gc", "dh2+da2+dh1", "end(da1,h1)", "G1"]
+        for w in range(4):
+            d = np.diff(buf[2:7, w, :10].astype(np.int64), axis=1).mean(0)
+            tot = (buf[3:8, w, 0].astype(np.int64) - buf[2:7, w, 0].astype(np.int64)).mean()
+            g = np.diff(buf[2:7, w, 10:15].astype(np.int64), axis=1).mean(0)
+            print(f"   G1 sub-phase 1: stage={int(g[0])} barrier={int(g[1])} mfma={int(g[2])} barrier={int(g[3])}")
+            print(f"wave {w}: " + " ".join(f"{n}={int(x)}" for n, x in zip(names, d)) + f" | round={int(tot)} (s_memtime ticks, 100 MHz?)")
 
 if __name__ == "__main__":
     main()
