@@ -67,6 +67,7 @@ SIGNATURES = {
     "cips_composite_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_gemm_f32": (i32, [C.POINTER(GemmDesc), vp]),
     "cips_gemm_bf16x3": (i32, [C.POINTER(GemmX3Desc), vp]),
+    "cips_gemm_bf16x3_set_wide": (None, [i32]),
     "cips_gemm_bf16x3_km": (i32, [C.POINTER(GemmX3Desc), vp]),
     "cips_split_planes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
     "cips_modfc_prep_x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),

@@ -65,6 +65,7 @@ struct Args {
   int tiles_m, tiles_n, total;
   int stagger_cycles;   // start-phase quantum (shader cycles), 0 = no staggering
   int ncu;
+  int dbg;              // tuning only (env CIPS_X3_GDBG): bit0 skip fragment reads + MFMA, bit1 skip the LDS-DMA loads, bit2 skip the main loop
 };
 
 __device__ __forceinline__ u16 f2bf(float v) {
@@ -200,10 +201,10 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   // front of tile kt is a COUNTED vmcnt that leaves the younger tiles' pieces outstanding
   // (cdna_hip_programming.md T3/T4: never drain to 0 in the main loop).
   constexpr int NSTAGE = CF::NSTAGE, PIECES = CF::PIECES, DIST = NSTAGE - 1;
-  const int nk = K / BK;
+  const int nk = (g.dbg & 4) ? 0 : K / BK;               // bit2: epilogue only
 #pragma unroll
   for (int t = 0; t < DIST; ++t)
-    if (t < nk) issue_tile(t, t * BK);
+    if (t < nk && !(g.dbg & 2)) issue_tile(t, t * BK);
   for (int kt = 0; kt < nk; ++kt) {
     const int younger = min(DIST - 1, nk - 1 - kt);      // tiles issued after kt that may stay in flight
     if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // every wave's pieces of tile kt have landed;
                                                           // every wave is done reading stage (kt-1) % NSTAGE
-    if (kt + DIST < nk) issue_tile((kt + DIST) % NSTAGE, (kt + DIST) * BK);
-    compute(kt % NSTAGE);
+    if (kt + DIST < nk && !(g.dbg & 2)) issue_tile((kt + DIST) % NSTAGE, (kt + DIST) * BK);
+    if (!(g.dbg & 1)) compute(kt % NSTAGE);
   }
   __builtin_amdgcn_s_barrier();
 
@@ -640,10 +641,22 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 }  // namespace
 
+extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream);   // gemm_bf16x3_wide.hip
+static int g_wide = -1;   // -1: from env CIPS_X3_WIDE (default 1); 0 never; 1 for large problems; 2 whenever supported
+extern "C" void cips_gemm_bf16x3_set_wide(int mode) { g_wide = mode; }
+
 extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
   if ((d->K & 31) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
     return (int)hipErrorInvalidValue;
+  // large square-ish problems: 256x256 tiles (less operand traffic per flop, prefetched epilogue inputs);
+  // CIPS_X3_WIDE=0 keeps everything on the 256x128 kernel below
+  if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }
+  const bool big = d->N >= 256 && d->M >= 256 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 256;
+  if (g_wide == 2 || (g_wide == 1 && big)) {
+    const int rc = cips_gemm_bf16x3_wide(d, stream);
+    if (rc != (int)hipErrorNotSupported) return rc;
+  }
   // tile choice: 256x128 / 8 waves / 3-stage ring (default, measured fastest); CIPS_X3_TILE=128 selects 128x128 / 4 waves / 4 stages
   static int tile = 0;
   if (!tile) {
@@ -677,6 +690,9 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   if (stagger_on < 0) { const char* e = getenv("CIPS_X3_STAGGER"); stagger_on = (e && atoi(e) == 1) ? 1 : 0; }   // measured: no effect (the F/D GEMMs are memory-system bound), off by default
   g.stagger_cycles = (stagger_on && g.total >= 2 * grid) ? (d->K / BK) * (tile == 256 ? 3500 : 1800) / 4 : 0;
   g.ncu = ncu;
+  static int gdbg = -1;
+  if (gdbg < 0) { const char* e = getenv("CIPS_X3_GDBG"); gdbg = e ? atoi(e) : 0; }
+  g.dbg = gdbg;
   if (tile == 256)
     hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3(grid), dim3(512), Cfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
   else
@@ -699,7 +715,7 @@ extern "C" int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t str
   long long total = (long long)g.tiles_m * g.tiles_n * d->batch;
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
-  g.stagger_cycles = 0; g.ncu = 0;
+  g.stagger_cycles = 0; g.ncu = 0; g.dbg = 0;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0; hipDeviceProp_t prop;

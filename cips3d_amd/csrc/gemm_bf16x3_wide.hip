@@ -1,0 +1,411 @@
+// gemm_bf16x3_wide.hip — 256x256-tile form of the split-bf16 "NT" GEMM (see gemm_bf16x3.hip for the numerics,
+// the LDS-DMA staging and the epilogue contract; this file only changes the tiling and the schedule).
+//
+// Why: at the CIPS head's shapes (M = 131072 rows, N = K = 512) the 256x128 kernel is bound by the bytes its
+// workgroups pull through L2 -> LDS (1.57 GB per GEMM, ~10 TB/s: loads alone 120 us, fragment reads + MFMA alone
+// 140 us, together 235 us) plus an epilogue whose global reads sit exposed behind it.  Here
+//   * the tile is 256 x 256 on eight waves (4 x 2, 64 x 128 each, 128 accumulator registers of the wave's 256;
+//     a four-wave 128 x 128 split needs all 256 AGPRs for accumulators and hipcc then shuttles tiles through
+//     arch VGPRs every k-step): 1.05 GB of operand traffic per GEMM (64 fp32-flop per byte instead of 43) and
+//     12 fragment reads per 24 MFMAs instead of 8 per 12;
+//   * two 64 KiB LDS stages; the DMA of k-tile t+1 is issued right after the barrier that publishes tile t and
+//     has the whole of tile t's 48 MFMAs per wave to land;
+//   * the three passes of the operand split are issued pass-major over the wave's 8 output tiles, so that
+//     consecutive MFMAs never chain on one accumulator;
+//   * the epilogue walks the wave's 64 x 128 block in eight 32 x 32 sub-tiles: the raw accumulators make ONE trip
+//     through a per-wave fp32 LDS scratch to turn "lane = column" into "lane = 8 consecutive columns of a row",
+//     and everything else (addend, gate, activation, residual, bf16 splitting with v_cvt_pk_bf16_f32, all
+//     stores) happens in that row-contiguous form straight from / to 16-byte global accesses; the global inputs
+//     of sub-tile s+2 (residual planes, gate plane, fp32 addend) are requested before sub-tile s is processed —
+//     the first two around the last k-tile's MFMAs — so those reads no longer sit exposed behind each other;
+//   * the scratch aliases LDS stage 1 only: the first k-tile of the workgroup's NEXT output tile is DMA'd into
+//     stage 0 before the epilogue starts, and the next main loop opens with a COUNTED vmcnt that leaves the
+//     epilogue's stores in flight (vmcnt retires in order: the DMA pieces are older than every store).
+// Restrictions (else the caller falls back to the 256x128 kernel): no transposed planes (T_hi), 16-byte aligned
+// rows of every auxiliary tensor (N, ldc, ldp multiples of 8).
+#include "common.h"
+#include "../../include/cips3d_hip.h"
+#include <stdlib.h>
+#include <utility>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+constexpr int BM = 256, BN = 256, BK = 32, ROWB = 64;
+constexpr int OFF_AHI = 0, OFF_ALO = BM * ROWB, OFF_BHI = 2 * BM * ROWB, OFF_BLO = OFF_BHI + BN * ROWB;
+constexpr int STAGE = OFF_BLO + BN * ROWB;      // 65536
+constexpr int NSTAGE = 2;
+constexpr int PIECES = 8;                       // LDS-DMA instructions per wave per k-tile
+constexpr int PF = 36;                          // scratch pitch: fp32 image [32][36] per wave
+constexpr int SCR_WAVE = 32 * PF * 4;           // 4608 B per wave
+constexpr int SMEM_BYTES = NSTAGE * STAGE;      // 131072; the epilogue scratch (36 KiB) aliases stage 1 only, so that
+                                                // the next tile's first k-tile can stream into stage 0 meanwhile
+static_assert(8 * SCR_WAVE <= STAGE, "scratch");
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// compile-time loop: the sub-tile index must be a constant, or acc[][] is indexed dynamically and lands in scratch
+template <typename F, int... I>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+struct WArgs {
+  cips_gemm_x3_desc d;
+  int tiles_m, tiles_n, total, dbg;
+};
+
+__device__ __forceinline__ u16 f2bf(float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// HAS_ADD / HAS_MASK / HAS_RES: which global inputs the epilogue reads (fp32 addend, gate plane, residual planes);
+// compile-time so that only their prefetch registers exist.
+template <bool HAS_ADD, bool HAS_MASK, bool HAS_RES>
+__global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const cips_gemm_x3_desc& d = g.d;
+  const int tid = threadIdx.x;
+  const int lane0 = tid & 63;
+  const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = uw, wm = wave >> 1, wn = wave & 1;       // 4 x 2 waves
+  const int M = d.M, N = d.N, K = d.K;
+  const int nk = (g.dbg & 4) ? 0 : K / BK;
+  const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+#define LDS_B128(a) (*((__attribute__((address_space(3))) const bf16x8*)(uintptr_t)(a)))
+
+  // tile coordinates of sequence number t (XCD-contiguous tile ranges, see gemm_bf16x3.hip)
+  auto decode = [&](int t, int& tm, int& tn, int& bz) {
+    const int nx = 8;
+    int q = g.total / nx, r = g.total % nx;
+    int xcd = t % nx, idx = t / nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int bid = base + idx;
+    tn = bid % g.tiles_n;
+    tm = (bid / g.tiles_n) % g.tiles_m;
+    bz = bid / (g.tiles_n * g.tiles_m);
+  };
+  // LDS-DMA of one k-tile: a wave instruction moves 16 rows x 64 B of one plane; lane L = (row L>>2, slot L&3) fetches
+  // the global 16-byte chunk slot ^ ((row>>2)&3) — the swizzle lives in the source address.  Addresses are a uniform
+  // plane pointer (advanced by k0 on the scalar side) plus one 32-bit byte offset per piece and lane; rows past
+  // M / N are clamped (their products are never stored).
+  struct Src { const u16 *Ahi, *Alo, *Bhi, *Blo; unsigned offA[2], offB[2]; };
+  auto make_src = [&](int tm, int tn, int bz, int lane, Src& sr) {
+    const int m0 = tm * BM, n0 = tn * BN;
+    sr.Ahi = (const u16*)d.A_hi + (long long)bz * d.strideA + (long long)m0 * d.lda;
+    sr.Alo = (const u16*)d.A_lo + (long long)bz * d.strideA + (long long)m0 * d.lda;
+    sr.Bhi = (const u16*)d.B_hi + (long long)bz * d.strideB + (long long)n0 * d.ldb;
+    sr.Blo = (const u16*)d.B_lo + (long long)bz * d.strideB + (long long)n0 * d.ldb;
+    const int drow = lane >> 2, dslot = lane & 3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = (uw + 8 * p) * 16 + drow;
+      const int kcsw = dslot ^ ((row >> 2) & 3);
+      const int ra = (row < M - m0) ? row : (M - m0 - 1), rb = (row < N - n0) ? row : (N - n0 - 1);
+      sr.offA[p] = (unsigned)(ra * d.lda + kcsw * 8) * 2u;
+      sr.offB[p] = (unsigned)(rb * d.ldb + kcsw * 8) * 2u;
+    }
+  };
+  auto dma = [&](const u16* plane_k, unsigned off, unsigned char* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)plane_k + off),
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+  };
+  auto dma_piece = [&](const Src& sr, int pc, int k0, unsigned char* s) {      // pc = 0..7
+    const int pp = pc >> 2, which = pc & 3;
+    const int gidx = uw + 8 * pp;                                               // 16 row groups per plane, two per wave
+    if (which == 0) dma(sr.Ahi + k0, sr.offA[pp], s + OFF_AHI + gidx * 16 * ROWB);
+    else if (which == 1) dma(sr.Alo + k0, sr.offA[pp], s + OFF_ALO + gidx * 16 * ROWB);
+    else if (which == 2) dma(sr.Bhi + k0, sr.offB[pp], s + OFF_BHI + gidx * 16 * ROWB);
+    else dma(sr.Blo + k0, sr.offB[pp], s + OFF_BLO + gidx * 16 * ROWB);
+  };
+
+  bool first_issued = false;       // k-tile 0 of the coming tile is already in flight (issued before the last epilogue)
+  int ops_after = 0;               // VMEM operations issued after those DMA pieces
+
+  for (int tseq = blockIdx.x; tseq < g.total; tseq += gridDim.x) {
+    // the whole tile body is invariant across the persistent loop: launder the lane id, or hipcc hoists every
+    // per-lane address of the epilogue out of the loop and spills them
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int l31 = lane & 31, hf = lane >> 5;
+    int tm, tn, bz;
+    decode(tseq, tm, tn, bz);
+    const int m0 = tm * BM, n0 = tn * BN;
+    Src src;
+    make_src(tm, tn, bz, lane, src);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Fragment reads: row R = tile row + lane&31, 16-byte chunk (2ks + hf) ^ ((R>>2)&3).  (R>>2)&3 only depends on
+    // the lane, so every address is one of four lane bases (A / B, ks = 0 / 1) plus an immediate.
+    const int csw = (l31 >> 2) & 3;
+    const unsigned fa0 = sbase + (wm * 64 + l31) * ROWB + ((hf ^ csw) << 4), fa1 = sbase + (wm * 64 + l31) * ROWB + (((2 + hf) ^ csw) << 4);
+    const unsigned fb0 = sbase + (wn * 128 + l31) * ROWB + ((hf ^ csw) << 4), fb1 = sbase + (wn * 128 + l31) * ROWB + (((2 + hf) ^ csw) << 4);
+    // One k-tile = two k-steps of 24 MFMAs (pass-major over the 8 output tiles).  The 8 LDS-DMA pieces of the NEXT
+    // k-tile are issued one per three MFMAs inside the first k-step: an LDS-DMA issue costs the wave 60-180
+    // cycles, which the matrix pipe spends on the MFMAs already queued instead of idling behind a burst of 8.
+    auto compute = [&](int stage, bool issue_next, int next_stage, int k0n) {
+      unsigned ba[2], bb[2];
+      ba[0] = fa0 + stage * STAGE; ba[1] = fa1 + stage * STAGE; bb[0] = fb0 + stage * STAGE; bb[1] = fb1 + stage * STAGE;
+      asm volatile("" : "+v"(ba[0]), "+v"(ba[1]), "+v"(bb[0]), "+v"(bb[1]));   // one base register per operand and k-step,
+                                                                                // constants go to the offset field
+      unsigned char* sn = smem + next_stage * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[i] = LDS_B128(ba[ks] + OFF_AHI + i * 32 * ROWB);
+          al[i] = LDS_B128(ba[ks] + OFF_ALO + i * 32 * ROWB);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bh[j] = LDS_B128(bb[ks] + OFF_BHI + j * 32 * ROWB);
+          bl[j] = LDS_B128(bb[ks] + OFF_BLO + j * 32 * ROWB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 24; ++m) {
+          const int pass = m >> 3, i = (m >> 2) & 1, j = m & 3;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pass == 0 ? al[i] : ah[i], pass == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+          if (ks == 0 && (m % 3) == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (issue_next) dma_piece(src, m / 3, k0n, sn);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    // ---------------- epilogue plumbing (declared first: the first sub-tiles' inputs are requested around the last k-tile)
+    const long long cb = (long long)bz * d.strideC, pb = (long long)bz * d.strideP;
+    u16* Phi = (u16*)d.P_hi; u16* Plo = (u16*)d.P_lo;
+    float* sc_f = reinterpret_cast<float*>(smem + STAGE + wave * SCR_WAVE);      // inside stage 1
+    // sub-tile st = 4*i + jj: rows wm*64 + 32 i .., columns wn*128 + 32 jj ..   (one MFMA tile).  Row-contiguous form:
+    // lane -> rows h_rr and h_rr + 16, 8 consecutive columns from h_c8
+    const int h_rr = lane >> 2, h_c8 = (lane & 3) * 8;
+    struct Pre { float4 add[HAS_ADD ? 4 : 1]; uint4 mask[HAS_MASK ? 2 : 1], rh[HAS_RES ? 2 : 1], rl[HAS_RES ? 2 : 1]; };
+    auto prefetch = [&](int st, Pre& p) {
+      const int row0 = m0 + wm * 64 + (st >> 2) * 32, col0 = n0 + wn * 128 + (st & 3) * 32;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int row = row0 + h_rr + 16 * c, col = col0 + h_c8;
+        const bool ok = row < M && col < N;
+        if constexpr (HAS_ADD) {
+          const float* q = d.add + cb + (long long)row * d.ldc + col;
+          p.add[2 * c] = ok ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+          p.add[2 * c + 1] = ok ? *reinterpret_cast<const float4*>(q + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const long long o = pb + (long long)row * d.ldp + col;
+        if constexpr (HAS_MASK) p.mask[c] = ok ? *reinterpret_cast<const uint4*>((const u16*)d.mask + o) : make_uint4(0, 0, 0, 0);
+        if constexpr (HAS_RES) {
+          p.rh[c] = ok ? *reinterpret_cast<const uint4*>((const u16*)d.res_hi + o) : make_uint4(0, 0, 0, 0);
+          p.rl[c] = ok ? *reinterpret_cast<const uint4*>((const u16*)d.res_lo + o) : make_uint4(0, 0, 0, 0);
+        }
+      }
+    };
+    constexpr int LOADS_PER_SUB = (HAS_ADD ? 4 : 0) + (HAS_MASK ? 2 : 0) + (HAS_RES ? 4 : 0);
+
+    // ---------------- main loop: two stages, DMA of k-tile kt+1 in flight under the MFMAs of k-tile kt
+    Pre pre[2];
+    if (nk > 0 && !first_issued && !(g.dbg & 2)) {
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) dma_piece(src, pc, 0, smem);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt == 0 && first_issued) {
+        // k-tile 0 was issued before the previous epilogue: leave that epilogue's younger stores / loads in flight
+        if (ops_after >= 56) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+        else if (ops_after >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        else if (ops_after >= 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        else if (ops_after >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (ops_after >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (ops_after >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();              // k-tile kt has landed everywhere; stage (kt+1)&1 is free again
+      const bool more = kt + 1 < nk;
+      if (!more) prefetch(0, pre[0]);            // last k-tile: the first sub-tile's epilogue inputs ride under its MFMAs
+      if (!(g.dbg & 1)) compute(kt & 1, more && !(g.dbg & 2), (kt + 1) & 1, (kt + 1) * BK);
+      else if (more && !(g.dbg & 2)) {
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) dma_piece(src, pc, (kt + 1) * BK, smem + ((kt + 1) & 1) * STAGE);
+      }
+    }
+    if (nk == 0) prefetch(0, pre[0]);
+    __syncthreads();   // main-loop LDS reads are done everywhere; the scratch regions alias stage 1
+
+    // ---------------- the next output tile's first k-tile streams into stage 0 while this tile's epilogue runs
+    first_issued = false;
+    if (nk > 0 && (nk & 1) == 0 && tseq + (int)gridDim.x < g.total && !(g.dbg & 2)) {
+      int tm2, tn2, bz2;
+      decode(tseq + gridDim.x, tm2, tn2, bz2);
+      Src nsrc;
+      make_src(tm2, tn2, bz2, lane, nsrc);
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) dma_piece(nsrc, pc, 0, smem);
+      first_issued = true;
+    }
+    prefetch(1, pre[1]);
+    // every global access below is younger than those DMA pieces; with the rank-3 term (scalar gathers, unknown count)
+    // fall back to a full drain
+    {
+      // a LOWER bound is required (waiting on vmcnt(n) with n above the real count would not wait for the DMA):
+      // boundary tiles may skip predicated-off accesses, so only interior tiles use the counted wait
+      const int stores_per_sub = (d.C_unmasked ? 4 : 0) + (d.mask_out ? 2 : 0) + (d.C ? 4 : 0) + (Phi ? 4 : 0);
+      const bool interior = (m0 + BM <= M) && (n0 + BN <= N);
+      ops_after = (d.rgb_g || !interior) ? 0 : 8 * stores_per_sub + 7 * LOADS_PER_SUB;
+    }
+
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    auto pack8 = [](const float (&x)[8]) -> uint4 {          // 8 floats -> 8 bf16 (RNE), v_cvt_pk_bf16_f32
+      unsigned w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f32x2 t = {x[2 * e], x[2 * e + 1]};
+        w[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+      }
+      return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    auto unpack8 = [](const uint4& u, float (&x)[8]) {
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(w[e] << 16); x[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    };
+    static_for(std::make_integer_sequence<int, 8>{}, [&](auto ST) {
+      constexpr int st = decltype(ST)::value, si = st >> 2, jj = st & 3;
+      const int row0 = m0 + wm * 64 + si * 32, col0 = n0 + wn * 128 + jj * 32;
+      // raw accumulators -> scratch (lane = column), read back as lane = 8 consecutive columns of rows h_rr, h_rr + 16
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc_f[mfma_row(r, hf) * PF + l31] = acc[si][jj][r];
+      WAVE_SYNC();
+      float x[2][8];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(sc_f + (h_rr + 16 * c) * PF + h_c8);
+        const float4 b = *reinterpret_cast<const float4*>(sc_f + (h_rr + 16 * c) * PF + h_c8 + 4);
+        x[c][0] = a.x; x[c][1] = a.y; x[c][2] = a.z; x[c][3] = a.w; x[c][4] = b.x; x[c][5] = b.y; x[c][6] = b.z; x[c][7] = b.w;
+      }
+      WAVE_SYNC();                                           // scratch may be overwritten by the next sub-tile
+      Pre& cur = pre[st & 1];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int row = row0 + h_rr + 16 * c, col = col0 + h_c8;
+        const bool ok = row < M && col < N;
+        float (&y)[8] = x[c];
+        if constexpr (HAS_ADD) {
+          y[0] += cur.add[2 * c].x; y[1] += cur.add[2 * c].y; y[2] += cur.add[2 * c].z; y[3] += cur.add[2 * c].w;
+          y[4] += cur.add[2 * c + 1].x; y[5] += cur.add[2 * c + 1].y; y[6] += cur.add[2 * c + 1].z; y[7] += cur.add[2 * c + 1].w;
+        }
+        if (d.rgb_g && ok) {                                 // rank-3 term: + g[row][0..2] . rgb_w[0..2][col..col+8]
+          const float* gp = d.rgb_g + ((long long)bz * M + row) * 3;
+          const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            y[e] = fmaf(g0, d.rgb_w[col + e], fmaf(g1, d.rgb_w[N + col + e], fmaf(g2, d.rgb_w[2 * N + col + e], y[e])));
+        }
+        if (d.C_unmasked && ok) {
+          float* q = d.C_unmasked + cb + (long long)row * d.ldc + col;
+          *reinterpret_cast<float4*>(q) = make_float4(y[0], y[1], y[2], y[3]);
+          *reinterpret_cast<float4*>(q + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+        if constexpr (HAS_MASK) {
+          const unsigned w[4] = {cur.mask[c].x, cur.mask[c].y, cur.mask[c].z, cur.mask[c].w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const unsigned mb = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+            const bool pos = ((mb & 0x8000u) == 0) && ((mb & 0x7fffu) != 0);
+            y[e] *= pos ? 1.f : d.slope;
+          }
+        }
+        if (d.act) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = lrelu(y[e], d.slope);
+        }
+        const long long po = pb + (long long)row * d.ldp + col;
+        if (d.mask_out && ok) *reinterpret_cast<uint4*>((u16*)d.mask_out + po) = pack8(y);
+        if constexpr (HAS_RES) {
+          float rh[8], rl[8];
+          unpack8(cur.rh[c], rh); unpack8(cur.rl[c], rl);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] += rh[e] + rl[e];
+        }
+        if (d.C && ok) {
+          float* q = d.C + cb + (long long)row * d.ldc + col;
+          *reinterpret_cast<float4*>(q) = make_float4(y[0], y[1], y[2], y[3]);
+          *reinterpret_cast<float4*>(q + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+        if (Phi && ok) {
+          const uint4 hi = pack8(y);
+          float hf_[8], lo[8];
+          unpack8(hi, hf_);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) lo[e] = y[e] - hf_[e];
+          *reinterpret_cast<uint4*>(Phi + po) = hi;
+          *reinterpret_cast<uint4*>(Plo + po) = pack8(lo);
+        }
+      }
+      if (st + 2 < 8) prefetch(st + 2, cur);                 // this sub-tile's inputs are consumed: request those of st + 2
+    });
+    __syncthreads();   // scratch (stage 1) is free again before the next tile's second k-tile lands in it
+#undef WAVE_SYNC
+  }  // persistent tile loop
+}
+
+}  // namespace
+
+// Internal entry (called by cips_gemm_bf16x3 when the shape and the epilogue qualify): same descriptor,
+// 256x256 tiles.  Returns hipErrorNotSupported for combinations it has no instantiation for.
+template <bool A, bool Mk, bool R>
+static void launch_wide(const WArgs& g, int grid, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_wide_kernel<A, Mk, R>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16x3_wide_kernel<A, Mk, R>), dim3(grid), dim3(512), SMEM_BYTES, stream, g);
+}
+
+extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
+  if ((d->K & 31) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7)) return (int)hipErrorInvalidValue;
+  if (d->T_hi || (d->N & 7) || (d->ldc & 3) || (d->strideC & 3) || (d->ldp & 7) || (d->strideP & 7)) return (int)hipErrorNotSupported;
+  const bool a = d->add != nullptr, m = d->mask != nullptr, r = d->res_hi != nullptr;
+  if ((a && !m) || (r && (a || m))) return (int)hipErrorNotSupported;
+  WArgs g;
+  g.d = *d;
+  g.tiles_m = (d->M + BM - 1) / BM;
+  g.tiles_n = (d->N + BN - 1) / BN;
+  long long total = (long long)g.tiles_m * g.tiles_n * d->batch;
+  if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  g.total = (int)total;
+  static int ncu = 0, gdbg = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+    ncu = (ncu / 8) * 8;
+    const char* e = getenv("CIPS_X3_GDBG"); gdbg = e ? atoi(e) : 0;
+  }
+  g.dbg = gdbg;
+  const int grid = g.total < ncu ? g.total : ncu;
+  hipStream_t st = (hipStream_t)stream;
+  if (a) launch_wide<true, true, false>(g, grid, st);
+  else if (m) launch_wide<false, true, false>(g, grid, st);
+  else if (r) launch_wide<false, false, true>(g, grid, st);
+  else launch_wide<false, false, false>(g, grid, st);
+  return CIPS_CHECK_LAUNCH();
+}

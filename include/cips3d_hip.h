@@ -226,6 +226,9 @@ typedef struct cips_gemm_x3_desc {
 int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream);
 /* K-major form: C[b][m][n] = sum_k A[b][k][m] * B[b][k][n] (A planes [K][lda], B planes [K][ldb]: the row-major
  * activation / gradient planes themselves; LDS transpose reads build the fragments).  fp32 C output only. */
+/* Tile-form selection of cips_gemm_bf16x3: 0 = 256x128 tiles always, 1 = 256x256 tiles for large problems (default;
+ * env CIPS_X3_WIDE), 2 = 256x256 tiles whenever the epilogue is supported (tests). */
+void cips_gemm_bf16x3_set_wide(int mode);
 int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t stream);
 
 /* fp32 (rows, cols) [ldx] -> split bf16 planes row-major [rows][ldp] and/or transposed [cols][ldt]. */

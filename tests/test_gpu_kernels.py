@@ -300,6 +300,56 @@ def test_gemm_bf16x3_kmajor(M, N, K, batch):
     assert torch.isfinite(C).all() and e < 3e-5
 
 
+@pytest.mark.parametrize("M,N,K,batch", [(256, 256, 64, 1), (520, 264, 96, 2), (4096, 512, 512, 20), (1024, 768, 32, 3)])
+@pytest.mark.parametrize("flavour", ["plain", "res", "mask", "add"])
+def test_gemm_bf16x3_wide(M, N, K, batch, flavour):
+    """256x256-tile form (gemm_bf16x3_wide.hip), forced on: every epilogue flavour, ragged edges, and enough tiles
+    per workgroup (4096x512x20 -> 640 tiles on 256 CUs) to exercise the prefetched first k-tile + counted wait."""
+    from cips3d_amd import ops, _lib
+    lib = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M + 3 * N + K + len(flavour))
+    A = torch.randn(batch, M, K, generator=g); B = torch.randn(batch, N, K, generator=g)
+    acc = torch.bmm(A.double(), B.double().transpose(1, 2))
+    Ap = ops.Planes(*[t.to(d) for t in _planes(A)]); Bp = ops.Planes(*[t.to(d) for t in _planes(B)])
+    res = torch.randn(batch, M, N, generator=g); add = torch.randn(batch, M, N, generator=g)
+    mask = torch.randn(batch, M, N, generator=g)
+    rg = torch.randn(batch * M, 3, generator=g); rw = torch.randn(3, N, generator=g)
+    resP = ops.Planes(*[t.to(d) for t in _planes(res)])
+    P = ops.Planes.empty(batch, M, N, device=d)
+    lib.cips_gemm_bf16x3_set_wide(2)
+    try:
+        if flavour == "plain":          # forward FC1: lrelu + planes, and the plain fp32 output
+            C = torch.full((batch, M, N), float("nan"), device=d)
+            ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, C=C, P=P, act=1)
+            want = torch.nn.functional.leaky_relu(acc, 0.2)
+            assert rel_err(C, want) < 3e-5 and rel_err(P.float(), C) < 1e-5
+        elif flavour == "res":          # forward FC2 of a skip block: lrelu, gate plane out, residual, planes
+            mo = torch.empty(batch, M, N, device=d, dtype=torch.bfloat16)
+            ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P, act=1, res=resP, mask_out=mo)
+            a = torch.nn.functional.leaky_relu(acc, 0.2)
+            assert rel_err(P.float(), a + resP.float().cpu().double()) < 3e-5
+            assert ((mo.float().cpu() > 0) == (a > 0)).float().mean() > 0.9999
+        elif flavour == "mask":         # backward through FC2: gate from a saved plane
+            ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P, mask=mask.bfloat16().to(d))
+            want = acc * torch.where(mask.bfloat16().float() > 0, 1.0, 0.2).double()
+            assert rel_err(P.float(), want) < 3e-5
+        else:                           # backward through FC1 of a skip block: add + rank-3 rgb term + unmasked copy + gate
+            CU = torch.empty(batch, M, N, device=d)
+            ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P, add=add.to(d), rgb_g=rg.to(d), rgb_w=rw.to(d),
+                        C_unmasked=CU, mask=mask.bfloat16().to(d))
+            s_ = acc + add.double() + (rg.double() @ rw.double()).view(batch, M, N)
+            assert rel_err(CU, s_) < 3e-5
+            assert rel_err(P.float(), s_ * torch.where(mask.bfloat16().float() > 0, 1.0, 0.2).double()) < 3e-5
+            # and without the rgb term (the counted-wait path of this flavour)
+            ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P, add=add.to(d), C_unmasked=CU, mask=mask.bfloat16().to(d))
+            s2 = acc + add.double()
+            assert rel_err(CU, s2) < 3e-5
+        torch.cuda.synchronize()
+    finally:
+        lib.cips_gemm_bf16x3_set_wide(-1)
+
+
 def test_gemm_bf16x3_epilogues():
     from cips3d_amd import ops
     d = dev()
