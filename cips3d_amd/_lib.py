@@ -36,6 +36,18 @@ class GemmDesc(C.Structure):
     ]
 
 
+class ModfcPrepJob(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("s", C.c_void_p), ("wb_hi", C.c_void_p), ("wb_lo", C.c_void_p),
+                ("wbt_hi", C.c_void_p), ("wbt_lo", C.c_void_p), ("demod", C.c_void_p), ("in_dim", C.c_int),
+                ("out_dim", C.c_int)]
+
+
+class ModfcBwdJob(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("s", C.c_void_p), ("demod", C.c_void_p), ("gwb", C.c_void_p),
+                ("cbuf", C.c_void_p), ("dweight", C.c_void_p), ("ds", C.c_void_p), ("in_dim", C.c_int),
+                ("out_dim", C.c_int)]
+
+
 class GemmX3Desc(C.Structure):
     _fields_ = [
         ("A_hi", vp), ("A_lo", vp), ("B_hi", vp), ("B_lo", vp),
@@ -69,12 +81,16 @@ SIGNATURES = {
     "cips_gemm_bf16x3": (i32, [C.POINTER(GemmX3Desc), vp]),
     "cips_gemm_bf16x3_set_wide": (None, [i32]),
     "cips_gemm_bf16x3_km": (i32, [C.POINTER(GemmX3Desc), vp]),
+    "cips_gemm_bf16x3_km_grouped": (i32, [C.POINTER(GemmX3Desc), i32, vp]),
     "cips_split_planes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
     "cips_modfc_prep_x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cips_torgb_fwd_x3": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "cips_torgb_bwd_w_x3": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "cips_modfc_prep": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cips_modfc_prep_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "cips_modfc_max_jobs": (i32, []),
+    "cips_modfc_prep_x3_batch": (i32, [C.POINTER(ModfcPrepJob), i32, i32, C.c_float, vp]),
+    "cips_modfc_prep_bwd_batch": (i32, [C.POINTER(ModfcBwdJob), i32, i32, vp]),
     "cips_torgb_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
     "cips_torgb_bwd_partials": (i32, [i64]),
     "cips_torgb_bwd_w": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),

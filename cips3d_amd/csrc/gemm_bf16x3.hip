@@ -700,12 +700,20 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   return CIPS_CHECK_LAUNCH();
 }
 
+
 extern "C" int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t stream) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || !d->C) return (int)hipErrorInvalidValue;
   if ((d->K & 31) || (d->M & 7) || (d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
     return (int)hipErrorInvalidValue;
   if (d->P_hi || d->T_hi || d->mask || d->add || d->rgb_g || d->C_unmasked || d->mask_out || d->res_hi || d->act)
     return (int)hipErrorNotSupported;            // the K-major form has the plain fp32 epilogue only
+  // square-ish outputs filling the chip with 256x256 tiles: the wide kernel (a single problem is a group of one)
+  if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }
+  if (g_wide >= 1 && d->M >= 256 && d->N >= 256 &&
+      ((long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 192 || g_wide == 2)) {
+    const int rc = cips_gemm_bf16x3_km_grouped(d, 1, stream);
+    if (rc != (int)hipErrorNotSupported) return rc;
+  }
   // 256-row tiles when M fills them, else the 128-row form (SIREN weight gradients: M = 128 / 64)
   const int bm = (d->M > 128) ? 256 : 128;
   Args g;

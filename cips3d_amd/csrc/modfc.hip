@@ -347,6 +347,145 @@ __global__ __launch_bounds__(256) void torgb_bwd_x_kernel(const float* __restric
   }
 }
 
+
+// ---- batched forms: every modulated-FC layer of the CIPS head in ONE launch --------------------------------
+// The per-layer kernels above are a few microseconds of work each; 18 layers x (2 + 3) launches per step cost more
+// in launch tails and idle CUs than in arithmetic.  The weights and styles of all layers are known before the
+// head's forward starts, and every dL/dWb is known once its backward is through, so both directions batch.
+constexpr int MAXJOBS = 24;
+struct PrepJobs {
+  const float* W[MAXJOBS]; const float* s[MAXJOBS]; float* demod[MAXJOBS];
+  unsigned short *wbh[MAXJOBS], *wbl[MAXJOBS], *wth[MAXJOBS], *wtl[MAXJOBS];
+  int in_dim[MAXJOBS], out_dim[MAXJOBS];
+};
+__global__ __launch_bounds__(256) void modfc_demod_batch_kernel(PrepJobs J, int B, float eps) {
+  __shared__ float red[8][33];
+  const int job = blockIdx.z, b = blockIdx.y;
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  if (blockIdx.x * 32 >= out_dim) return;
+  const float* __restrict__ W = J.W[job];
+  const float* __restrict__ sb = J.s[job] + (long long)b * in_dim;
+  const int c = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  float q = 0.f;
+  if (n < out_dim)
+    for (int k = kg; k < in_dim; k += 8) {
+      float u = W[(long long)k * out_dim + n] * (sb[k] + 1.f);
+      q = fmaf(u, u, q);
+    }
+  red[kg][c] = q;
+  __syncthreads();
+  if (kg == 0 && n < out_dim) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][c];
+    J.demod[job][(long long)b * out_dim + n] = rsqrtf(t + eps);
+  }
+}
+__global__ __launch_bounds__(256) void modfc_planes_batch_kernel(PrepJobs J, int B) {
+  __shared__ unsigned short th[32][33], tl[32][33];
+  const int job = blockIdx.z / B, b = blockIdx.z % B;
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  if (n0 >= out_dim || k0 >= in_dim) return;
+  const float* __restrict__ W = J.W[job];
+  const float* __restrict__ s = J.s[job];
+  const float* __restrict__ demod = J.demod[job];
+  unsigned short *wbh = J.wbh[job], *wbl = J.wbl[job], *wth = J.wth[job], *wtl = J.wtl[job];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long base = (long long)b * in_dim * out_dim;
+  for (int kk = ty; kk < 32; kk += 8) {
+    const int k = k0 + kk, n = n0 + tx;
+    unsigned short h = 0, l = 0;
+    if (k < in_dim && n < out_dim) {
+      const float v = W[(long long)k * out_dim + n] * (s[(long long)b * in_dim + k] + 1.f) * demod[(long long)b * out_dim + n];
+      h = f2bf_rne(v);
+      l = f2bf_rne(v - __uint_as_float(((unsigned)h) << 16));
+      wbh[base + (long long)k * out_dim + n] = h;
+      wbl[base + (long long)k * out_dim + n] = l;
+    }
+    th[kk][tx] = h; tl[kk][tx] = l;
+  }
+  __syncthreads();
+  for (int nn = ty; nn < 32; nn += 8) {
+    const int n = n0 + nn, k = k0 + tx;
+    if (k < in_dim && n < out_dim) {
+      wth[base + (long long)n * in_dim + k] = th[tx][nn];
+      wtl[base + (long long)n * in_dim + k] = tl[tx][nn];
+    }
+  }
+}
+
+struct BwdJobs {
+  const float* W[MAXJOBS]; const float* s[MAXJOBS]; const float* demod[MAXJOBS]; const float* G[MAXJOBS];
+  float *cbuf[MAXJOBS], *dW[MAXJOBS], *ds[MAXJOBS];
+  int in_dim[MAXJOBS], out_dim[MAXJOBS];
+};
+__global__ __launch_bounds__(256) void modfc_prep_bwd_c_batch_kernel(BwdJobs J) {
+  __shared__ float red[8][33];
+  const int job = blockIdx.z, b = blockIdx.y;
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  if (blockIdx.x * 32 >= out_dim) return;
+  const float* __restrict__ W = J.W[job];
+  const float* __restrict__ sb = J.s[job] + (long long)b * in_dim;
+  const float* __restrict__ Gb = J.G[job] + (long long)b * in_dim * out_dim;
+  const int c = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  float q = 0.f;
+  if (n < out_dim)
+    for (int k = kg; k < in_dim; k += 8)
+      q = fmaf(Gb[(long long)k * out_dim + n], W[(long long)k * out_dim + n] * (sb[k] + 1.f), q);
+  red[kg][c] = q;
+  __syncthreads();
+  if (kg == 0 && n < out_dim) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][c];
+    J.cbuf[job][(long long)b * out_dim + n] = t;
+  }
+}
+__global__ __launch_bounds__(256) void modfc_prep_bwd_w_batch_kernel(BwdJobs J, int B) {
+  const int job = blockIdx.y;
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)in_dim * out_dim) return;
+  const float* __restrict__ s = J.s[job]; const float* __restrict__ demod = J.demod[job];
+  const float* __restrict__ G = J.G[job]; const float* __restrict__ cbuf = J.cbuf[job];
+  const int k = (int)(idx / out_dim), n = (int)(idx % out_dim);
+  const float w = J.W[job][idx];
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {   // fixed order: deterministic
+    const float m = s[(long long)b * in_dim + k] + 1.f;
+    const float d = demod[(long long)b * out_dim + n];
+    const float g = G[((long long)b * in_dim + k) * out_dim + n];
+    const float du = d * (g - d * d * (w * m) * cbuf[(long long)b * out_dim + n]);
+    acc = fmaf(m, du, acc);
+  }
+  J.dW[job][idx] = acc;
+}
+__global__ __launch_bounds__(256) void modfc_prep_bwd_s_batch_kernel(BwdJobs J, int B) {
+  const int job = blockIdx.y;
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)B * in_dim) return;
+  const float* __restrict__ W = J.W[job]; const float* __restrict__ demod = J.demod[job];
+  const float* __restrict__ G = J.G[job]; const float* __restrict__ cbuf = J.cbuf[job];
+  const int b = (int)(row / in_dim), k = (int)(row % in_dim);
+  const float m = J.s[job][row] + 1.f;
+  float acc = 0.f;
+  for (int n = lane; n < out_dim; n += 64) {
+    const float w = W[(long long)k * out_dim + n];
+    const float d = demod[(long long)b * out_dim + n];
+    const float g = G[row * out_dim + n];
+    const float du = d * (g - d * d * (w * m) * cbuf[(long long)b * out_dim + n]);
+    acc = fmaf(w, du, acc);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) J.ds[job][row] = acc;
+}
+
 }  // namespace
 
 extern "C" int cips_modfc_prep(const float* weight, const float* s, float* wb, float* wbt, float* demod,
@@ -442,5 +581,48 @@ extern "C" int cips_torgb_bwd_x(const float* drgb, const float* w, const float* 
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(torgb_bwd_x_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, drgb, w, add,
                      mask, slope, out_unmasked, out, M, K);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_modfc_max_jobs(void) { return MAXJOBS; }
+
+extern "C" int cips_modfc_prep_x3_batch(const cips_modfc_prep_job* jobs, int njobs, int B, float eps, cips_stream_t stream) {
+  if (!jobs || njobs <= 0 || njobs > MAXJOBS || B <= 0) return (int)hipErrorInvalidValue;
+  PrepJobs J;
+  int max_in = 0, max_out = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const cips_modfc_prep_job& j = jobs[i];
+    if (j.in_dim <= 0 || j.out_dim <= 0) return (int)hipErrorInvalidValue;
+    J.W[i] = j.weight; J.s[i] = j.s; J.demod[i] = j.demod;
+    J.wbh[i] = (unsigned short*)j.wb_hi; J.wbl[i] = (unsigned short*)j.wb_lo;
+    J.wth[i] = (unsigned short*)j.wbt_hi; J.wtl[i] = (unsigned short*)j.wbt_lo;
+    J.in_dim[i] = j.in_dim; J.out_dim[i] = j.out_dim;
+    max_in = j.in_dim > max_in ? j.in_dim : max_in; max_out = j.out_dim > max_out ? j.out_dim : max_out;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(modfc_demod_batch_kernel, dim3((max_out + 31) / 32, B, njobs), dim3(256), 0, st, J, B, eps);
+  hipLaunchKernelGGL(modfc_planes_batch_kernel, dim3((max_out + 31) / 32, (max_in + 31) / 32, B * njobs), dim3(256), 0, st, J, B);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_modfc_prep_bwd_batch(const cips_modfc_bwd_job* jobs, int njobs, int B, cips_stream_t stream) {
+  if (!jobs || njobs <= 0 || njobs > MAXJOBS || B <= 0) return (int)hipErrorInvalidValue;
+  BwdJobs J;
+  int max_in = 0, max_out = 0;
+  long long max_nw = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const cips_modfc_bwd_job& j = jobs[i];
+    if (j.in_dim <= 0 || j.out_dim <= 0) return (int)hipErrorInvalidValue;
+    J.W[i] = j.weight; J.s[i] = j.s; J.demod[i] = j.demod; J.G[i] = j.gwb;
+    J.cbuf[i] = j.cbuf; J.dW[i] = j.dweight; J.ds[i] = j.ds;
+    J.in_dim[i] = j.in_dim; J.out_dim[i] = j.out_dim;
+    max_in = j.in_dim > max_in ? j.in_dim : max_in; max_out = j.out_dim > max_out ? j.out_dim : max_out;
+    const long long nw = (long long)j.in_dim * j.out_dim;
+    max_nw = nw > max_nw ? nw : max_nw;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(modfc_prep_bwd_c_batch_kernel, dim3((max_out + 31) / 32, B, njobs), dim3(256), 0, st, J);
+  hipLaunchKernelGGL(modfc_prep_bwd_w_batch_kernel, dim3((unsigned)((max_nw + 255) / 256), njobs), dim3(256), 0, st, J, B);
+  hipLaunchKernelGGL(modfc_prep_bwd_s_batch_kernel, dim3((unsigned)(((long long)B * max_in + 3) / 4), njobs), dim3(256), 0, st, J, B);
   return CIPS_CHECK_LAUNCH();
 }

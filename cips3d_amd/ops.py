@@ -531,6 +531,25 @@ def gemm_x3_km(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C):
     check(lib.cips_gemm_bf16x3_km(_ct.byref(d), _stream()), "cips_gemm_bf16x3_km")
 
 
+def gemm_x3_km_grouped(problems, M, N, K, lda, ldb, batch, strideA, strideB):
+    """problems: list of (A Planes, B Planes, C fp32) of one shape -> one launch when the library supports the shape
+    (256x256 tiles), else one K-major GEMM per problem."""
+    lib = _lib.load()
+    descs = (GemmX3Desc * len(problems))()
+    for d, (A, Bm, C) in zip(descs, problems):
+        d.A_hi, d.A_lo, d.B_hi, d.B_lo = _p(A.hi), _p(A.lo), _p(Bm.hi), _p(Bm.lo)
+        d.M, d.N, d.K, d.lda, d.ldb = M, N, K, lda, ldb
+        d.strideA, d.strideB, d.batch = strideA, strideB, batch
+        d.C, d.ldc, d.strideC = _p(C), N, M * N
+        d.slope = LRELU_SLOPE
+    rc = lib.cips_gemm_bf16x3_km_grouped(descs, len(problems), _stream())
+    if rc == 801:      # hipErrorNotSupported
+        for (A, Bm, C) in problems:
+            gemm_x3_km(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C)
+        return
+    check(rc, "cips_gemm_bf16x3_km_grouped")
+
+
 def split_planes(x, want_p=True, want_t=True):
     """x (B, rows, cols) fp32 -> Planes row-major (B,rows,cols) and transposed (B,cols,rows)."""
     lib = _lib.load()
@@ -555,6 +574,57 @@ def modfc_prep_x3(W, s, eps=1e-8):
     check(lib.cips_modfc_prep_x3(_p(W), _p(s), _p(wb.hi), _p(wb.lo), _p(wbt.hi), _p(wbt.lo), _p(demod), B, in_dim,
                                  out_dim, eps, _stream()), "cips_modfc_prep_x3")
     return wb, wbt, demod
+
+
+def modfc_prep_x3_batch(layers, eps=1e-8):
+    """layers: list of (W (in,out), s (B,in)) -> list of (wb Planes (B,in,out), wbt Planes (B,out,in), demod (B,out)),
+    all layers in two launches."""
+    lib = _lib.load()
+    from ._lib import ModfcPrepJob
+    mx = lib.cips_modfc_max_jobs()
+    out = []
+    for c0 in range(0, len(layers), mx):
+        chunk = layers[c0:c0 + mx]
+        jobs = (ModfcPrepJob * len(chunk))()
+        B = chunk[0][1].shape[0]
+        for j, (W, s) in zip(jobs, chunk):
+            in_dim, out_dim = W.shape
+            dev = W.device
+            wb = Planes.empty(B, in_dim, out_dim, device=dev)
+            wbt = Planes.empty(B, out_dim, in_dim, device=dev)
+            demod = torch.empty(B, out_dim, device=dev)
+            j.weight, j.s, j.demod = _p(W), _p(s), _p(demod)
+            j.wb_hi, j.wb_lo, j.wbt_hi, j.wbt_lo = _p(wb.hi), _p(wb.lo), _p(wbt.hi), _p(wbt.lo)
+            j.in_dim, j.out_dim = in_dim, out_dim
+            out.append((wb, wbt, demod))
+        check(lib.cips_modfc_prep_x3_batch(jobs, len(chunk), B, eps, _stream()), "cips_modfc_prep_x3_batch")
+    return out
+
+
+def modfc_prep_bwd_batch(layers):
+    """layers: list of (W, s, demod, gwb) -> list of (dW, ds), all layers in three launches."""
+    lib = _lib.load()
+    from ._lib import ModfcBwdJob
+    mx = lib.cips_modfc_max_jobs()
+    out = []
+    for c0 in range(0, len(layers), mx):
+        chunk = layers[c0:c0 + mx]
+        jobs = (ModfcBwdJob * len(chunk))()
+        B = chunk[0][1].shape[0]
+        keep = []
+        for j, (W, s, demod, gwb) in zip(jobs, chunk):
+            in_dim, out_dim = W.shape
+            dev = W.device
+            cbuf = torch.empty(B, out_dim, device=dev)
+            dW = torch.empty(in_dim, out_dim, device=dev)
+            ds = torch.empty(B, in_dim, device=dev)
+            j.weight, j.s, j.demod, j.gwb = _p(W), _p(s), _p(demod), _p(gwb)
+            j.cbuf, j.dweight, j.ds = _p(cbuf), _p(dW), _p(ds)
+            j.in_dim, j.out_dim = in_dim, out_dim
+            keep.append(cbuf)
+            out.append((dW, ds))
+        check(lib.cips_modfc_prep_bwd_batch(jobs, len(chunk), B, _stream()), "cips_modfc_prep_bwd_batch")
+    return out
 
 
 def torgb_fwd_x3(xp, w, b, rgb2d, accumulate):
@@ -601,14 +671,16 @@ class InrHeadX3Function(torch.autograd.Function):
         rgb = torch.empty(B, n, 3, device=dev)
         first_rgb = True
         saved = []
+        # modulate / demodulate / split every layer's weights up front, in one batch
+        prepped = modfc_prep_x3_batch([(W, s_) for (W1, s1, W2, s2) in blocks for (W, s_) in ((W1, s1), (W2, s2))])
         for k, (W1, s1, W2, s2) in enumerate(blocks):
             cin, cout = W1.shape
-            wb1, wbt1, d1 = modfc_prep_x3(W1, s1)
+            wb1, wbt1, d1 = prepped[2 * k]
             a1P = Planes.empty(B, n, cout, device=dev)
             a1T = Planes.empty(B, cout, n, device=dev) if want_t else None
             gemm_x3(xP, wbt1, n, cout, cin, cin, cin, B, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
                     act=1)
-            wb2, wbt2, d2 = modfc_prep_x3(W2, s2)
+            wb2, wbt2, d2 = prepped[2 * k + 1]
             skip = (k >= 4) and (cin == cout)
             oP = Planes.empty(B, n, cout, device=dev)
             oT = Planes.empty(B, cout, n, device=dev) if want_t else None
@@ -666,6 +738,7 @@ class InrHeadX3Function(torch.autograd.Function):
                 gT.hi.zero_(); gT.lo.zero_()
             Dout = torch.zeros(B, n, width, device=dev) if saved[k]["skip"] else None
         dx0 = None
+        pending = []      # (W, s, demod, dL/dWb) of every layer: their prep backward runs as one batch at the end
         for k in range(nblocks - 1, -1, -1):
             sv = saved[k]
             W1, s1, W2, s2 = blocks[k]
@@ -673,24 +746,24 @@ class InrHeadX3Function(torch.autograd.Function):
             if k >= 3:
                 dT, dtau = torgb_bwd_w_x3(sv["oP"], drgb2)
                 grads_rgb[2 * (k - 3)], grads_rgb[2 * (k - 3) + 1] = dT, dtau
-            # ---- mod2 ----
-            gwb2 = torch.empty(B, cout, cout, device=dev)
-            if km:
-                gemm_x3_km(sv["a1P"], gP, cout, cout, n, cout, cout, B, n * cout, n * cout, gwb2)
-            else:
-                gemm_x3(sv["a1T"], gT, cout, cout, n, n, n, B, cout * n, cout * n, C=gwb2)
-            dW2, ds2 = modfc_prep_bwd(W2, s2, sv["d2"], gwb2)
+            # ---- mod2: gradient through the gate of a1 ----
             g1P, g1T = Planes.empty(B, n, cout, device=dev), PT(cout)
             gemm_x3(gP, sv["wb2"], n, cout, cout, cout, cout, B, n * cout, cout * cout, P=g1P, T=g1T, ldt=n,
                     strideT=cout * n, mask=sv["a1m"])
-            # ---- mod1 ----
+            # ---- weight gradients of both layers: dWb2 = a1^T g, dWb1 = x^T g1 ----
+            gwb2 = torch.empty(B, cout, cout, device=dev)
             gwb1 = torch.empty(B, cin, cout, device=dev)
-            if km:
+            if km and cin == cout:
+                gemm_x3_km_grouped([(sv["a1P"], gP, gwb2), (sv["xP"], g1P, gwb1)], cout, cout, n, cout, cout, B,
+                                   n * cout, n * cout)
+            elif km:
+                gemm_x3_km(sv["a1P"], gP, cout, cout, n, cout, cout, B, n * cout, n * cout, gwb2)
                 gemm_x3_km(sv["xP"], g1P, cin, cout, n, cin, cout, B, n * cin, n * cout, gwb1)
             else:
+                gemm_x3(sv["a1T"], gT, cout, cout, n, n, n, B, cout * n, cout * n, C=gwb2)
                 gemm_x3(sv["xT"], g1T, cin, cout, n, n, n, B, cin * n, cout * n, C=gwb1)
-            dW1, ds1 = modfc_prep_bwd(W1, s1, sv["d1"], gwb1)
-            grads_blocks[k] = (dW1, ds1, dW2, ds2)
+            pending.append((W2, s2, sv["d2"], gwb2))
+            pending.append((W1, s1, sv["d1"], gwb1))
             if k == 0:
                 dx0 = torch.empty(B, n, cin, device=dev)
                 gemm_x3(g1P, sv["wb1"], n, cin, cout, cout, cout, B, n * cout, cin * cout, C=dx0)
@@ -703,6 +776,10 @@ class InrHeadX3Function(torch.autograd.Function):
                         rgb_g=drgb2 if k - 1 >= 3 else None, rgb_w=rgbp[2 * (k - 1 - 3)] if k - 1 >= 3 else None,
                         C_unmasked=newD, mask=pv["m2"])
                 Dout = newD
+        res = modfc_prep_bwd_batch(pending)          # pending order: block nblocks-1 (mod2, mod1), ..., block 0
+        for i, k in enumerate(range(nblocks - 1, -1, -1)):
+            (dW2, ds2), (dW1, ds1) = res[2 * i], res[2 * i + 1]
+            grads_blocks[k] = (dW1, ds1, dW2, ds2)
         flat = [None, dx0]
         for gb in grads_blocks:
             flat.extend(gb)

@@ -230,6 +230,10 @@ int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream);
  * env CIPS_X3_WIDE), 2 = 256x256 tiles whenever the epilogue is supported (tests). */
 void cips_gemm_bf16x3_set_wide(int mode);
 int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t stream);
+/* Up to four K-major problems of identical shape (M, N, K, batch, leading dimensions, strides) in one launch of
+ * 256x256 tiles; only the operand planes and C differ.  hipErrorNotSupported (801) when the shapes do not qualify:
+ * issue them one by one with cips_gemm_bf16x3_km then. */
+int cips_gemm_bf16x3_km_grouped(const cips_gemm_x3_desc* descs, int ngroups, cips_stream_t stream);
 
 /* fp32 (rows, cols) [ldx] -> split bf16 planes row-major [rows][ldp] and/or transposed [cols][ldt]. */
 int cips_split_planes(const float* x, void* p_hi, void* p_lo, void* t_hi, void* t_lo, int rows, int cols,
@@ -254,6 +258,23 @@ int cips_modfc_prep_x3(const float* weight, const float* s, void* wb_hi, void* w
 int cips_modfc_prep_bwd(const float* weight, const float* s, const float* demod, const float* gwb,
                         float* cbuf, float* dweight, float* ds, int B, int in_dim, int out_dim,
                         cips_stream_t stream);
+
+/* Batched forms: all modulated-FC layers of the CIPS head in one call (njobs <= cips_modfc_max_jobs()); same
+ * per-layer contracts as cips_modfc_prep_x3 / cips_modfc_prep_bwd, one shared batch size B. */
+typedef struct cips_modfc_prep_job {
+  const float* weight; const float* s;        /* (in,out), (B,in) */
+  void *wb_hi, *wb_lo, *wbt_hi, *wbt_lo;      /* (B,in,out) and (B,out,in) bf16 planes */
+  float* demod;                               /* (B,out) */
+  int in_dim, out_dim;
+} cips_modfc_prep_job;
+typedef struct cips_modfc_bwd_job {
+  const float* weight; const float* s; const float* demod; const float* gwb;   /* gwb (B,in,out) = dL/d wb */
+  float *cbuf, *dweight, *ds;                 /* scratch (B,out); outputs (in,out), (B,in) */
+  int in_dim, out_dim;
+} cips_modfc_bwd_job;
+int cips_modfc_max_jobs(void);
+int cips_modfc_prep_x3_batch(const cips_modfc_prep_job* jobs, int njobs, int B, float eps, cips_stream_t stream);
+int cips_modfc_prep_bwd_batch(const cips_modfc_bwd_job* jobs, int njobs, int B, cips_stream_t stream);
 
 /* ToRGB (generator.py:983-1006): rgb (M,3) (+)= x (M,K) @ w^T (3,K) + bias.
  * accumulate != 0: rgb += ...  */

@@ -350,6 +350,52 @@ def test_gemm_bf16x3_wide(M, N, K, batch, flavour):
         lib.cips_gemm_bf16x3_set_wide(-1)
 
 
+@pytest.mark.parametrize("M,N,K,batch", [(512, 512, 4096, 32), (512, 512, 2048, 3), (256, 256, 64, 2), (520, 264, 96, 2),
+                                         (512, 768, 1024, 40)])
+def test_gemm_bf16x3_kmajor_wide(M, N, K, batch):
+    """256x256-tile K-major form (forced on), single problem; run twice: the result must be bit-identical."""
+    from cips3d_amd import ops, _lib
+    lib = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K + batch)
+    A = torch.randn(batch, K, M, generator=g); B = torch.randn(batch, K, N, generator=g)
+    Ap = ops.Planes(*[t.to(d) for t in _planes(A)]); Bp = ops.Planes(*[t.to(d) for t in _planes(B)])
+    ref = torch.bmm(A.to(d).double().transpose(1, 2), B.to(d).double())
+    lib.cips_gemm_bf16x3_set_wide(2)
+    try:
+        C = torch.full((batch, M, N), float("nan"), device=d)
+        ops.gemm_x3_km(Ap, Bp, M, N, K, M, N, batch, K * M, K * N, C)
+        C2 = torch.full((batch, M, N), float("nan"), device=d)
+        ops.gemm_x3_km(Ap, Bp, M, N, K, M, N, batch, K * M, K * N, C2)
+        torch.cuda.synchronize()
+    finally:
+        lib.cips_gemm_bf16x3_set_wide(-1)
+    e = rel_err(C, ref)
+    print(f"bf16x3 k-major wide {M}x{N}x{K}x{batch}: rel err vs fp64 {e:.3e}")
+    assert torch.isfinite(C).all() and e < 3e-5
+    assert torch.equal(C, C2)
+
+
+def test_gemm_bf16x3_kmajor_grouped():
+    """two weight-gradient problems of one shape in one launch (the head's dWb2 / dWb1 pair), and the fallback for a
+    shape the grouped kernel refuses (N < 256)"""
+    from cips3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(77)
+    for (M, N, K, batch) in [(512, 512, 1024, 32), (512, 128, 256, 4)]:
+        probs, refs = [], []
+        for _ in range(2):
+            A = torch.randn(batch, K, M, generator=g); B = torch.randn(batch, K, N, generator=g)
+            Ap = ops.Planes(*[t.to(d) for t in _planes(A)]); Bp = ops.Planes(*[t.to(d) for t in _planes(B)])
+            C = torch.full((batch, M, N), float("nan"), device=d)
+            probs.append((Ap, Bp, C))
+            refs.append(torch.bmm(A.to(d).double().transpose(1, 2), B.to(d).double()))
+        ops.gemm_x3_km_grouped(probs, M, N, K, M, N, batch, K * M, K * N)
+        torch.cuda.synchronize()
+        for (_, _, C), ref in zip(probs, refs):
+            assert torch.isfinite(C).all() and rel_err(C, ref) < 3e-5
+
+
 def test_gemm_bf16x3_epilogues():
     from cips3d_amd import ops
     d = dev()
