@@ -62,10 +62,9 @@ def gemm_roofline(dev, b, n, mode):
     if mode == "bf16x3":
         xP, _ = ops.split_planes(x, want_t=False)
         wP, _ = ops.split_planes(w, want_t=False)
-        oP, oT = ops.Planes.empty(b, n, 512, device=dev), ops.Planes.empty(b, 512, n, device=dev)
-        fn = lambda: ops.gemm_x3(xP, wP, n, 512, 512, 512, 512, b, n * 512, 512 * 512, P=oP, T=oT, ldt=n,
-                                 strideT=512 * n, act=1)
-        name, peak = "gemm_bf16x3_kernel<4> (modfc 512x512 fwd: lrelu + split planes in both orientations)", \
+        oP = ops.Planes.empty(b, n, 512, device=dev)
+        fn = lambda: ops.gemm_x3(xP, wP, n, 512, 512, 512, 512, b, n * 512, 512 * 512, P=oP, act=1)
+        name, peak = "gemm_bf16x3_wide_kernel<0,0,0> (modfc 512x512 fwd: 256x256 tiles, lrelu + split-bf16 planes out)", \
             BF16_MFMA_PEAK_TFLOPS / 3.0
     else:
         out = torch.empty(b, n, 512, device=dev)

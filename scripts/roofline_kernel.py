@@ -8,7 +8,7 @@ d = torch.device("cuda:0")
 b, n = 32, 4096
 x = torch.randn(b, n, 512, device=d); w = torch.randn(b, 512, 512, device=d) * 0.04
 xP, _ = ops.split_planes(x, want_t=False); wP, _ = ops.split_planes(w, want_t=False)
-oP, oT = ops.Planes.empty(b, n, 512, device=d), ops.Planes.empty(b, 512, n, device=d)
+oP = ops.Planes.empty(b, n, 512, device=d)
 for _ in range(6):
-    ops.gemm_x3(xP, wP, n, 512, 512, 512, 512, b, n * 512, 512 * 512, P=oP, T=oT, ldt=n, strideT=512 * n, act=1)
+    ops.gemm_x3(xP, wP, n, 512, 512, 512, 512, b, n * 512, 512 * 512, P=oP, act=1)
 torch.cuda.synchronize()
