@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
     ap.add_argument("--inr-mode", default=None, choices=["bf16x3", "f32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph of the step")
     return ap.parse_args()
 
 
@@ -156,13 +157,40 @@ def main():
     G0 = torch.randn(b, 3, img, img, device=dev) / (b * 3 * img * img)
     params = list(G.parameters())
 
-    def step():
+    def fwd_bwd():
         zs = G.get_zs(b)
         for p in params:
             p.grad = None
         imgs, _ = G(zs, img_size=img, num_steps=S, hierarchical_sample=a.hier, nerf_noise=0.,
                     return_aux_img=False, grad_points=None, forward_points=None, **G_KW)
         imgs.backward(G0)
+
+    graph = None
+    if not a.no_graph:
+        # ~570 kernel launches per step: capture latents (graph-safe Philox RNG: fresh draws per replay) + forward +
+        # backward once, replay per step; the gradient all-reduce stays outside the graph.  Eager on any capture error.
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    fwd_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fwd_bwd()
+        except Exception as e:                      # noqa: BLE001
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    use_graph = [graph is not None]
+
+    def step():
+        if use_graph[0]:
+            graph.replay()
+        else:
+            fwd_bwd()
         if world > 1:
             allreduce_grads(params)
 
@@ -192,8 +220,11 @@ def main():
     value = world * b * a.steps / dt
     exact = None
     if mode == "bf16x3" and not a.no_exact:
-        ops.INR_MODE = "f32"          # same step with the INR GEMMs on exact fp32 MFMA, for reference
+        ops.INR_MODE = "f32"          # same step with the INR GEMMs on exact fp32 MFMA, for reference (eager launches)
+        was = use_graph[0]
+        use_graph[0] = False
         dte = timed(max(2, a.steps // 2), 1)
+        use_graph[0] = was
         ops.INR_MODE = mode
         ne = max(2, a.steps // 2)
         exact = {"value": round(world * b * ne / dte, 2), "ms_per_step": round(dte / ne * 1e3, 3),
@@ -207,7 +238,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"FFHQ r{img}, {E} SIREN evals/ray (num_steps {S}, hierarchical {a.hier}), "
                                f"batch {b}/GPU, G fwd+bwd, all 9 CIPS blocks",
-                   "global_batch": world * b, "parallelism": f"dp{world}", "inr_gemm_mode": mode},
+                   "global_batch": world * b, "parallelism": f"dp{world}", "inr_gemm_mode": mode,
+                   "launch": "hipGraph replay" if use_graph[0] else "eager"},
     }
     if exact:
         line["exact_f32"] = exact

@@ -318,7 +318,8 @@ def create_cam2world_matrix(forward_vector, origin, up_vector=None):
     device = origin.device
     forward_vector = _normalize(forward_vector)
     if up_vector is None:
-        up_vector = torch.tensor([0, 1, 0], dtype=torch.float, device=device).expand_as(forward_vector)
+        # (0, 1, 0) built on the device — no host-to-device copy, so the step can be captured in a hipGraph
+        up_vector = (torch.arange(3, device=device) == 1).to(torch.float).expand_as(forward_vector)
     left_vector = _normalize(torch.cross(up_vector, forward_vector, dim=-1))
     up_vector = _normalize(torch.cross(forward_vector, left_vector, dim=-1))
     rot = torch.eye(4, device=device).unsqueeze(0).repeat(forward_vector.shape[0], 1, 1)

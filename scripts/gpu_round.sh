@@ -17,7 +17,7 @@ tail -2 gpurun_out/smoke.log
 timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/bench.log 2>&1; echo "bench exit $?" | tee -a gpurun_out/summary.txt
 tail -3 gpurun_out/bench.log
 if [ -n "$PROFILE" ]; then
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o r1 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/gpurun_out/prof.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o r1 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $OLDPWD/gpurun_out/prof.log 2>&1)
   echo "prof exit $?" | tee -a gpurun_out/summary.txt
   find gpurun_out/prof -name "*kernel_stats*" | head
 fi

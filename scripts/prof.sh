@@ -5,7 +5,7 @@ TAG=${1:-run}; shift
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 REPO=$PWD
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o p -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-exact "$@" > $REPO/gpurun_out/prof_$TAG.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o p -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-exact --no-graph "$@" > $REPO/gpurun_out/prof_$TAG.log 2>&1)
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 python - "$f" "$TAG" <<'PY'
 import csv, sys
