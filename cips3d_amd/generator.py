@@ -401,8 +401,13 @@ class GeneratorNerfINR(nn.Module):
     def _render(self, style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean,
                 v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise, white_back, last_back,
                 return_aux_img, forward_points=None, camera_pos=None, camera_lookup=None, up_vector=None,
-                nerf_grad=True, rand_override=None):
-        """whole_grad_forward + points_forward (generator.py:1378-1534, 1659-1762) on the HIP path.
+                nerf_grad=True, rand_override=None, grad_points=None):
+        """whole_grad_forward / part_grad_forward + points_forward (generator.py:1378-1657, 1659-1762) on the HIP path.
+
+        `grad_points` (a count of pixels < img_size^2): part_grad_forward — after the ray set-up a `randperm(n)`
+        splits the pixels of every image into a subset rendered with gradients and a rest rendered under
+        no_grad (each with its own noise draws, in that order), and the two are scattered back (int64
+        bookkeeping of comm_utils.py:240-282).
 
         Random tensors are drawn with the reference's calls, shapes and order
         so that a same-device, same-seed run consumes the generator identically; `rand_override`
@@ -442,7 +447,14 @@ class GeneratorNerfINR(nn.Module):
                 ph = draw('phi', torch.randn, (bs, 1)) * v_stddev + v_mean
             return th, ph
 
-        if not staged:
+        part = grad_points is not None and grad_points < n
+        if part and staged:
+            raise NotImplementedError("grad_points together with forward_points")
+        if part:
+            jitter = draw('jitter', torch.rand, (b, n, S, 1))
+            theta, phi = draw_cam(b) if need_cam else (None, None)
+            noise_c = u = noise_f = None          # drawn per pixel subset below, after the randperm
+        elif not staged:
             jitter = draw('jitter', torch.rand, (b, n, S, 1))
             theta, phi = draw_cam(b) if need_cam else (None, None)
             noise_c = draw('noise_c', torch.randn, (b, n, S, 1)) if hierarchical_sample else None
@@ -489,34 +501,64 @@ class GeneratorNerfINR(nn.Module):
             ray_origins = cam2world[:, :3, 3].contiguous()       # every ray starts at the camera
 
         nerf_styles = self._nerf_styles(style_dict)
-        ctx_nerf = torch.enable_grad() if nerf_grad else torch.no_grad()
-        with ctx_nerf:
-            feat_c, sig_c = self.siren.evaluate(points.view(b, n * S, 3), nerf_styles)
-            feat_c = feat_c.view(b * n, S, 32)
-            sig_c = sig_c.view(b * n, S)
-            z_c = z_vals.view(b * n, S)
-            if hierarchical_sample:
-                with torch.no_grad():
-                    fine_z, fine_pts = ops.resample_fwd(
-                        sig_c, z_c, noise_c.reshape(b * n, S) if nerf_noise != 0 else None, nerf_noise,
-                        u, ray_origins, dirs.view(b * n, 3), b, n, S, clamp)
-                feat_f, sig_f = self.siren.evaluate(fine_pts.view(b, n * S, 3), nerf_styles)
-                feat_f = feat_f.view(b * n, S, 32)
-                sig_f = sig_f.view(b * n, S)
-            else:
-                feat_f = sig_f = fine_z = None
-            pixels_fea, depth, weights, order, zsorted = ops.CompositeFunction.apply(
-                feat_c, sig_c, z_c, feat_f, sig_f, fine_z,
-                noise_f.reshape(b * n, E) if nerf_noise != 0 else None, nerf_noise, clamp, flags)
-            pixels_fea = pixels_fea.view(b, n, 32)
-            if return_aux_img:
-                aux_img = torch.tanh(_ToRGBFunction.apply(pixels_fea, self.aux_to_rbg[0].weight,
+        def pipeline(points, z_vals, dirs, n, noise_c, u, noise_f, nerf_grad):
+            """points_forward (generator.py:1659-1762) for n rays per image: -> inr rgb (b,n,3), aux rgb or None"""
+            ctx_nerf = torch.enable_grad() if nerf_grad else torch.no_grad()
+            with ctx_nerf:
+                feat_c, sig_c = self.siren.evaluate(points.reshape(b, n * S, 3), nerf_styles)
+                feat_c = feat_c.view(b * n, S, 32)
+                sig_c = sig_c.view(b * n, S)
+                z_c = z_vals.reshape(b * n, S)
+                if hierarchical_sample:
+                    with torch.no_grad():
+                        fine_z, fine_pts = ops.resample_fwd(
+                            sig_c, z_c, noise_c.reshape(b * n, S) if nerf_noise != 0 else None, nerf_noise,
+                            u, ray_origins, dirs.reshape(b * n, 3), b, n, S, clamp)
+                    feat_f, sig_f = self.siren.evaluate(fine_pts.view(b, n * S, 3), nerf_styles)
+                    feat_f = feat_f.view(b * n, S, 32)
+                    sig_f = sig_f.view(b * n, S)
+                else:
+                    feat_f = sig_f = fine_z = None
+                pixels_fea, depth, weights, order, zsorted = ops.CompositeFunction.apply(
+                    feat_c, sig_c, z_c, feat_f, sig_f, fine_z,
+                    noise_f.reshape(b * n, E) if nerf_noise != 0 else None, nerf_noise, clamp, flags)
+                pixels_fea = pixels_fea.view(b, n, 32)
+                if return_aux_img:
+                    aux = torch.tanh(_ToRGBFunction.apply(pixels_fea, self.aux_to_rbg[0].weight,
                                                           self.aux_to_rbg[0].bias))
-            else:
-                aux_img = None
-        if not nerf_grad:
-            pixels_fea = pixels_fea.detach()
-        inr_img = self.inr_net(pixels_fea, style_dict)
+                else:
+                    aux = None
+            if not nerf_grad:
+                pixels_fea = pixels_fea.detach()
+            return self.inr_net(pixels_fea, style_dict), aux
+
+        if not part:
+            inr_img, aux_img = pipeline(points, z_vals, dirs, n, noise_c, u, noise_f, nerf_grad)
+        else:
+            # ---- part_grad_forward (generator.py:1536-1657) ----
+            rand_idx = ro['rand_idx'].to(device) if 'rand_idx' in ro else torch.randperm(n, device=device)
+            idx_grad, idx_rest = rand_idx[:grad_points], rand_idx[grad_points:]
+            pts4, z3, dirs3 = points.view(b, n, S, 3), z_vals.view(b, n, S), dirs.view(b, n, 3)
+
+            def subset(idx, tag, with_grad):
+                m = idx.numel()
+                nc = draw('noise_c' + tag, torch.randn, (b, m, S, 1)) if hierarchical_sample else None
+                uu = draw('u' + tag, torch.rand, (b * m, S)) if hierarchical_sample else None
+                nf = draw('noise_f' + tag, torch.randn, (b, m, E, 1))
+                return pipeline(pts4.index_select(1, idx).contiguous(), z3.index_select(1, idx).contiguous(),
+                                dirs3.index_select(1, idx).contiguous(), m, nc, uu, nf, with_grad)
+
+            inr_g, aux_g = subset(idx_grad, '_grad', nerf_grad)
+            with torch.no_grad():
+                inr_r, aux_r = subset(idx_rest, '_rest', False)
+
+            def scatter(pg, pr):       # comm_utils.scatter_points: rows idx_grad <- pg (with grad), idx_rest <- pr
+                out = torch.zeros(b, n, pg.shape[-1], device=device, dtype=pg.dtype)
+                out = out.index_copy(1, idx_grad, pg)
+                return out.index_copy(1, idx_rest, pr)
+
+            inr_img = scatter(inr_g, inr_r)
+            aux_img = scatter(aux_g, aux_r) if return_aux_img else None
 
         inr_img = inr_img.view(b, H, W, 3).permute(0, 3, 1, 2)
         inr_img = self.filters(inr_img)
@@ -539,18 +581,15 @@ class GeneratorNerfINR(nn.Module):
             avg_styles = self.generate_avg_frequencies(device=self.device)
             style_dict = self.get_truncated_freq_phase(raw_style_dict=style_dict, avg_style_dict=avg_styles,
                                                        raw_lambda=psi)
-        if grad_points is not None and grad_points < img_size ** 2:
-            raise NotImplementedError(
-                "part_grad_forward (random pixel subset with gradients, generator.py:1536-1657) is only "
-                "reachable for img_size > 256 with the shipped configs and is not built yet")
+        part = grad_points if (grad_points is not None and grad_points < img_size ** 2) else None
         return self._forward_styles(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                                     h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise,
                                     white_back, last_back, return_aux_img, forward_points,
-                                    rand_override=kwargs.get('rand_override'))
+                                    rand_override=kwargs.get('rand_override'), grad_points=part)
 
     def _forward_styles(self, style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                         h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise, white_back,
-                        last_back, return_aux_img, forward_points, rand_override=None, **cam):
+                        last_back, return_aux_img, forward_points, rand_override=None, grad_points=None, **cam):
         if forward_points is not None:
             with torch.no_grad():
                 return self._render(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
@@ -559,7 +598,7 @@ class GeneratorNerfINR(nn.Module):
                                     rand_override=rand_override, **cam)
         return self._render(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean,
                             v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise, white_back, last_back,
-                            return_aux_img, rand_override=rand_override, **cam)
+                            return_aux_img, rand_override=rand_override, grad_points=grad_points, **cam)
 
     def forward_camera_pos_and_lookup(self, zs, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                                       h_mean, v_mean, hierarchical_sample, camera_pos, camera_lookup, psi=1,
@@ -572,12 +611,11 @@ class GeneratorNerfINR(nn.Module):
             avg_styles = self.generate_avg_frequencies(device=self.device)
             style_dict = self.get_truncated_freq_phase(raw_style_dict=style_dict, avg_style_dict=avg_styles,
                                                        raw_lambda=psi)
-        if grad_points is not None and grad_points < img_size ** 2:
-            raise NotImplementedError("part_grad_forward is not built yet")
+        part = grad_points if (grad_points is not None and grad_points < img_size ** 2) else None
         return self._forward_styles(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                                     h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise,
                                     white_back, last_back, return_aux_img, forward_points,
-                                    rand_override=kwargs.get('rand_override'),
+                                    rand_override=kwargs.get('rand_override'), grad_points=part,
                                     camera_pos=camera_pos, camera_lookup=camera_lookup, up_vector=up_vector)
 
 

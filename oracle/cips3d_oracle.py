@@ -228,10 +228,45 @@ def inr_head(sd, fea, w_inr, prefix="inr_net.", return_all=False):
 # ----------------------------------------------------------------------------------------
 # generator.forward — exp/cips3d/models/generator.py:1256-1370, 1378-1534, 1659-1762
 # ----------------------------------------------------------------------------------------
+def _points_forward(sd, w_nerf, w_inr, pts, z, origins, dirs, b, n, S, hierarchical_sample, nerf_noise, clamp_mode,
+                    noise_c, u, noise_f, return_aux_img, nerf_nograd, keep=None):
+    """points_forward (exp/cips3d/models/generator.py:1659-1762) for n rays per image:
+    -> inr rgb (b,n,3), aux rgb (b,n,3) or None"""
+    ctx = torch.no_grad() if nerf_nograd else torch.enable_grad()
+    with ctx:
+        coarse = siren(sd, pts.reshape(b, n * S, 3), w_nerf).reshape(b, n, S, 33)
+    if hierarchical_sample:
+        with torch.no_grad():
+            fp, fz, book = fine_points(coarse, z, noise_c, nerf_noise, u, origins, dirs, clamp_mode)
+        with ctx:
+            fine = siren(sd, fp, w_nerf).reshape(b, n, S, 33)
+        all_o = torch.cat([fine, coarse], dim=-2)
+        all_z = torch.cat([fz, z], dim=-2)
+        _, idx = torch.sort(all_z, dim=-2)
+        all_z = torch.gather(all_z, -2, idx)
+        all_o = torch.gather(all_o, -2, idx.expand(-1, -1, -1, all_o.shape[-1]))
+    else:
+        all_o, all_z, idx, fz, fp, book, fine = coarse, z, None, None, None, None, None
+    fea, depth, weights = integrate(all_o, all_z, noise_f, nerf_noise, clamp_mode=clamp_mode)
+    inr = inr_head(sd, fea, w_inr)
+    aux = None
+    if return_aux_img:
+        with ctx:
+            aux = torch.tanh(F.linear(fea, sd["aux_to_rbg.0.weight"], sd["aux_to_rbg.0.bias"]))
+    if keep is not None:
+        keep.update(coarse=coarse, fine=fine, fine_z=fz, fine_points=fp, book=book, sort_idx=idx,
+                    pixels_fea=fea, depth=depth, weights=weights)
+    return inr, aux
+
+
 def generator_forward(sd, zs, rand, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                       hierarchical_sample, nerf_noise=0., clamp_mode="relu", return_aux_img=False,
-                      freeze_nerf=False, keep=False):
-    """Returns dict(imgs, pitch_yaw, + intermediates when keep).  `sd` values may require grad."""
+                      freeze_nerf=False, keep=False, grad_points=None):
+    """Returns dict(imgs, pitch_yaw, + intermediates when keep).  `sd` values may require grad.
+
+    grad_points (< img_size^2): part_grad_forward (generator.py:1536-1657) — `rand["rand_idx"]` (the randperm)
+    splits the pixels into a subset rendered with gradients (draws rand["noise_c_grad"/"u_grad"/"noise_f_grad"])
+    and the rest rendered under no_grad (rand["..._rest"]), scattered back like comm_utils.py:240-258."""
     b = zs["z_nerf"].shape[0]
     S = num_steps
     n = img_size * img_size
@@ -244,38 +279,45 @@ def generator_forward(sd, zs, rand, img_size, fov, ray_start, ray_end, num_steps
     with torch.no_grad():
         r = rays(b, img_size, fov, ray_start, ray_end, S, rand["jitter"], rand["theta"], rand["phi"],
                  h_stddev, v_stddev)
-    pts = r["points"].reshape(b, n * S, 3)
     out = {}
-    ctx = torch.no_grad() if freeze_nerf else torch.enable_grad()
-    with ctx:
-        coarse = siren(sd, pts, w_nerf).reshape(b, n, S, 33)
-    if hierarchical_sample:
-        with torch.no_grad():
-            fp, fz, book = fine_points(coarse, r["z"], rand["noise_c"], nerf_noise, rand["u"], r["origins"],
-                                       r["dirs"], clamp_mode)
-        with ctx:
-            fine = siren(sd, fp, w_nerf).reshape(b, n, S, 33)
-        all_o = torch.cat([fine, coarse], dim=-2)
-        all_z = torch.cat([fz, r["z"]], dim=-2)
-        _, idx = torch.sort(all_z, dim=-2)
-        all_z = torch.gather(all_z, -2, idx)
-        all_o = torch.gather(all_o, -2, idx.expand(-1, -1, -1, all_o.shape[-1]))
+    kept = {} if keep else None
+    if grad_points is None or grad_points >= n:
+        inr, aux = _points_forward(sd, w_nerf, w_inr, r["points"], r["z"], r["origins"], r["dirs"], b, n, S,
+                                   hierarchical_sample, nerf_noise, clamp_mode, rand.get("noise_c"), rand.get("u"),
+                                   rand["noise_f"], return_aux_img, freeze_nerf, kept)
     else:
-        all_o, all_z, idx, fz, fp, book, fine = coarse, r["z"], None, None, None, None, None
-    fea, depth, weights = integrate(all_o, all_z, rand["noise_f"], nerf_noise, clamp_mode=clamp_mode)
-    inr = inr_head(sd, fea, w_inr)
+        ridx = rand["rand_idx"]
+        parts = []
+        for tag, idx, nograd in (("_grad", ridx[:grad_points], freeze_nerf), ("_rest", ridx[grad_points:], True)):
+            m = idx.numel()
+            sub = lambda t: t.index_select(1, idx)
+            def run():
+                return _points_forward(sd, w_nerf, w_inr, sub(r["points"].reshape(b, n, S, 3)), sub(r["z"]),
+                                       sub(r["origins"]), sub(r["dirs"]), b, m, S, hierarchical_sample, nerf_noise,
+                                       clamp_mode, rand.get("noise_c" + tag), rand.get("u" + tag),
+                                       rand["noise_f" + tag], return_aux_img, nograd)
+            if tag == "_rest":
+                with torch.no_grad():
+                    parts.append((idx, run()))
+            else:
+                parts.append((idx, run()))
+
+        def scatter(k):
+            o = torch.zeros(b, n, 3)
+            for idx, res in parts:
+                o = o.index_copy(1, idx, res[k])
+            return o
+        inr = scatter(0)
+        aux = scatter(1) if return_aux_img else None
     imgs = inr.reshape(b, img_size, img_size, 3).permute(0, 3, 1, 2)
     pitch_yaw = torch.cat([r["pitch"], r["yaw"]], -1)
     if return_aux_img:
-        with ctx:
-            aux = torch.tanh(F.linear(fea, sd["aux_to_rbg.0.weight"], sd["aux_to_rbg.0.bias"]))
         imgs = torch.cat([imgs, aux.reshape(b, img_size, img_size, 3).permute(0, 3, 1, 2)])
         pitch_yaw = torch.cat([pitch_yaw, pitch_yaw])
     out.update(imgs=imgs, pitch_yaw=pitch_yaw)
     if keep:
-        out.update(w_nerf=w_nerf, w_inr=w_inr, points=r["points"], z=r["z"], dirs=r["dirs"], origins=r["origins"],
-                   coarse=coarse, fine=fine, fine_z=fz, fine_points=fp, book=book, sort_idx=idx,
-                   pixels_fea=fea, depth=depth, weights=weights)
+        out.update(w_nerf=w_nerf, w_inr=w_inr, points=r["points"], z=r["z"], dirs=r["dirs"], origins=r["origins"])
+        out.update(kept)
     return out
 
 

@@ -41,11 +41,15 @@ def d_cfg():
 
 
 class Capture:
-    """Record torch.rand / torch.randn results in call order."""
+    """Record torch.rand / torch.randn / torch.randperm results in call order."""
 
     def __enter__(self):
         self.draws = []
-        self._rand, self._randn = torch.rand, torch.randn
+        self._rand, self._randn, self._randperm = torch.rand, torch.randn, torch.randperm
+
+        def randperm(*a, **k):
+            t = self._randperm(*a, **k); self.draws.append(("randperm", t.clone())); return t
+        torch.randperm = randperm
 
         def rand(*a, **k):
             t = self._rand(*a, **k); self.draws.append(("rand", t.clone())); return t
@@ -57,7 +61,7 @@ class Capture:
         return self
 
     def __exit__(self, *exc):
-        torch.rand, torch.randn = self._rand, self._randn
+        torch.rand, torch.randn, torch.randperm = self._rand, self._randn, self._randperm
 
 
 def checksums(sd):
@@ -75,6 +79,34 @@ def grad_digest(named_params, stride=97):
                        sample=g[::stride].clone() if g.numel() > 70000 else g.clone(),
                        stride=stride if g.numel() > 70000 else 1)
     return d
+
+
+def make_generator_part_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, grad_points):
+    """part_grad_forward (generator.py:1536-1657): gradients through a random pixel subset only."""
+    torch.manual_seed(seed)
+    G = ref_gen.GeneratorNerfINR(**g_cfg(), device="cpu")
+    sums = checksums(G.state_dict())
+    torch.manual_seed(seed + 1)
+    zs = G.get_zs(b)
+    kw = dict(fov=12, ray_start=0.88, ray_end=1.12, num_steps=S, h_stddev=0.3, v_stddev=0.155,
+              hierarchical_sample=hier, psi=1., sample_dist="gaussian")
+    with Capture() as cap:
+        imgs, pitch_yaw = G(zs, img_size=img_size, nerf_noise=nerf_noise, return_aux_img=aux,
+                            grad_points=grad_points, forward_points=None, **kw)
+    per = (["noise_c", "u"] if hier else []) + ["noise_f"]
+    names = ["jitter", "theta", "phi", "rand_idx"] + [n + "_grad" for n in per] + [n + "_rest" for n in per]
+    assert len(cap.draws) == len(names), (len(cap.draws), names)
+    rand = {n: t for n, (_, t) in zip(names, cap.draws)}
+    torch.manual_seed(4321)
+    G0 = torch.randn_like(imgs) / imgs.numel()
+    (imgs * G0).sum().backward()
+    fix = dict(tag=tag, seed=seed, b=b, img_size=img_size, S=S, hier=hier, nerf_noise=nerf_noise, aux=aux,
+               freeze=False, grad_points=grad_points, G_kwargs=kw, state_checksums=sums,
+               zs={k: v.clone() for k, v in zs.items()}, rand=rand, G0=G0, imgs=imgs.detach().clone(),
+               pitch_yaw=pitch_yaw.detach().clone(), grads=grad_digest(G.named_parameters()))
+    path = os.path.join(OUT, f"{tag}.pt")
+    torch.save(fix, path)
+    print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "imgs", tuple(imgs.shape))
 
 
 def make_generator_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, freeze=False):
@@ -181,6 +213,8 @@ if __name__ == "__main__":
     make_generator_case("g_r8_flat_noise", seed=0, b=2, img_size=8, S=4, hier=False, nerf_noise=0.3, aux=False)
     make_generator_case("g_r8_hier_noise", seed=5, b=1, img_size=8, S=5, hier=True, nerf_noise=0.25, aux=False)
     make_generator_case("g_r8_freeze", seed=3, b=2, img_size=8, S=4, hier=True, nerf_noise=0.0, aux=False, freeze=True)
+    make_generator_part_case("g_r16_part", seed=21, b=2, img_size=16, S=5, hier=True, nerf_noise=0.2, aux=True,
+                             grad_points=96)
     make_discriminator_case("d_r16", seed=11, b=2, size=16, alpha=1.0, use_aux=False)
     make_discriminator_case("d_r16_aux_alpha", seed=12, b=2, size=16, alpha=0.5, use_aux=True)
     make_op_cases()

@@ -8,7 +8,7 @@ from oracle import cips3d_oracle as orc
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze"]
+CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze", "g_r16_part"]   # _part: part_grad_forward
 
 
 @pytest.fixture(params=["f32", "bf16x3"])
@@ -30,7 +30,7 @@ def test_generator_matches_reference_golden(tag, inr_mode):
     zs = {k: v.to(d) for k, v in fix["zs"].items()}
     rand = {k: v.to(d) for k, v in fix["rand"].items()}
     imgs, pitch_yaw = G(zs, img_size=fix["img_size"], nerf_noise=fix["nerf_noise"], return_aux_img=fix["aux"],
-                        grad_points=None, forward_points=None, rand_override=rand, **fix["G_kwargs"])
+                        grad_points=fix.get("grad_points"), forward_points=None, rand_override=rand, **fix["G_kwargs"])
     torch.cuda.synchronize()
     assert imgs.shape == fix["imgs"].shape
     e = max_rel(imgs, fix["imgs"])
@@ -50,7 +50,8 @@ def test_generator_matches_reference_golden(tag, inr_mode):
         o64 = orc.generator_forward(dict(G64.named_parameters()), dbl(fix["zs"]), dbl(fix["rand"]), fix["img_size"],
                                     kw["fov"], kw["ray_start"], kw["ray_end"], kw["num_steps"], kw["h_stddev"],
                                     kw["v_stddev"], kw["hierarchical_sample"], nerf_noise=fix["nerf_noise"],
-                                    return_aux_img=fix["aux"], freeze_nerf=fix["freeze"])
+                                    return_aux_img=fix["aux"], freeze_nerf=fix["freeze"],
+                                    grad_points=fix.get("grad_points"))
     finally:
         torch.set_default_dtype(torch.float32)
     (o64["imgs"] * fix["G0"].double()).sum().backward()
