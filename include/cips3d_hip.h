@@ -325,6 +325,24 @@ int cips_im2col(const float* x, float* col, int B, int C, int H, int W,
 int cips_col2im(const float* col, float* dx, int B, int C, int H, int W,
                 int kh, int kw, int stride, int pad, cips_stream_t stream);
 
+/* ------------------------------------------------------------------ */
+/* Training-step tail: gradient-norm clip + Adam + EMA over all tensors of one optimiser,
+ * two launches.  Replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step + EMA.update
+ * (exp/cips3d/scripts/train.py:420-491, exp/comm/comm_model_utils.py:97-118).
+ * table_dev: device array of tensors; grad == NULL: no Adam update (parameter unused this step), ema == NULL: no EMA.
+ * The tensors are walked in chunks of cips_opt_chunk() elements: chunk_tensor_dev[c] = tensor index,
+ * chunk_off_dev[c] = first element; partial_dev: nchunks doubles of scratch; total_norm_dev (optional): pre-clip norm.
+ * max_norm <= 0 disables clipping; `step` = this tensor's 1-based Adam step count (torch counts per parameter);
+ * write_grad != 0 stores the clipped gradient back. */
+typedef struct cips_opt_tensor {
+  float* param; const float* grad; float* exp_avg; float* exp_avg_sq; float* ema; long long n; long long step;
+} cips_opt_tensor;
+int cips_opt_chunk(void);
+int cips_opt_step(const cips_opt_tensor* table_dev, const int* chunk_tensor_dev, const long long* chunk_off_dev,
+                  int nchunks, double* partial_dev, float* total_norm_dev, float max_norm, float lr,
+                  float beta1, float beta2, float eps, float ema_decay, int write_grad,
+                  cips_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

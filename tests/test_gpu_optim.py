@@ -1,0 +1,77 @@
+"""GPU: the fused clip + Adam + EMA step (cips3d_amd/optim.py, csrc/optim.hip) against the reference's own recipe —
+torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(betas, weight_decay=0) + EMA.update
+(exp/cips3d/scripts/train.py:420-491, exp/comm/comm_model_utils.py:97-118) — over several steps, including
+parameters without a gradient, tensors spanning several chunks, clipping active and inactive."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("betas,max_norm", [((0.0, 0.999), 10.0), ((0.0, 0.999), 0.05), ((0.9, 0.99), None)])
+def test_fused_clip_adam_ema_matches_torch(betas, max_norm):
+    from cips3d_amd.optim import FusedClipAdamEMA
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    shapes = [(7, 5), (300000,), (3,), (512, 512), (1,), (65536,), (4,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(*s, generator=g).to(d)) for s in shapes]
+    p_ref = mk()
+    p_fus = [torch.nn.Parameter(p.detach().clone()) for p in p_ref]
+    e_ref = [p.detach().clone() for p in p_ref]
+    e_fus = [p.detach().clone() for p in p_ref]
+    opt = torch.optim.Adam([{"params": p_ref}], lr=2e-3, betas=betas, weight_decay=0)
+    fus = FusedClipAdamEMA(p_fus, lr=2e-3, betas=betas, max_norm=max_norm, ema_params=e_fus, ema_decay=0.999)
+    for it in range(4):
+        grads = [torch.randn(*s, generator=g).to(d) * (0.3 + it) for s in shapes]
+        for k, (a, b) in enumerate(zip(p_ref, p_fus)):
+            if k == 6 or (k == 2 and it % 2):          # a parameter that never / sometimes gets a gradient
+                a.grad = b.grad = None
+            else:
+                a.grad, b.grad = grads[k].clone(), grads[k].clone()
+        if max_norm:
+            n_ref = torch.nn.utils.clip_grad_norm_(p_ref, max_norm)
+        else:
+            n_ref = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad) for p in p_ref if p.grad is not None]))
+        opt.step()
+        with torch.no_grad():
+            for e, p in zip(e_ref, p_ref):
+                e.copy_(e * 0.999 + p * (1 - 0.999))
+        n_fus = fus.step()
+        torch.cuda.synchronize()
+        assert abs(float(n_fus) - float(n_ref)) <= 1e-5 * float(n_ref)
+        for k, (a, b, ea, eb) in enumerate(zip(p_ref, p_fus, e_ref, e_fus)):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (it, k, float((a - b).abs().max()))
+            assert torch.allclose(ea, eb, rtol=2e-6, atol=1e-7), (it, k)
+            if max_norm and a.grad is not None:       # the clipped gradient is visible in .grad like clip_grad_norm_'s
+                assert torch.allclose(a.grad, b.grad, rtol=2e-6, atol=1e-9), (it, k)
+    sd = fus.state_dict()
+    ref_sd = opt.state_dict()
+    for i in range(len(shapes)):
+        if i in ref_sd["state"]:
+            assert torch.allclose(sd["state"][i]["exp_avg_sq"], ref_sd["state"][i]["exp_avg_sq"], rtol=2e-5, atol=1e-12)   # the clip coefficient (norm in double here, fp32 norm-of-norms in torch) enters squared
+
+
+def test_fused_optimizer_on_generator_parameters():
+    """all 172-key generator parameters through one fused step: finite, changed, EMA moved"""
+    from conftest import G_CFG
+    from cips3d_amd.generator import GeneratorNerfINR
+    from cips3d_amd.optim import FusedClipAdamEMA
+    d = torch.device("cuda:0")
+    torch.manual_seed(0)
+    G = GeneratorNerfINR(**G_CFG, device=d).to(d); G.device = d
+    G_ema = copy.deepcopy(G)
+    opt = FusedClipAdamEMA(G.parameters(), lr=2e-4, betas=(0.0, 0.999), max_norm=10.0, ema_params=G_ema.parameters())
+    kw = dict(fov=12, ray_start=0.88, ray_end=1.12, num_steps=4, h_stddev=0.3, v_stddev=0.155,
+              hierarchical_sample=True, psi=1., sample_dist="gaussian")
+    imgs, _ = G(G.get_zs(2), img_size=8, nerf_noise=0.1, return_aux_img=True, grad_points=None, forward_points=None, **kw)
+    imgs.square().mean().backward()
+    before = [p.detach().clone() for p in G.parameters()]
+    norm = opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(norm).all() and float(norm) > 0
+    changed = sum(int(not torch.equal(a, b)) for a, b in zip(before, G.parameters()))
+    assert changed > 100
+    assert all(torch.isfinite(p).all() for p in G.parameters())
+    assert any(not torch.equal(a, b) for a, b in zip(G_ema.parameters(), before))
