@@ -295,21 +295,22 @@ __global__ __launch_bounds__(256) void torgb_bwd_w_partial_kernel(const void* __
   }
 }
 
-// sum the per-chunk partials: block -> 32 consecutive outputs x 8 chunk groups, fixed combine order
+// sum the per-chunk partials: block -> 8 consecutive outputs x 32 chunk groups (193 blocks at K = 512 instead of 49,
+// 32 serial loads per thread instead of 128), fixed combine order
 __global__ __launch_bounds__(256) void torgb_bwd_w_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                                  float* __restrict__ dbias, int chunks, int K) {
-  __shared__ float red[8][33];
-  const int c = threadIdx.x & 31, gi = threadIdx.x >> 5;
-  const int idx = blockIdx.x * 32 + c;
+  __shared__ float red[32][9];
+  const int c = threadIdx.x & 7, gi = threadIdx.x >> 3;
+  const int idx = blockIdx.x * 8 + c;
   float acc = 0.f;
   if (idx < 3 * K + 3)
-    for (int ch = gi; ch < chunks; ch += 8) acc += partial[(long long)ch * 4 * K + idx];
+    for (int ch = gi; ch < chunks; ch += 32) acc += partial[(long long)ch * 4 * K + idx];
   red[gi][c] = acc;
   __syncthreads();
   if (gi == 0 && idx < 3 * K + 3) {
     float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) t += red[g][c];
+    for (int g = 0; g < 32; ++g) t += red[g][c];
     if (idx < 3 * K) dw[idx] = t; else dbias[idx - 3 * K] = t;
   }
 }
@@ -556,7 +557,7 @@ extern "C" int cips_torgb_bwd_w(const float* x, const float* drgb, float* partia
   if ((K & 3) || K > 512) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(torgb_bwd_w_partial_kernel<false>, dim3(chunks), dim3(256), 0, st, (const void*)x,
                      (const void*)nullptr, drgb, partials, M, K);
-  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 31) / 32), dim3(256), 0, st, partials, dw,
+  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 7) / 8), dim3(256), 0, st, partials, dw,
                      dbias, chunks, K);
   return CIPS_CHECK_LAUNCH();
 }
@@ -568,7 +569,7 @@ extern "C" int cips_torgb_bwd_w_x3(const void* x_hi, const void* x_lo, const flo
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(torgb_bwd_w_partial_kernel<true>, dim3(chunks), dim3(256), 0, st, x_hi, x_lo, drgb, partials,
                      M, K);
-  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 31) / 32), dim3(256), 0, st, partials, dw,
+  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 7) / 8), dim3(256), 0, st, partials, dw,
                      dbias, chunks, K);
   return CIPS_CHECK_LAUNCH();
 }
