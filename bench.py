@@ -220,21 +220,24 @@ def main():
     value = world * b * a.steps / dt
     exact = None
     if mode == "bf16x3" and not a.no_exact:
-        ops.INR_MODE = "f32"          # same step with the INR GEMMs on exact fp32 MFMA, for reference (eager launches)
+        ops.INR_MODE = "f32"          # same step with the head GEMMs and the SIREN forward on exact fp32 MFMA, for
+        fwd_was = ops.SIREN_FWD_MODE  # reference (eager launches)
+        ops.SIREN_FWD_MODE = "f32"
         was = use_graph[0]
         use_graph[0] = False
         dte = timed(max(2, a.steps // 2), 1)
         use_graph[0] = was
         ops.INR_MODE = mode
+        ops.SIREN_FWD_MODE = fwd_was
         ne = max(2, a.steps // 2)
         exact = {"value": round(world * b * ne / dte, 2), "ms_per_step": round(dte / ne * 1e3, 3),
-                 "note": "identical step, INR GEMMs on v_mfma_f32_32x32x2_f32 (CIPS_INR_MODE=f32)"}
+                 "note": "identical step, INR GEMMs and SIREN forward on v_mfma_f32_32x32x2_f32 (CIPS_INR_MODE=f32 CIPS_SIREN_FWD=f32)"}
     E = 2 * S if a.hier else S
     line = {
         "metric": "rendered imgs/sec (G fwd+bwd)", "value": round(value, 2), "unit": "img/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if mode == "f32" else "f32 (fp32 MFMA; CIPS-head GEMMs as 3-pass split-bf16 MFMA, fp32 accumulate)",
+        "dtype": "f32" if mode == "f32" else "f32 (dense layers as 3-pass split-bf16 MFMA with fp32 accumulate, ~1e-5 rel.; everything else fp32)",
         "data": "synthetic",
         "config": {"workload": f"FFHQ r{img}, {E} SIREN evals/ray (num_steps {S}, hierarchical {a.hier}), "
                                f"batch {b}/GPU, G fwd+bwd, all 9 CIPS blocks",

@@ -67,6 +67,7 @@ SIGNATURES = {
     "cips_arch": (C.c_char_p, []),
     "cips_rays_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_siren_fwd": (i32, [C.POINTER(SirenWeights), vp, vp, vp, i32, i32, vp]),
+    "cips_siren_fwd_x3": (i32, [C.POINTER(SirenWeights), vp, vp, vp, i32, i32, vp]),
     "cips_siren_bwd_rows": (i32, [i32, i32]),
     "cips_siren_bwd_x3_chunks": (i32, [i32, i32]),
     "cips_siren_bwd_x3_gpart": (i32, []),

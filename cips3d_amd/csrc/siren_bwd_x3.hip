@@ -778,6 +778,138 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_x3_kernel(BwdX3Args a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Forward on the same split-bf16 register chain (default; CIPS_SIREN_FWD=f32 selects siren.hip's exact fp32 MFMA
+// kernel): layer 0 on the VALU, W1 / Wc / Wf on v_mfma_f32_32x32x16_bf16 in three passes, sigma as a VALU
+// dot with one cross-half add.  No weight-gradient accumulators, so eight waves (two per SIMD) share the LDS images.
+struct FwdX3Args {
+  cips_siren_weights w;
+  const float* points;
+  float* feat;
+  float* sigma;
+  int B, P, chunk;
+};
+
+template <bool HW>
+__global__ __launch_bounds__(512) void siren_fwd_x3_kernel(FwdX3Args a) {
+  extern __shared__ __attribute__((aligned(1024))) uchar smem[];
+  const int b = blockIdx.y;
+  stage_weights_x3(smem, a.w, b);
+  if (threadIdx.x < CF) reinterpret_cast<float*>(smem + O_AUX)[threadIdx.x] = a.w.bf[threadIdx.x];   // bf[32] (aux image unused here)
+  __syncthreads();
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uchar*)smem);
+  const float bs = a.w.bs[0];
+  const int cstart = blockIdx.x * a.chunk;
+  const int cend = min(cstart + a.chunk, a.P);
+  for (int pbase = cstart + wave * 32; pbase < cend; pbase += 8 * 32) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int l31 = lane & 31, hf = lane >> 5;
+    const LaneAddr LA = lane_addr(lane, sbase);
+    const int p = pbase + l31;
+    const bool valid = p < cend;
+    const long long gp = (long long)b * a.P + (valid ? p : cend - 1);
+    const float px = a.points[gp * 3 + 0], py = a.points[gp * 3 + 1], pz = a.points[gp * 3 + 2];
+
+    f32x16 acc[4];
+    zero_acc(acc);
+    {
+      Act<4> h1p;
+      float4 pn[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 16 * e);
+#pragma unroll
+      for (int grp = 0; grp < 16; ++grp) {
+        float4 pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = pn[e];
+        if (grp + 1 < 16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 128 * (grp + 1) + 16 * e);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float sn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sn[e] = film_sin<HW>(fmaf(pk[e].x, px, fmaf(pk[e].y, py, fmaf(pk[e].z, pz, pk[e].w))));
+        const int q = grp >> 2, g = grp & 3;
+        split2(sn[0], sn[1], h1p.hi[q][2 * g], h1p.lo[q][2 * g]);
+        split2(sn[2], sn[3], h1p.hi[q][2 * g + 1], h1p.lo[q][2 * g + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      layer_fwd<4, 4, H, O_W1H, O_W1L - O_W1H>(LA, h1p, acc);
+    }
+    Act<4> h2p;
+    float sig = 0.f;
+    {
+      float4 gn = lds_ld4(LA.v16 + (O_G1 - O_L0)), cn = lds_ld4(LA.v16 + (O_C1 - O_L0)), wn = lds_ld4(LA.v16 + (O_WS - O_L0));
+#pragma unroll
+      for (int grp = 0; grp < 16; ++grp) {
+        const float4 g4 = gn, c4 = cn, w4 = wn;
+        if (grp + 1 < 16) {
+          gn = lds_ld4(LA.v16 + (O_G1 - O_L0) + 32 * (grp + 1)); cn = lds_ld4(LA.v16 + (O_C1 - O_L0) + 32 * (grp + 1));
+          wn = lds_ld4(LA.v16 + (O_WS - O_L0) + 32 * (grp + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = grp >> 2, g = grp & 3;
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+        float sn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sn[e] = film_sin<HW>(fmaf(gg[e], acc[q][4 * g + e], cc[e]));
+          sig = fmaf(ww[e], sn[e], sig);
+        }
+        split2(sn[0], sn[1], h2p.hi[q][2 * g], h2p.lo[q][2 * g]);
+        split2(sn[2], sn[3], h2p.hi[q][2 * g + 1], h2p.lo[q][2 * g + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    sig += __shfl_xor(sig, 32);
+    sig += bs;
+
+    f32x16 accc[2];
+    zero_acc(accc);
+    layer_fwd<2, 4, HC, O_WCH, O_WCL - O_WCH>(LA, h2p, accc);
+    Act<2> hcp;
+    {
+      float4 gn = lds_ld4(LA.v16 + (O_GC - O_L0)), cn = lds_ld4(LA.v16 + (O_CC - O_L0));
+#pragma unroll
+      for (int grp = 0; grp < 8; ++grp) {
+        const float4 g4 = gn, c4 = cn;
+        if (grp + 1 < 8) { gn = lds_ld4(LA.v16 + (O_GC - O_L0) + 32 * (grp + 1)); cn = lds_ld4(LA.v16 + (O_CC - O_L0) + 32 * (grp + 1)); }
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = grp >> 2, g = grp & 3;
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
+        float sn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sn[e] = film_sin<HW>(fmaf(gg[e], accc[q][4 * g + e], cc[e]));
+        split2(sn[0], sn[1], hcp.hi[q][2 * g], hcp.lo[q][2 * g]);
+        split2(sn[2], sn[3], hcp.hi[q][2 * g + 1], hcp.lo[q][2 * g + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    f32x16 accf[1];
+    zero_acc(accf);
+    layer_fwd<1, 2, CF, O_WFH, O_WFL - O_WFH>(LA, hcp, accf);
+    if (valid) {
+      float* fo = a.feat + gp * CF + 4 * hf;
+      const float* bfv = reinterpret_cast<const float*>(smem + O_AUX);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v;
+        v.x = accf[0][4 * g + 0] + bfv[8 * g + 4 * hf + 0];
+        v.y = accf[0][4 * g + 1] + bfv[8 * g + 4 * hf + 1];
+        v.z = accf[0][4 * g + 2] + bfv[8 * g + 4 * hf + 2];
+        v.w = accf[0][4 * g + 3] + bfv[8 * g + 4 * hf + 3];
+        *reinterpret_cast<float4*>(fo + 8 * g) = v;
+      }
+      if (hf == 0) a.sigma[gp] = sig;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace
 
 // 4096-point chunks when that still fills the chip (>= 3 workgroups per CU on 256 CUs), else 2048 / 1024 / 512
@@ -828,5 +960,27 @@ extern "C" int cips_siren_bwd_x3(const cips_siren_weights* w, const float* point
     hipLaunchKernelGGL(siren_bwd_x3_kernel<true>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(siren_bwd_x3_kernel<false>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_siren_fwd_x3(const cips_siren_weights* w, const float* points, float* feat, float* sigma, int B, int P,
+                                 cips_stream_t stream) {
+  if (!w || !points || !feat || !sigma || B <= 0 || P <= 0) return (int)hipErrorInvalidValue;
+  FwdX3Args a;
+  a.w = *w; a.points = points; a.feat = feat; a.sigma = sigma; a.B = B; a.P = P;
+  a.chunk = 4096;
+  while (a.chunk > 512 && (long long)B * ((P + a.chunk - 1) / a.chunk) < 768) a.chunk >>= 1;
+  dim3 grid((P + a.chunk - 1) / a.chunk, B);
+  const int smem = O_STG;            // weight images + FiLM vectors + the 4 KiB slot reused for the output bias
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)siren_fwd_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)siren_fwd_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  if (w->trig_mode == 1)
+    hipLaunchKernelGGL(siren_fwd_x3_kernel<true>, grid, dim3(512), smem, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(siren_fwd_x3_kernel<false>, grid, dim3(512), smem, (hipStream_t)stream, a);
   return CIPS_CHECK_LAUNCH();
 }

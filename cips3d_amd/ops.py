@@ -130,6 +130,7 @@ def _split_k(P, target=8):
     return 1
 
 
+SIREN_FWD_MODE = __import__("os").environ.get("CIPS_SIREN_FWD", "x3")   # "x3": split-bf16 chain (default, ~1e-5 rel.); "f32": exact fp32 MFMA
 SIREN_BWD_MODE = __import__("os").environ.get("CIPS_SIREN_BWD", "x3")   # "x3": fused bf16x3 backward; "staged": data pass + GEMMs
 
 
@@ -154,7 +155,8 @@ class SirenFunction(torch.autograd.Function):
         feat = torch.empty(B, P, 32, device=points.device)
         sigma = torch.empty(B, P, device=points.device)
         sw = _siren_struct(t)
-        check(lib.cips_siren_fwd(C.byref(sw), _p(points), _p(feat), _p(sigma), B, P, _stream()), "cips_siren_fwd")
+        fwd = lib.cips_siren_fwd_x3 if SIREN_FWD_MODE == "x3" else lib.cips_siren_fwd
+        check(fwd(C.byref(sw), _p(points), _p(feat), _p(sigma), B, P, _stream()), "cips_siren_fwd")
         ctx.save_for_backward(points, *[t[n] for n in _SIREN_NAMES])
         return feat, sigma
 

@@ -27,7 +27,13 @@ def main():
     e0.record()
     for _ in range(reps): step()
     e1.record(); torch.cuda.synchronize()
-    print(f"siren fwd+bwd b={b} P={P} mode={ops.SIREN_BWD_MODE}: {e0.elapsed_time(e1) / reps:.3f} ms/iter")
+    print(f"siren fwd+bwd b={b} P={P} fwd={ops.SIREN_FWD_MODE} bwd={ops.SIREN_BWD_MODE}: {e0.elapsed_time(e1) / reps:.3f} ms/iter")
+    with torch.no_grad():
+        for _ in range(2): ops.SirenFunction.apply(*args)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(reps): ops.SirenFunction.apply(*args)
+        e1.record(); torch.cuda.synchronize()
+    print(f"  forward only: {e0.elapsed_time(e1) / reps:.3f} ms")
     if os.environ.get("CIPS_X3_PROF"):
         import ctypes, numpy as np
         from cips3d_amd import _lib

@@ -13,12 +13,14 @@ CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze", "g_r
 
 @pytest.fixture(params=["f32", "bf16x3"])
 def inr_mode(request):
-    """Run under both INR GEMM modes: exact fp32 MFMA and the 3-pass split-bf16 MFMA (default)."""
+    """Run under both numeric modes: exact fp32 MFMA (head GEMMs and SIREN forward) and the 3-pass split-bf16 MFMA
+    path (default)."""
     from cips3d_amd import ops
-    old = ops.INR_MODE
+    old = (ops.INR_MODE, ops.SIREN_FWD_MODE)
     ops.INR_MODE = request.param
+    ops.SIREN_FWD_MODE = "f32" if request.param == "f32" else "x3"
     yield request.param
-    ops.INR_MODE = old
+    ops.INR_MODE, ops.SIREN_FWD_MODE = old
 
 
 @pytest.mark.parametrize("tag", CASES)

@@ -86,8 +86,10 @@ def _siren_inputs(seed, b, P):
 
 @pytest.mark.parametrize("trig", [0, 1])
 @pytest.mark.parametrize("b,P", [(2, 32 * 7 + 5), (3, 4096 + 64)])
-def test_siren_forward(trig, b, P):
+def test_siren_forward(trig, b, P, monkeypatch):
+    """exact fp32 MFMA forward (CIPS_SIREN_FWD=f32)"""
     from cips3d_amd import ops
+    monkeypatch.setattr(ops, "SIREN_FWD_MODE", "f32")
     G, pts, style = _siren_inputs(3, b, P)
     sd = dict(G.named_parameters())
     with torch.no_grad():
@@ -104,6 +106,29 @@ def test_siren_forward(trig, b, P):
     e_f, e_s = max_rel(out[..., :32], ref[..., :32]), max_rel(out[..., 32], ref[..., 32])
     print(f"siren fwd trig={trig} b={b} P={P}: feat max_rel {e_f:.3e} sigma max_rel {e_s:.3e}")
     assert e_f < TOL and e_s < TOL
+
+
+@pytest.mark.parametrize("trig,b,P", [(1, 2, 2048 + 96), (0, 3, 128 * 7 + 5), (1, 1, 4096 * 3)])
+def test_siren_forward_x3(trig, b, P, monkeypatch):
+    """split-bf16 forward (default) vs the fp32 CPU oracle"""
+    from cips3d_amd import ops
+    monkeypatch.setattr(ops, "SIREN_FWD_MODE", "x3")
+    G, pts, style = _siren_inputs(4, b, P)
+    sd = dict(G.named_parameters())
+    with torch.no_grad():
+        ref = orc.siren(sd, pts, style)
+    Gd = G.to(dev())
+    st = style.to(dev())
+    ops.TRIG_MODE = trig
+    try:
+        with torch.no_grad():
+            out = Gd.siren(pts.to(dev()), {"nerf_w0": st, "nerf_w1": st, "nerf_rgb": st})
+    finally:
+        ops.TRIG_MODE = 0
+    torch.cuda.synchronize()
+    e_f, e_s = max_rel(out[..., :32], ref[..., :32]), max_rel(out[..., 32], ref[..., 32])
+    print(f"siren fwd x3 trig={trig} b={b} P={P}: feat max_rel {e_f:.3e} sigma max_rel {e_s:.3e}")
+    assert e_f < 2e-4 and e_s < 2e-4
 
 
 @pytest.mark.parametrize("trig,mode,b,P", [(0, "x3", 2, 2048 + 96), (1, "x3", 2, 2048 + 96), (1, "x3", 3, 128 * 7 + 5),
