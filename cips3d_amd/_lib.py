@@ -101,6 +101,7 @@ SIGNATURES = {
     "cips_fused_bias_act": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, vp]),
     "cips_upfirdn2d": (i32, [vp, vp, vp] + [i32] * 14 + [vp]),
     "cips_im2col": (i32, [vp, vp] + [i32] * 8 + [vp]),
+    "cips_im2col_x3": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cips_col2im": (i32, [vp, vp] + [i32] * 8 + [vp]),
 }
 

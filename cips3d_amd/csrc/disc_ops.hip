@@ -77,8 +77,12 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirArgs a) {
 }
 
 // colT[b][(c,ky,kx)][(oy,ox)] = x[b][c][oy*s+ky-p][ox*s+kx-p]   (zero outside)
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int C,
-                                                     int H, int W, int kh, int kw, int stride, int pad, int Ho, int Wo) {
+// X3: write the k-major matrix as split-bf16 planes (x = hi + lo) — the B operand of the K-major / NT bf16x3 GEMMs —
+// instead of fp32 (same bytes)
+template <bool X3>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col,
+                                                     unsigned short* __restrict__ col_hi, unsigned short* __restrict__ col_lo,
+                                                     int B, int C, int H, int W, int kh, int kw, int stride, int pad, int Ho, int Wo) {
   const long long total = (long long)B * C * kh * kw * Ho * Wo;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     long long t = idx;
@@ -91,7 +95,16 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
     const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
     float v = 0.f;
     if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((b * C + c) * H + iy) * W + ix];
-    col[idx] = v;
+    if (X3) {
+      unsigned u = __float_as_uint(v);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      const unsigned short h = (unsigned short)(u >> 16);
+      unsigned l = __float_as_uint(v - __uint_as_float(((unsigned)h) << 16));
+      l += 0x7fffu + ((l >> 16) & 1u);
+      col_hi[idx] = h; col_lo[idx] = (unsigned short)(l >> 16);
+    } else {
+      col[idx] = v;
+    }
   }
 }
 
@@ -164,8 +177,18 @@ extern "C" int cips_im2col(const float* x, float* col, int B, int C, int H, int 
   const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
   long long total = (long long)B * C * kh * kw * Ho * Wo;
   if (total <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, col, B, C, H, W,
-                     kh, kw, stride, pad, Ho, Wo);
+  hipLaunchKernelGGL(im2col_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, col,
+                     (unsigned short*)nullptr, (unsigned short*)nullptr, B, C, H, W, kh, kw, stride, pad, Ho, Wo);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_im2col_x3(const float* x, void* col_hi, void* col_lo, int B, int C, int H, int W, int kh, int kw,
+                              int stride, int pad, cips_stream_t stream) {
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  long long total = (long long)B * C * kh * kw * Ho * Wo;
+  if (total <= 0 || !col_hi || !col_lo) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(im2col_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (float*)nullptr,
+                     (unsigned short*)col_hi, (unsigned short*)col_lo, B, C, H, W, kh, kw, stride, pad, Ho, Wo);
   return CIPS_CHECK_LAUNCH();
 }
 

@@ -142,10 +142,29 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+# Conv GEMMs of eligible layers run as 3-pass split-bf16 MFMA (cips_gemm_bf16x3*, ~5e-6 relative, ~3x the fp32 MFMA
+# rate); CIPS_D_CONV_MODE=f32 keeps every layer on the exact fp32 MFMA GEMM.  Eligible: all three contraction lengths
+# (C*kh*kw, Ho*Wo, O) multiples of 32 — i.e. everything but the RGB input convs and the 4x4 tail.
+import os as _os
+CONV_MODE = _os.environ.get("CIPS_D_CONV_MODE", "bf16x3")
+
+
+def _x3_ok(K, N, O):
+    return CONV_MODE == "bf16x3" and K % 32 == 0 and N % 32 == 0 and O % 32 == 0
+
+
 def _conv_fwd(x, w, stride, pad):
     B, C, H, W = x.shape
     O, _, kh, kw = w.shape
     x = x.contiguous()
+    Ho_, Wo_ = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if _x3_ok(C * kh * kw, Ho_ * Wo_, O):
+        K, N = C * kh * kw, Ho_ * Wo_
+        colP, _, _ = ops.im2col_x3(x, kh, kw, stride, pad)               # planes (B, K, N): k-major B operand
+        _, wT = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=False, want_t=True)   # (1, K, O): k-major A operand
+        y = torch.empty(B, O, Ho_, Wo_, device=x.device)
+        ops.gemm_x3_km(wT, colP, O, N, K, O, N, B, 0, K * N, y)          # y[b] (O,N) = W (O,K) @ col[b] (K,N)
+        return y
     col, Ho, Wo = ops.im2col(x, kh, kw, stride, pad)                  # (B, K, Ho*Wo)
     K, N = C * kh * kw, Ho * Wo
     if N % 4:
@@ -167,6 +186,12 @@ def _conv_bwd_data(dy, w, in_shape, stride, pad):
     dy = dy.contiguous()
     Ho, Wo = dy.shape[2], dy.shape[3]
     K, N = C * kh * kw, Ho * Wo
+    if _x3_ok(K, N, O):
+        wP, _ = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=True, want_t=False)    # (1, O, K): contraction index o = rows
+        dyP, _ = ops.split_planes(dy.view(B, O, N), want_p=True, want_t=False)
+        dcol = torch.empty(B, K, N, device=dy.device)
+        ops.gemm_x3_km(wP, dyP, K, N, O, K, N, B, 0, O * N, dcol)        # dcol[b] (K,N) = W^T (K,O) @ dy[b] (O,N)
+        return ops.col2im(dcol, B, C, H, W, kh, kw, stride, pad)
     wm = w.reshape(O, K)
     Kp = _pad4(K)
     if Kp != K:
@@ -184,8 +209,14 @@ def _conv_bwd_weight(dy, x, w_shape, stride, pad):
     B = x.shape[0]
     x = x.contiguous()
     dy = dy.contiguous()
+    K, N = C * kh * kw, dy.shape[2] * dy.shape[3]
+    if _x3_ok(K, N, O):
+        colP, _, _ = ops.im2col_x3(x, kh, kw, stride, pad)
+        dyP, _ = ops.split_planes(dy.view(B, O, N), want_p=True, want_t=False)
+        part = torch.empty(B, O, K, device=x.device)
+        ops.gemm_x3(dyP, colP, O, K, N, N, N, B, O * N, K * N, C=part)   # part[b] (O,K) = dy[b] (O,N) @ col[b]^T (N,K)
+        return part.sum(0).view(O, C, kh, kw)
     col, Ho, Wo = ops.im2col(x, kh, kw, stride, pad)
-    K, N = C * kh * kw, Ho * Wo
     part = torch.empty(B, O, K, device=x.device)
     ops.gemm(dy, col, part, O, K, N, N, N, K, batch=B, strideA=O * N, strideB=K * N, strideC=O * K, b_nmajor=True)
     return part.sum(0).view(O, C, kh, kw)

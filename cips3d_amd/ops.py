@@ -843,6 +843,17 @@ def im2col(x, kh, kw, stride, pad):
     return col, Ho, Wo
 
 
+def im2col_x3(x, kh, kw, stride, pad):
+    """im2col as split-bf16 planes (B, C*kh*kw, Ho*Wo)"""
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    col = Planes.empty(B, Cc * kh * kw, Ho * Wo, device=x.device)
+    check(lib.cips_im2col_x3(_p(x), _p(col.hi), _p(col.lo), B, Cc, H, W, kh, kw, stride, pad, _stream()), "cips_im2col_x3")
+    return col, Ho, Wo
+
+
 def col2im(col, B, Cc, H, W, kh, kw, stride, pad):
     lib = _lib.load()
     dx = torch.empty(B, Cc, H, W, device=col.device)

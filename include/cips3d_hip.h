@@ -327,6 +327,9 @@ int cips_upfirdn2d(const float* input, const float* kernel, float* out,
  * (gather form, deterministic). */
 int cips_im2col(const float* x, float* col, int B, int C, int H, int W,
                 int kh, int kw, int stride, int pad, cips_stream_t stream);
+/* im2col writing split-bf16 planes (col = hi + lo), the operand form of the bf16x3 GEMMs */
+int cips_im2col_x3(const float* x, void* col_hi, void* col_lo, int B, int C, int H, int W, int kh, int kw,
+                   int stride, int pad, cips_stream_t stream);
 int cips_col2im(const float* col, float* dx, int B, int C, int H, int W,
                 int kh, int kw, int stride, int pad, cips_stream_t stream);
 
