@@ -32,6 +32,30 @@ def test_conv2d_function_double_backward_matches_torch_cpu():
         assert rel_err(xd.grad, x.grad) < 1e-4 and rel_err(wd.grad, w.grad) < 1e-4
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_conv2d_x3_eligible_shapes_double_backward(mode, monkeypatch):
+    """layers whose contraction lengths are all multiples of 32 (the split-bf16 GEMM path when mode = bf16x3):
+    forward, input gradient, and the double-backward graph against torch on the CPU in fp64"""
+    from cips3d_amd import discriminator as dm
+    monkeypatch.setattr(dm, "CONV_MODE", mode)
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    tol = 3e-5 if mode == "bf16x3" else 1e-5
+    for (B, C, O, H, k, stride, pad) in [(3, 32, 64, 16, 3, 1, 1), (2, 64, 32, 17, 3, 2, 0), (2, 32, 32, 16, 1, 1, 0)]:
+        x = torch.randn(B, C, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+        w = (torch.randn(O, C, k, k, generator=g, dtype=torch.float64) / (C * k * k) ** 0.5).requires_grad_(True)
+        y = torch.nn.functional.conv2d(x, w, stride=stride, padding=pad)
+        up = torch.randn(y.shape, generator=g, dtype=torch.float64)
+        gx, = torch.autograd.grad((y * up).sum(), x, create_graph=True)
+        ((gx ** 2).sum() + (y ** 2).sum()).backward()
+        xd = x.detach().float().to(d).requires_grad_(True); wd = w.detach().float().to(d).requires_grad_(True)
+        yd = dm.conv2d(xd, wd, stride=stride, padding=pad)
+        gxd, = torch.autograd.grad((yd * up.float().to(d)).sum(), xd, create_graph=True)
+        ((gxd ** 2).sum() + (yd ** 2).sum()).backward()
+        assert rel_err(yd, y) < tol and rel_err(gxd, gx) < tol, (mode, C, O, H, k, stride)
+        assert rel_err(xd.grad, x.grad) < 3 * tol and rel_err(wd.grad, w.grad) < 3 * tol, (mode, C, O, H, k, stride)
+
+
 @pytest.mark.parametrize("tag", ["d_r16", "d_r16_aux_alpha"])
 def test_discriminator_matches_reference_golden(tag):
     from cips3d_amd.discriminator import Discriminator_MultiScale_Aux
