@@ -755,12 +755,25 @@ class InrHeadX3Function(torch.autograd.Function):
             # ---- weight gradients of both layers: dWb2 = a1^T g, dWb1 = x^T g1 ----
             gwb2 = torch.empty(B, cout, cout, device=dev)
             gwb1 = torch.empty(B, cin, cout, device=dev)
-            if km and cin == cout:
-                gemm_x3_km_grouped([(sv["a1P"], gP, gwb2), (sv["xP"], g1P, gwb1)], cout, cout, n, cout, cout, B,
-                                   n * cout, n * cout)
-            elif km:
-                gemm_x3_km(sv["a1P"], gP, cout, cout, n, cout, cout, B, n * cout, n * cout, gwb2)
-                gemm_x3_km(sv["xP"], g1P, cin, cout, n, cin, cout, B, n * cin, n * cout, gwb1)
+            if km:
+                # dWb[b] = X[b]^T G[b] contracts over the n pixels of image b.  With few images per GPU a 512x512
+                # output is too few tiles for the chip, so the pixel range is split in `ksp` parts — a pure view of
+                # the row-major planes, (B, n, C) -> (B*ksp, n/ksp, C) — and the partial products are summed.
+                ksp = 1
+                while B * ksp < 32 and n % (2 * ksp * 32) == 0 and n // (2 * ksp) >= 512:
+                    ksp *= 2
+                nk_ = n // ksp
+                part2 = gwb2 if ksp == 1 else torch.empty(B * ksp, cout, cout, device=dev)
+                part1 = gwb1 if ksp == 1 else torch.empty(B * ksp, cin, cout, device=dev)
+                if cin == cout:
+                    gemm_x3_km_grouped([(sv["a1P"], gP, part2), (sv["xP"], g1P, part1)], cout, cout, nk_, cout, cout,
+                                       B * ksp, nk_ * cout, nk_ * cout)
+                else:
+                    gemm_x3_km(sv["a1P"], gP, cout, cout, nk_, cout, cout, B * ksp, nk_ * cout, nk_ * cout, part2)
+                    gemm_x3_km(sv["xP"], g1P, cin, cout, nk_, cin, cout, B * ksp, nk_ * cin, nk_ * cout, part1)
+                if ksp > 1:
+                    torch.sum(part2.view(B, ksp, cout, cout), dim=1, out=gwb2)
+                    torch.sum(part1.view(B, ksp, cin, cout), dim=1, out=gwb1)
             else:
                 gemm_x3(sv["a1T"], gT, cout, cout, n, n, n, B, cout * n, cout * n, C=gwb2)
                 gemm_x3(sv["xT"], g1T, cin, cout, n, n, n, B, cin * n, cout * n, C=gwb1)
