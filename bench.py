@@ -142,7 +142,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from cips3d_amd.generator import GeneratorNerfINR
-    from cips3d_amd.distributed import allreduce_grads
+    from cips3d_amd.distributed import GradAllReducer
     from cips3d_amd import ops
     if a.inr_mode:
         ops.INR_MODE = a.inr_mode
@@ -156,6 +156,7 @@ def main():
     b, img = a.batch, a.img_size
     G0 = torch.randn(b, 3, img, img, device=dev) / (b * 3 * img * img)
     params = list(G.parameters())
+    reduce_grads = GradAllReducer(params)
 
     def fwd_bwd():
         zs = G.get_zs(b)
@@ -192,7 +193,7 @@ def main():
         else:
             fwd_bwd()
         if world > 1:
-            allreduce_grads(params)
+            reduce_grads()
 
     def fence():
         torch.cuda.synchronize()

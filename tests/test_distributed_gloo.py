@@ -28,8 +28,24 @@ def _worker(rank, world, port, q):
         params[2].grad = torch.randn(3, generator=g)     # only rank 0 has a grad for this one
     # params[3]: never used on any rank -> must stay None (find_unused_parameters semantics)
     nbytes = allreduce_grads(params, bucket_mb=0.5)
-    out = [None if p.grad is None else p.grad.clone() for p in params]
-    q.put((rank, out, nbytes))
+    out = [None if p.grad is None else p.grad.clone().numpy() for p in params]   # numpy: pickled by value
+    # steady-state form: same plan reused for a second step, then re-planned when the local pattern changes
+    from cips3d_amd.distributed import GradAllReducer
+    red = GradAllReducer(params, bucket_mb=0.5)
+    steady = []
+    for step in range(3):
+        for p in params:
+            p.grad = None
+        params[0].grad = torch.full((7, 5), float(rank + 1 + step))
+        params[1].grad = torch.full((300000,), float(10 * (rank + 1) + step))
+        if step == 2:                                        # the pattern changes on every rank at the same step
+            if rank == 1:                                    # (the contract), differently per rank
+                params[3].grad = torch.full((4,), 8.0)
+            else:
+                params[2].grad = torch.full((3,), 6.0)
+        red()
+        steady.append([None if p.grad is None else p.grad.clone().numpy() for p in params])
+    q.put((rank, out, nbytes, steady))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,8 +60,8 @@ def _run_world(world):
     res = {}
     try:
         for _ in range(world):
-            r, out, nbytes = q.get(timeout=180)
-            res[r] = (out, nbytes)
+            r, out, nbytes, steady = q.get(timeout=180)
+            res[r] = (out, nbytes, steady)
         for p in procs:
             p.join(timeout=60)
             if p.exitcode != 0:
@@ -73,9 +89,19 @@ def test_allreduce_grads_world2_gloo():
     g1 = [torch.randn(300000, generator=g) for g in gens]
     g2 = torch.randn(3, generator=gens[0])
     for r in range(world):
-        out, nbytes = res[r]
+        out, nbytes, steady = res[r]
+        out = [None if o is None else torch.from_numpy(o) for o in out]
+        steady = [[None if o is None else torch.from_numpy(o) for o in st] for st in steady]
         assert torch.allclose(out[0], (g0[0] + g0[1]) / 2, atol=1e-6)
         assert torch.allclose(out[1], (g1[0] + g1[1]) / 2, atol=1e-6)
         assert torch.allclose(out[2], g2 / 2, atol=1e-6)
         assert out[3] is None
         assert nbytes == (35 + 300000 + 3) * 4
+        for step in range(3):
+            st = steady[step]
+            assert torch.allclose(st[0], torch.full((7, 5), 1.5 + step))
+            assert torch.allclose(st[1], torch.full((300000,), 15.0 + step))
+            if step < 2:
+                assert st[2] is None and st[3] is None
+            else:
+                assert torch.allclose(st[2], torch.full((3,), 3.0)) and torch.allclose(st[3], torch.full((4,), 4.0))
