@@ -150,3 +150,76 @@ def test_generator_r64_vs_oracle_forward(inr_mode):
         e = max_rel(imgs, ref["imgs"])
         print(f"r64 S={S} hier={hier} [{inr_mode}]: imgs max_rel {e:.3e}")
         assert e < TOL
+
+
+@pytest.mark.parametrize("S,hier", [(24, False), (12, True)])
+def test_generator_full_size_properties(S, hier):
+    """BASELINE configuration C2 at its full size (64^2, 24 SIREN evaluations per ray, 32 images, default numeric
+    mode), through properties that need no oracle run:
+      * determinism: the same inputs give bit-identical images and parameter gradients (no atomics anywhere),
+      * batch-sharding invariance (what the data-parallel path of SURVEY.md §8e relies on): images 8..15 rendered on
+        their own equal rows 8..15 of the batch and the four quarter-batch gradients sum to the batch gradient — to
+        fp32 summation-order noise, not bitwise: another batch size selects other GEMM tilings (hipBLASLt in the
+        mapping MLPs); for the gradients that noise is amplified by LeakyReLU gate flips, see the comment at the
+        assertion,
+      * linearity of the backward in the upstream gradient: doubling it doubles every parameter gradient exactly
+        (a power of two commutes with fp32 rounding and with the hi/lo bf16 split)."""
+    d = torch.device("cuda:0")
+    G = seeded_generator(1234, device=d)
+    g = torch.Generator().manual_seed(5)
+    b, n = 32, 64 * 64
+    E = 2 * S if hier else S
+    zs = {"z_nerf": torch.randn(b, 256, generator=g).to(d), "z_inr": torch.randn(b, 512, generator=g).to(d)}
+    rand = dict(jitter=torch.rand(b, n, S, 1, generator=g), theta=torch.randn(b, 1, generator=g),
+                phi=torch.randn(b, 1, generator=g), noise_c=torch.randn(b, n, S, 1, generator=g),
+                u=torch.rand(b * n, S, generator=g), noise_f=torch.randn(b, n, E, 1, generator=g))
+    rand = {k: v.to(d) for k, v in rand.items()}
+    G0 = (torch.randn(b, 3, 64, 64, generator=g) / (b * 3 * 64 * 64)).to(d)
+    params = [p for p in G.parameters()]
+
+    def run(sl, scale=1.0):
+        rs = {k: (v[sl] if k != "u" else v.view(b, n, S)[sl].reshape(-1, S)) for k, v in rand.items()}
+        for p in params:
+            p.grad = None
+        imgs, _ = G({k: v[sl] for k, v in zs.items()}, img_size=64, fov=12, ray_start=0.88, ray_end=1.12, num_steps=S,
+                    h_stddev=0.3, v_stddev=0.155, hierarchical_sample=hier, sample_dist="gaussian", rand_override=rs)
+        imgs.backward(G0[sl] * scale)
+        return imgs.detach().clone(), [None if p.grad is None else p.grad.clone() for p in params]
+
+    full = slice(0, b)
+    im1, g1 = run(full)
+    im2, g2 = run(full)
+    assert torch.isfinite(im1).all() and im1.abs().max() <= 1.0
+    assert torch.equal(im1, im2), "forward is not deterministic"
+    for a_, b_ in zip(g1, g2):
+        assert (a_ is None) == (b_ is None)
+        if a_ is not None:
+            assert torch.equal(a_, b_), "backward is not deterministic"
+    _, g3 = run(full, scale=2.0)
+    for a_, c_ in zip(g1, g3):
+        if a_ is not None:
+            assert torch.equal(a_ * 2, c_), "backward is not linear in the upstream gradient"
+    acc = [None if x is None else torch.zeros_like(x, dtype=torch.float64) for x in g1]
+    for q in range(4):
+        sl = slice(8 * q, 8 * q + 8)
+        imq, gq = run(sl)
+        e = max_rel(imq, im1[sl])
+        assert e < 2e-5, f"images {8 * q}..{8 * q + 7} depend on the rest of the batch ({e:.2e})"
+        for a_, x in zip(acc, gq):
+            if a_ is not None:
+                a_ += x.double()
+    worst, rows = 0.0, []
+    names = [k for k, _ in G.named_parameters()]
+    for nm, a_, x in zip(names, acc, g1):
+        if a_ is not None:
+            e = rel_err(a_.float(), x)
+            rows.append((e, nm))
+            worst = max(worst, e)
+    # Gradient tolerance: the mapping MLPs (hipBLASLt picks another kernel for 8 rows than for 32) move the styles by
+    # ~1e-7 and the images by ~1e-5 (asserted above at 2e-5).  At that perturbation about 1e-5 of the 6.7e7 LeakyReLU
+    # gates per layer sit on the other side of zero (DESIGN.md §0), each changing one term of a heavily cancelling sum:
+    # measured 5-6e-3 on every parameter alike, in both numeric modes.  A dropped image, chunk or partial sum would
+    # show up at >= 0.15.
+    print(f"   worst parameters: {sorted(rows, reverse=True)[:3]}")
+    print(f"C2 full size S={S} hier={hier}: sum of quarter-batch gradients vs batch gradient, worst rel err {worst:.2e}")
+    assert worst < 2e-2
