@@ -218,7 +218,7 @@ def test_generator_full_size_properties(S, hier):
     # Gradient tolerance: the mapping MLPs (hipBLASLt picks another kernel for 8 rows than for 32) move the styles by
     # ~1e-7 and the images by ~1e-5 (asserted above at 2e-5).  At that perturbation about 1e-5 of the 6.7e7 LeakyReLU
     # gates per layer sit on the other side of zero, each changing one term of a heavily cancelling sum:
-    # measured 5-6e-3 on every parameter alike, in both numeric modes.  A dropped image, chunk or partial sum would
+    # measured 5-6e-3 on every parameter alike.  A dropped image, chunk or partial sum would
     # show up at >= 0.15.
     print(f"   worst parameters: {sorted(rows, reverse=True)[:3]}")
     print(f"C2 full size S={S} hier={hier}: sum of quarter-batch gradients vs batch gradient, worst rel err {worst:.2e}")
