@@ -426,37 +426,37 @@ class GeneratorNerfINR(nn.Module):
         staged = forward_points is not None
 
         # ---------------- random draws in reference order ----------------
-        def draw(kind, fn, shape):
+        def draw(kind, fn, shape, override=True):
             t = fn(shape, device=device)
-            return ro[kind].to(device).reshape(shape).float() if kind in ro else t
+            return ro[kind].to(device).reshape(shape).float() if (override and kind in ro) else t
 
         need_cam = camera_pos is None or camera_lookup is None
         mode = sample_dist
         if need_cam and mode not in ('gaussian', 'normal', 'uniform', 'mean', None):
             raise NotImplementedError(f"camera sample_dist {mode!r}")
 
-        def draw_cam(bs):
+        def cam_angles(th_raw, ph_raw):
             if mode == 'uniform':
-                th = (draw('theta', torch.rand, (bs, 1)) - 0.5) * 2 * h_stddev + h_mean
-                ph = (draw('phi', torch.rand, (bs, 1)) - 0.5) * 2 * v_stddev + v_mean
-            elif mode == 'mean':
-                th = torch.ones((bs, 1), device=device) * h_mean
-                ph = torch.ones((bs, 1), device=device) * v_mean
-            else:
-                th = draw('theta', torch.randn, (bs, 1)) * h_stddev + h_mean
-                ph = draw('phi', torch.randn, (bs, 1)) * v_stddev + v_mean
-            return th, ph
+                return (th_raw - 0.5) * 2 * h_stddev + h_mean, (ph_raw - 0.5) * 2 * v_stddev + v_mean
+            return th_raw * h_stddev + h_mean, ph_raw * v_stddev + v_mean
+
+        def draw_cam(bs, override=True):
+            """-> the RAW draws (b,1) x 2 (or the fixed angles for mode 'mean')"""
+            if mode == 'mean':
+                return None, None
+            fn = torch.rand if mode == 'uniform' else torch.randn
+            return draw('theta', fn, (bs, 1), override), draw('phi', fn, (bs, 1), override)
 
         part = grad_points is not None and grad_points < n
         if part and staged:
             raise NotImplementedError("grad_points together with forward_points")
         if part:
             jitter = draw('jitter', torch.rand, (b, n, S, 1))
-            theta, phi = draw_cam(b) if need_cam else (None, None)
+            th_raw, ph_raw = draw_cam(b) if need_cam else (None, None)
             noise_c = u = noise_f = None          # drawn per pixel subset below, after the randperm
         elif not staged:
             jitter = draw('jitter', torch.rand, (b, n, S, 1))
-            theta, phi = draw_cam(b) if need_cam else (None, None)
+            th_raw, ph_raw = draw_cam(b) if need_cam else (None, None)
             noise_c = draw('noise_c', torch.randn, (b, n, S, 1)) if hierarchical_sample else None
             u = draw('u', torch.rand, (b * n, S)) if hierarchical_sample else None
             noise_f = draw('noise_f', torch.randn, (b, n, E, 1))
@@ -464,8 +464,8 @@ class GeneratorNerfINR(nn.Module):
             js, ths, phs, ncs, us, nfs = [], [], [], [], [], []
             for _ in range(b):
                 js.append(torch.rand((1, n, S, 1), device=device))
-                if need_cam:
-                    th, ph = draw_cam(1)
+                if need_cam and mode != 'mean':
+                    th, ph = draw_cam(1, override=False)
                     ths.append(th); phs.append(ph)
                 head = 0
                 while head < n:
@@ -476,8 +476,8 @@ class GeneratorNerfINR(nn.Module):
                     nfs.append(torch.randn((1, c, E, 1), device=device))
                     head += forward_points
             jitter = ro.get('jitter', torch.cat(js, 0))
-            theta = ro.get('theta', torch.cat(ths, 0)) if need_cam else None
-            phi = ro.get('phi', torch.cat(phs, 0)) if need_cam else None
+            th_raw = ro.get('theta', torch.cat(ths, 0) if ths else None) if need_cam else None
+            ph_raw = ro.get('phi', torch.cat(phs, 0) if phs else None) if need_cam else None
             noise_c = ro.get('noise_c', torch.cat(ncs, 1).view(b, n, S, 1)) if hierarchical_sample else None
             u = ro.get('u', torch.cat(us, 0)) if hierarchical_sample else None
             noise_f = ro.get('noise_f', torch.cat(nfs, 1).view(b, n, E, 1))
@@ -485,6 +485,11 @@ class GeneratorNerfINR(nn.Module):
         # ---------------- camera (O(b) host math) ----------------
         with torch.no_grad():
             if need_cam:
+                if mode == 'mean':
+                    theta = torch.ones((b, 1), device=device) * h_mean
+                    phi = torch.ones((b, 1), device=device) * v_mean
+                else:
+                    theta, phi = cam_angles(th_raw, ph_raw)
                 origin, pitch = camera_origin_from_angles(theta, phi)
                 yaw = theta
                 forward_vector = _normalize(-origin)
@@ -492,7 +497,9 @@ class GeneratorNerfINR(nn.Module):
                 origin = camera_pos
                 pitch = yaw = torch.zeros(b, 1, device=device)
                 forward_vector = _normalize(camera_lookup)
-            cam2world = create_cam2world_matrix(forward_vector, origin, up_vector=up_vector)
+            # reference quirk kept: only the staged branch of whole_grad_forward hands `up_vector` on
+            # (generator.py:1437 vs :1481-1497); the one-shot branch always uses (0, 1, 0)
+            cam2world = create_cam2world_matrix(forward_vector, origin, up_vector=up_vector if staged else None)
             xg = torch.linspace(-1, 1, W, device=device)
             yg = torch.linspace(1, -1, H, device=device)
             zg = torch.linspace(ray_start, ray_end, S, device=device)

@@ -64,9 +64,10 @@ def _unit(v):
 
 
 def rays(b, img_size, fov, ray_start, ray_end, S, jitter, theta_n, phi_n, h_stddev, v_stddev,
-         h_mean=math.pi * 0.5, v_mean=math.pi * 0.5):
+         h_mean=math.pi * 0.5, v_mean=math.pi * 0.5, camera_pos=None, camera_lookup=None, up_vector=None):
     """-> points (b,n,S,3) world, z (b,n,S,1), dirs (b,n,3), origins (b,n,3), pitch, yaw.
-    jitter = rand(b,n,S,1); theta_n/phi_n = the raw randn(b,1) draws ('gaussian' camera)."""
+    jitter = rand(b,n,S,1); theta_n/phi_n = the raw randn(b,1) draws ('gaussian' camera).
+    With camera_pos / camera_lookup (comm_utils.py:626-641) the camera is explicit and pitch = yaw = 0."""
     W = H = img_size
     gx, gy = torch.meshgrid(torch.linspace(-1, 1, W), torch.linspace(1, -1, H), indexing="ij")
     x = gx.T.flatten()
@@ -82,14 +83,19 @@ def rays(b, img_size, fov, ray_start, ray_end, S, jitter, theta_n, phi_n, h_stdd
     z = z + off
     pts = pts + off * d_cam.unsqueeze(2)
     # camera on the unit sphere (sample_camera_positions, mode gaussian)
-    theta = theta_n * h_stddev + h_mean
-    phi = torch.clamp(phi_n * v_stddev + v_mean, 1e-5, math.pi - 1e-5)
-    o = torch.zeros(b, 3)
-    o[:, 0:1] = torch.sin(phi) * torch.cos(theta)
-    o[:, 2:3] = torch.sin(phi) * torch.sin(theta)
-    o[:, 1:2] = torch.cos(phi)
-    fwd = _unit(-o)
-    up0 = torch.tensor([0., 1., 0.]).expand_as(fwd)
+    if camera_pos is None or camera_lookup is None:
+        theta = theta_n * h_stddev + h_mean
+        phi = torch.clamp(phi_n * v_stddev + v_mean, 1e-5, math.pi - 1e-5)
+        o = torch.zeros(b, 3)
+        o[:, 0:1] = torch.sin(phi) * torch.cos(theta)
+        o[:, 2:3] = torch.sin(phi) * torch.sin(theta)
+        o[:, 1:2] = torch.cos(phi)
+        fwd = _unit(-o)
+    else:
+        o = camera_pos
+        theta = phi = torch.zeros(b, 1)
+        fwd = _unit(camera_lookup)
+    up0 = (torch.tensor([0., 1., 0.]) if up_vector is None else up_vector).expand_as(fwd)
     left = _unit(torch.cross(up0, fwd, dim=-1))
     up = _unit(torch.cross(fwd, left, dim=-1))
     rot = torch.eye(4).unsqueeze(0).repeat(b, 1, 1)
@@ -229,7 +235,7 @@ def inr_head(sd, fea, w_inr, prefix="inr_net.", return_all=False):
 # generator.forward — exp/cips3d/models/generator.py:1256-1370, 1378-1534, 1659-1762
 # ----------------------------------------------------------------------------------------
 def _points_forward(sd, w_nerf, w_inr, pts, z, origins, dirs, b, n, S, hierarchical_sample, nerf_noise, clamp_mode,
-                    noise_c, u, noise_f, return_aux_img, nerf_nograd, keep=None):
+                    noise_c, u, noise_f, return_aux_img, nerf_nograd, keep=None, last_back=False, white_back=False):
     """points_forward (exp/cips3d/models/generator.py:1659-1762) for n rays per image:
     -> inr rgb (b,n,3), aux rgb (b,n,3) or None"""
     ctx = torch.no_grad() if nerf_nograd else torch.enable_grad()
@@ -247,7 +253,8 @@ def _points_forward(sd, w_nerf, w_inr, pts, z, origins, dirs, b, n, S, hierarchi
         all_o = torch.gather(all_o, -2, idx.expand(-1, -1, -1, all_o.shape[-1]))
     else:
         all_o, all_z, idx, fz, fp, book, fine = coarse, z, None, None, None, None, None
-    fea, depth, weights = integrate(all_o, all_z, noise_f, nerf_noise, clamp_mode=clamp_mode)
+    fea, depth, weights = integrate(all_o, all_z, noise_f, nerf_noise, clamp_mode=clamp_mode, last_back=last_back,
+                                    white_back=white_back)
     inr = inr_head(sd, fea, w_inr)
     aux = None
     if return_aux_img:
@@ -261,8 +268,16 @@ def _points_forward(sd, w_nerf, w_inr, pts, z, origins, dirs, b, n, S, hierarchi
 
 def generator_forward(sd, zs, rand, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                       hierarchical_sample, nerf_noise=0., clamp_mode="relu", return_aux_img=False,
-                      freeze_nerf=False, keep=False, grad_points=None):
+                      freeze_nerf=False, keep=False, grad_points=None, last_back=False, white_back=False, psi=1.,
+                      avg_styles=None, camera=None, forward_points=None):
     """Returns dict(imgs, pitch_yaw, + intermediates when keep).  `sd` values may require grad.
+
+    psi < 1: truncation towards `avg_styles` = (avg_w_nerf (1,128), avg_w_inr (1,512)), the batch mean of the
+    mapping networks over 10 000 latents (generator.py:1320-1323, 1804-1817; generator_nerf_inr.py:770-782).
+    camera = dict(camera_pos, camera_lookup, up_vector): forward_camera_pos_and_lookup (generator.py:1828-1951).
+    The staged forward (`forward_points`, generator.py:1406-1473) computes the same image chunk by chunk; its
+    observable differences are the order of the random draws, which `rand` already carries in assembled form, and
+    that ONLY it hands `up_vector` to the camera matrix (generator.py:1437; the one-shot branch :1481-1497 drops it).
 
     grad_points (< img_size^2): part_grad_forward (generator.py:1536-1657) — `rand["rand_idx"]` (the randperm)
     splits the pixels into a subset rendered with gradients (draws rand["noise_c_grad"/"u_grad"/"noise_f_grad"])
@@ -276,15 +291,20 @@ def generator_forward(sd, zs, rand, img_size, fov, ray_start, ray_end, num_steps
     else:
         w_nerf = mapping_nerf(sd, zs["z_nerf"])
     w_inr = mapping_inr(sd, zs["z_inr"])
+    if psi < 1:
+        w_nerf = avg_styles[0] + psi * (w_nerf - avg_styles[0])
+        w_inr = avg_styles[1] + psi * (w_inr - avg_styles[1])
     with torch.no_grad():
-        r = rays(b, img_size, fov, ray_start, ray_end, S, rand["jitter"], rand["theta"], rand["phi"],
-                 h_stddev, v_stddev)
+        r = rays(b, img_size, fov, ray_start, ray_end, S, rand["jitter"], rand.get("theta"), rand.get("phi"),
+                 h_stddev, v_stddev, **{k: (v if (k != "up_vector" or forward_points is not None) else None)
+                                        for k, v in (camera or {}).items()})
     out = {}
     kept = {} if keep else None
     if grad_points is None or grad_points >= n:
         inr, aux = _points_forward(sd, w_nerf, w_inr, r["points"], r["z"], r["origins"], r["dirs"], b, n, S,
                                    hierarchical_sample, nerf_noise, clamp_mode, rand.get("noise_c"), rand.get("u"),
-                                   rand["noise_f"], return_aux_img, freeze_nerf, kept)
+                                   rand["noise_f"], return_aux_img, freeze_nerf, kept, last_back=last_back,
+                                   white_back=white_back)
     else:
         ridx = rand["rand_idx"]
         parts = []

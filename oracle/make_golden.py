@@ -6,6 +6,7 @@ with every torch.rand / torch.randn draw captured, and writes small fixtures to 
 Weights are NOT stored: the product modules reproduce the reference's initial state_dict
 bit-for-bit under the same torch seed (checked here and stored as per-key checksums).
 """
+import math
 import os
 import sys
 
@@ -170,6 +171,79 @@ def make_generator_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, freeze
     print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "imgs", tuple(imgs.shape))
 
 
+def make_generator_eval_case(tag, seed, b, img_size, S, hier, psi, forward_points, nerf_noise, aux, clamp_mode,
+                             last_back, white_back, camera=False):
+    """Inference path: truncation psi < 1 through generate_avg_frequencies (generator.py:1320-1323,
+    1804-1817), the staged no-grad forward in chunks of `forward_points` pixels (generator.py:1406-1473) with its
+    per-image / per-chunk draw order, the composite's clamp_mode / last_back / white_back options, and — with
+    `camera` — forward_camera_pos_and_lookup (generator.py:1828-1951) with an explicit camera and up vector."""
+    torch.manual_seed(seed)
+    G = ref_gen.GeneratorNerfINR(**g_cfg(), device="cpu")
+    G.eval()
+    sums = checksums(G.state_dict())
+    torch.manual_seed(seed + 1)
+    zs = G.get_zs(b)
+    n = img_size * img_size
+    E = 2 * S if hier else S
+    kw = dict(fov=12, ray_start=0.88, ray_end=1.12, num_steps=S, h_stddev=0.3, v_stddev=0.155,
+              hierarchical_sample=hier, psi=psi, sample_dist="gaussian", clamp_mode=clamp_mode,
+              last_back=last_back, white_back=white_back)
+    cam = None
+    if camera:
+        g = torch.Generator().manual_seed(seed + 2)
+        pos = torch.nn.functional.normalize(torch.randn(b, 3, generator=g), dim=-1)
+        cam = dict(camera_pos=pos, camera_lookup=-pos + 0.05 * torch.randn(b, 3, generator=g),
+                   up_vector=torch.nn.functional.normalize(torch.tensor([[0.1, 1.0, 0.05]]), dim=-1)[0 if forward_points is None else slice(None)])
+    with Capture() as cap, torch.no_grad():
+        if camera:
+            kw.update(h_mean=math.pi * 0.5, v_mean=math.pi * 0.5)
+            imgs, pitch_yaw = G.forward_camera_pos_and_lookup(zs, img_size=img_size, nerf_noise=nerf_noise, return_aux_img=aux,
+                                                              grad_points=None, forward_points=forward_points, **kw, **cam)
+        else:
+            imgs, pitch_yaw = G(zs, img_size=img_size, nerf_noise=nerf_noise, return_aux_img=aux, grad_points=None,
+                                forward_points=forward_points, **kw)
+    draws = list(cap.draws)
+    fix_avg = None
+    if psi < 1:
+        (_, azn), (_, azi) = draws[0], draws[1]
+        assert azn.shape == (10000, 256) and azi.shape == (10000, 512)
+        # 30 MB of latents are not stored: they are the next two CPU draws after get_zs(b) under seed + 1 (the test
+        # regenerates them and checks these checksums); the reference's averaged styles are stored as the answer
+        fix_avg = dict(z_checksums=checksums(dict(z_nerf=azn, z_inr=azi)),
+                       styles={k: v.detach().clone() for k, v in G.avg_styles.items()})
+        draws = draws[2:]
+    # staged order: per image [jitter, (theta, phi)], then per chunk [noise_c, u] (if hierarchical) and noise_f
+    js, ths, phs, ncs, us, nfs = [], [], [], [], [], []
+    it = iter(draws)
+    if forward_points is not None:
+        for _ in range(b):
+            js.append(next(it)[1])
+            if not camera:
+                ths.append(next(it)[1]); phs.append(next(it)[1])
+            head = 0
+            while head < n:
+                if hier:
+                    ncs.append(next(it)[1]); us.append(next(it)[1])
+                nfs.append(next(it)[1])
+                head += forward_points
+        rand = dict(jitter=torch.cat(js, 0), noise_f=torch.cat(nfs, 1).reshape(b, n, E, 1))
+        if not camera:
+            rand.update(theta=torch.cat(ths, 0), phi=torch.cat(phs, 0))
+        if hier:
+            rand.update(noise_c=torch.cat(ncs, 1).reshape(b, n, S, 1), u=torch.cat(us, 0))
+    else:
+        names = ["jitter"] + ([] if camera else ["theta", "phi"]) + (["noise_c", "u"] if hier else []) + ["noise_f"]
+        rand = {nm: next(it)[1] for nm in names}
+    assert next(it, None) is None, "unconsumed reference draws"
+    fix = dict(tag=tag, seed=seed, b=b, img_size=img_size, S=S, hier=hier, nerf_noise=nerf_noise, aux=aux, freeze=False,
+               forward_points=forward_points, camera=cam, G_kwargs=kw, state_checksums=sums,
+               zs={k: v.clone() for k, v in zs.items()}, avg=fix_avg, rand=rand, imgs=imgs.detach().clone(),
+               pitch_yaw=pitch_yaw.detach().clone())
+    path = os.path.join(OUT, f"{tag}.pt")
+    torch.save(fix, path)
+    print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "imgs", tuple(imgs.shape))
+
+
 def make_discriminator_case(tag, seed, b, size, alpha, use_aux):
     torch.manual_seed(seed)
     D = ref_disc.Discriminator_MultiScale_Aux(**d_cfg())
@@ -215,6 +289,12 @@ if __name__ == "__main__":
     make_generator_case("g_r8_freeze", seed=3, b=2, img_size=8, S=4, hier=True, nerf_noise=0.0, aux=False, freeze=True)
     make_generator_part_case("g_r16_part", seed=21, b=2, img_size=16, S=5, hier=True, nerf_noise=0.2, aux=True,
                              grad_points=96)
+    make_generator_eval_case("g_r8_eval_psi_staged", seed=31, b=2, img_size=8, S=4, hier=True, psi=0.7, forward_points=24,
+                             nerf_noise=0.0, aux=True, clamp_mode="relu", last_back=True, white_back=False)
+    make_generator_eval_case("g_r8_eval_camera", seed=32, b=2, img_size=8, S=5, hier=True, psi=1.0, forward_points=None,
+                             nerf_noise=0.15, aux=False, clamp_mode="softplus", last_back=False, white_back=True, camera=True)
+    make_generator_eval_case("g_r8_eval_camera_staged", seed=33, b=1, img_size=8, S=4, hier=True, psi=1.0, forward_points=40,
+                             nerf_noise=0.1, aux=True, clamp_mode="relu", last_back=False, white_back=False, camera=True)
     make_discriminator_case("d_r16", seed=11, b=2, size=16, alpha=1.0, use_aux=False)
     make_discriminator_case("d_r16_aux_alpha", seed=12, b=2, size=16, alpha=0.5, use_aux=True)
     make_op_cases()

@@ -223,3 +223,40 @@ def test_generator_full_size_properties(S, hier):
     print(f"   worst parameters: {sorted(rows, reverse=True)[:3]}")
     print(f"C2 full size S={S} hier={hier}: sum of quarter-batch gradients vs batch gradient, worst rel err {worst:.2e}")
     assert worst < 2e-2
+
+
+@pytest.mark.parametrize("tag", ["g_r8_eval_psi_staged", "g_r8_eval_camera", "g_r8_eval_camera_staged"])
+def test_generator_eval_paths_match_reference_golden(tag, inr_mode):
+    """Inference path against vectors minted from the reference: psi truncation through
+    generate_avg_frequencies, the staged forward (forward_points, ragged last chunk) with its per-image / per-chunk draw
+    order, last_back / white_back / softplus, forward_camera_pos_and_lookup (one-shot: up_vector dropped like the
+    reference does; staged: honoured)."""
+    from test_oracle_golden import eval_avg_styles
+    fix = load_golden(tag)
+    d = torch.device("cuda:0")
+    G = seeded_generator(fix["seed"], device=d)
+    check_checksums(G.state_dict(), fix["state_checksums"])
+    kw = dict(fix["G_kwargs"])
+    zs = {k: v.to(d) for k, v in fix["zs"].items()}
+    rand = {k: v.to(d) for k, v in fix["rand"].items()}
+    az = eval_avg_styles(fix, seeded_generator(fix["seed"]))
+    if az is not None:                      # the 10 000 averaging latents the reference drew (regenerated on the CPU)
+        real_get_zs = G.get_zs
+        G.get_zs = lambda n, **k: {k_: v.to(d) for k_, v in az.items()} if n == 10000 else real_get_zs(n, **k)
+    common = dict(img_size=fix["img_size"], nerf_noise=fix["nerf_noise"], return_aux_img=fix["aux"], grad_points=None,
+                  forward_points=fix["forward_points"], rand_override=rand)
+    with torch.no_grad():
+        if fix["camera"] is not None:
+            cam = {k: v.to(d) for k, v in fix["camera"].items()}
+            imgs, py = G.forward_camera_pos_and_lookup(zs, **common, **kw, **cam)
+        else:
+            imgs, py = G(zs, **common, **kw)
+    if az is not None:
+        ref = fix["avg"]["styles"]
+        for k, v in G.avg_styles.items():
+            assert max_rel(v, ref[k]) < 1e-4, k
+    e = max_rel(imgs, fix["imgs"])
+    print(f"{tag} [{inr_mode}]: imgs max_rel {e:.3e}")
+    assert imgs.shape == fix["imgs"].shape and e < TOL
+    assert max_rel(py, fix["pitch_yaw"]) < 1e-5 or float(fix["pitch_yaw"].abs().max()) == 0.0
+    assert torch.equal(py.cpu() == 0, fix["pitch_yaw"] == 0)

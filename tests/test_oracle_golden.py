@@ -46,6 +46,50 @@ def test_generator_oracle_matches_reference(tag):
         assert float((got - d["sample"]).norm() / d["sample"].norm().clamp_min(1e-30)) < 1e-3, name
 
 
+EVAL_CASES = ["g_r8_eval_psi_staged", "g_r8_eval_camera", "g_r8_eval_camera_staged"]
+
+
+def eval_avg_styles(fix, G):
+    """The 10 000 latents behind the reference's truncation average are not stored (30 MB): they are the two CPU draws
+    that follow get_zs(b) under seed + 1.  Regenerate, check against the stored checksums, return them."""
+    if fix["avg"] is None:
+        return None
+    torch.manual_seed(fix["seed"] + 1)
+    G.get_zs(fix["b"])
+    az = {"z_nerf": torch.randn(10000, 256), "z_inr": torch.randn(10000, 512)}
+    for k, (s1, s2) in fix["avg"]["z_checksums"].items():
+        assert abs(float(az[k].double().sum()) - s1) < 1e-6 * abs(s2) and abs(float(az[k].double().abs().sum()) - s2) < 1e-9 * s2, \
+            "CPU RNG stream differs from the one the fixture was minted with"
+    return az
+
+
+@pytest.mark.parametrize("tag", EVAL_CASES)
+def test_generator_oracle_eval_paths(tag):
+    """Inference path: psi truncation + staged forward with last_back; explicit camera, softplus
+    clamp, white_back and noise (one-shot: the reference drops `up_vector` there; staged, one image: it is honoured)."""
+    fix = load_golden(tag)
+    G = seeded_generator(fix["seed"])
+    check_checksums(G.state_dict(), fix["state_checksums"])
+    sd = {k: v for k, v in G.named_parameters()}
+    kw = fix["G_kwargs"]
+    avg = None
+    az = eval_avg_styles(fix, G)
+    with torch.no_grad():
+        if az is not None:
+            avg = (orc.mapping_nerf(sd, az["z_nerf"]).mean(0, keepdim=True), orc.mapping_inr(sd, az["z_inr"]).mean(0, keepdim=True))
+            ref = fix["avg"]["styles"]
+            assert max_rel(avg[0], next(v for k, v in ref.items() if k.startswith("nerf"))) < 1e-5
+            assert max_rel(avg[1], next(v for k, v in ref.items() if k.startswith("inr"))) < 1e-5
+        out = orc.generator_forward(sd, fix["zs"], fix["rand"], fix["img_size"], kw["fov"], kw["ray_start"], kw["ray_end"],
+                                    kw["num_steps"], kw["h_stddev"], kw["v_stddev"], kw["hierarchical_sample"],
+                                    nerf_noise=fix["nerf_noise"], clamp_mode=kw["clamp_mode"], return_aux_img=fix["aux"],
+                                    last_back=kw["last_back"], white_back=kw["white_back"], psi=kw["psi"], avg_styles=avg,
+                                    camera=fix["camera"], forward_points=fix["forward_points"])
+    assert max_rel(out["imgs"], fix["imgs"]) < 1e-5
+    assert max_rel(out["pitch_yaw"], fix["pitch_yaw"]) < 1e-6 or float(fix["pitch_yaw"].abs().max()) == 0.0
+    assert torch.equal(out["pitch_yaw"] == 0, fix["pitch_yaw"] == 0)
+
+
 def test_upfirdn2d_oracle_matches_reference_native():
     for c in load_golden("upfirdn2d_cases"):
         x = c["x"]                       # (major, h, w, minor) as the reference op sees it
