@@ -440,7 +440,7 @@ def _rand_translation(x, ratio=0.125):
     return xp.permute(0, 2, 3, 1).contiguous()[gb, gx, gy].permute(0, 3, 1, 2)
 
 
-def _rand_cutout(x, ratio=0.5):
+def _rand_cutout(x, ratio=0.2):      # the reference's default (diffaug.py:64), not the DiffAugment paper's 0.5
     cs = int(x.size(2) * ratio + 0.5), int(x.size(3) * ratio + 0.5)
     ox = torch.randint(0, x.size(2) + (1 - cs[0] % 2), size=[x.size(0), 1, 1], device=x.device)
     oy = torch.randint(0, x.size(3) + (1 - cs[1] % 2), size=[x.size(0), 1, 1], device=x.device)

@@ -429,8 +429,45 @@ def equal_linear(sd, prefix, x, activation=False):
     return F.linear(x, w * scale, bias=sd[prefix + "bias"])
 
 
-def disc_multiscale(sd, prefix, x, alpha=1., first_downsample=False):
-    """Discriminator_MultiScale.forward (discriminator.py:502-585), stddev_group 0, diffaug off."""
+def diff_augment(x, draws, policy="color,translation,cutout"):
+    """DiffAugment (exp/cips3d/models/diffaug.py:9-85) with its random draws handed in: `draws` is an iterator over
+    the tensors the reference drew, in its order — color: 3 x rand(b,1,1,1) (brightness, saturation, contrast);
+    translation: 2 x randint(b,1,1) (rows, columns; shift up to 1/8 of the size); cutout: 2 x randint(b,1,1) (the
+    centre of a square hole of 0.2 x the size)."""
+    b, c, h, w = x.shape
+    for p in policy.split(","):
+        if p == "color":
+            x = x + (next(draws) - 0.5)
+            m = x.mean(dim=1, keepdim=True)
+            x = (x - m) * (next(draws) * 2) + m
+            m = x.mean(dim=[1, 2, 3], keepdim=True)
+            x = (x - m) * (next(draws) + 0.5) + m
+        elif p == "translation":
+            tx, ty = next(draws), next(draws)
+            gb, gx, gy = torch.meshgrid(torch.arange(b), torch.arange(h), torch.arange(w), indexing="ij")
+            gx = torch.clamp(gx + tx + 1, 0, h + 1)
+            gy = torch.clamp(gy + ty + 1, 0, w + 1)
+            xp = F.pad(x, [1, 1, 1, 1, 0, 0, 0, 0])
+            x = xp.permute(0, 2, 3, 1).contiguous()[gb, gx, gy].permute(0, 3, 1, 2)
+        elif p == "cutout":
+            ch, cw = int(h * 0.2 + 0.5), int(w * 0.2 + 0.5)
+            ox, oy = next(draws), next(draws)
+            gb, gx, gy = torch.meshgrid(torch.arange(b), torch.arange(ch), torch.arange(cw), indexing="ij")
+            gx = torch.clamp(gx + ox - ch // 2, min=0, max=h - 1)
+            gy = torch.clamp(gy + oy - cw // 2, min=0, max=w - 1)
+            mask = torch.ones(b, h, w, dtype=x.dtype)
+            mask[gb, gx, gy] = 0
+            x = x * mask.unsqueeze(1)
+        else:
+            raise KeyError(p)
+    return x.contiguous()
+
+
+def disc_multiscale(sd, prefix, x, alpha=1., first_downsample=False, draws=None):
+    """Discriminator_MultiScale.forward (discriminator.py:502-585), stddev_group 0; `draws`: DiffAugment on the input
+    (discriminator.py:507-508) with these recorded draws."""
+    if draws is not None:
+        x = diff_augment(x, draws)
     size = x.shape[-1]
     ls = int(math.log(size, 2))
     cur = conv_layer(sd, f"{prefix}conv_in.{2 ** ls}.", x, 1)
@@ -449,11 +486,13 @@ def disc_multiscale(sd, prefix, x, alpha=1., first_downsample=False):
     return equal_linear(sd, f"{prefix}out_linear.", out)
 
 
-def discriminator_forward(sd, x, alpha=1., use_aux_disc=False):
-    """Discriminator_MultiScale_Aux.forward (discriminator.py:647-664)."""
+def discriminator_forward(sd, x, alpha=1., use_aux_disc=False, draws=None):
+    """Discriminator_MultiScale_Aux.forward (discriminator.py:647-664).  `draws` (diffaug=True): the recorded random
+    tensors, main discriminator's first."""
+    it = iter(draws) if draws is not None else None
     if use_aux_disc:
         b = x.shape[0] // 2
-        m = disc_multiscale(sd, "main_disc.", x[:b], alpha, first_downsample=False)
-        a = disc_multiscale(sd, "aux_disc.", x[b:], alpha, first_downsample=True)
+        m = disc_multiscale(sd, "main_disc.", x[:b], alpha, first_downsample=False, draws=it)
+        a = disc_multiscale(sd, "aux_disc.", x[b:], alpha, first_downsample=True, draws=it)
         return torch.cat([m, a], dim=0)
-    return disc_multiscale(sd, "main_disc.", x, alpha, first_downsample=False)
+    return disc_multiscale(sd, "main_disc.", x, alpha, first_downsample=False, draws=it)

@@ -42,11 +42,15 @@ def d_cfg():
 
 
 class Capture:
-    """Record torch.rand / torch.randn / torch.randperm results in call order."""
+    """Record torch.rand / torch.randn / torch.randperm / torch.randint results in call order."""
 
     def __enter__(self):
         self.draws = []
-        self._rand, self._randn, self._randperm = torch.rand, torch.randn, torch.randperm
+        self._rand, self._randn, self._randperm, self._randint = torch.rand, torch.randn, torch.randperm, torch.randint
+
+        def randint(*a, **k):
+            t = self._randint(*a, **k); self.draws.append(("randint", t.clone())); return t
+        torch.randint = randint
 
         def randperm(*a, **k):
             t = self._randperm(*a, **k); self.draws.append(("randperm", t.clone())); return t
@@ -62,7 +66,7 @@ class Capture:
         return self
 
     def __exit__(self, *exc):
-        torch.rand, torch.randn, torch.randperm = self._rand, self._randn, self._randperm
+        torch.rand, torch.randn, torch.randperm, torch.randint = self._rand, self._randn, self._randperm, self._randint
 
 
 def checksums(sd):
@@ -244,19 +248,42 @@ def make_generator_eval_case(tag, seed, b, img_size, S, hier, psi, forward_point
     print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "imgs", tuple(imgs.shape))
 
 
-def make_discriminator_case(tag, seed, b, size, alpha, use_aux):
+def make_diffaug_case():
+    """exp/cips3d/models/diffaug.py:9-85: output and input gradient under recorded draws."""
+    from exp.cips3d.models import diffaug as ref_da
+    torch.manual_seed(17)
+    cases = []
+    for shape, policy in [((3, 3, 16, 16), "color,translation,cutout"), ((2, 3, 10, 12), "translation,cutout"),
+                          ((2, 3, 8, 8), "color")]:
+        x = (torch.rand(*shape) * 2 - 1).requires_grad_(True)
+        with Capture() as cap:
+            y = ref_da.DiffAugment(x, policy=policy)
+        g0 = torch.randn_like(y)
+        gx, = torch.autograd.grad((y * g0).sum(), x)
+        cases.append(dict(x=x.detach().clone(), policy=policy, draws=[(k, t) for k, t in cap.draws], y=y.detach().clone(),
+                          g0=g0, gx=gx.clone()))
+    path = os.path.join(OUT, "diffaug_cases.pt")
+    torch.save(cases, path)
+    print("diffaug ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def make_discriminator_case(tag, seed, b, size, alpha, use_aux, diffaug=False):
     torch.manual_seed(seed)
-    D = ref_disc.Discriminator_MultiScale_Aux(**d_cfg())
+    cfg = d_cfg()
+    cfg["diffaug"] = diffaug
+    D = ref_disc.Discriminator_MultiScale_Aux(**cfg)
     sums = checksums(D.state_dict())
     torch.manual_seed(seed + 1)
     x = (torch.rand(b * (2 if use_aux else 1), 3, size, size) * 2 - 1).requires_grad_(True)
-    out, _, _ = D(x, alpha=alpha, use_aux_disc=use_aux)
+    with Capture() as cap:
+        out, _, _ = D(x, alpha=alpha, use_aux_disc=use_aux)
     # R1 path of train.py:385-409
     grad_real, = torch.autograd.grad(outputs=out.sum(), inputs=x, create_graph=True)
     pen = grad_real.flatten(1).pow(2).sum(1)
     loss = torch.nn.functional.softplus(-out).mean() + 0.5 * 10. * pen.mean()
     loss.backward()
-    fix = dict(tag=tag, seed=seed, b=b, size=size, alpha=alpha, use_aux=use_aux, state_checksums=sums,
+    fix = dict(tag=tag, seed=seed, b=b, size=size, alpha=alpha, use_aux=use_aux, state_checksums=sums, diffaug=diffaug,
+               draws=[(k, t) for k, t in cap.draws],
                x=x.detach().clone(), out=out.detach().clone(), grad_real=grad_real.detach().clone(),
                loss=float(loss), grads=grad_digest(D.named_parameters(), stride=997))
     path = os.path.join(OUT, f"{tag}.pt")
@@ -297,4 +324,6 @@ if __name__ == "__main__":
                              nerf_noise=0.1, aux=True, clamp_mode="relu", last_back=False, white_back=False, camera=True)
     make_discriminator_case("d_r16", seed=11, b=2, size=16, alpha=1.0, use_aux=False)
     make_discriminator_case("d_r16_aux_alpha", seed=12, b=2, size=16, alpha=0.5, use_aux=True)
+    make_discriminator_case("d_r16_diffaug", seed=13, b=2, size=16, alpha=0.7, use_aux=True, diffaug=True)
+    make_diffaug_case()
     make_op_cases()

