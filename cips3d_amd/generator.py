@@ -8,6 +8,7 @@ parameters (same names, shapes and initialisers, created in the reference's orde
 same torch seed yields the same initial weights) and orchestrate kernel launches.
 """
 import math
+import random
 from collections import OrderedDict
 
 import numpy as np
@@ -313,6 +314,52 @@ def camera_origin_from_angles(theta, phi, r=1.0):
     return out, phi
 
 
+def _truncated_normal(shape, device):
+    """comm_utils.py:441-448: per element the first of four standard-normal draws that lies in (-2, 2) (the first
+    draw if none does)."""
+    tmp = torch.empty(tuple(shape) + (4,), device=device).normal_()
+    ok = (tmp < 2) & (tmp > -2)
+    first = ok.max(-1, keepdim=True)[1]
+    return tmp.gather(-1, first).squeeze(-1)
+
+
+def sample_camera_positions(device, bs=1, r=1, horizontal_stddev=1, vertical_stddev=1, horizontal_mean=math.pi * 0.5,
+                            vertical_mean=math.pi * 0.5, mode='normal'):
+    """comm_utils.py:451-535: camera origins on the sphere of radius r -> (origin (bs,3), phi = pitch (bs,1),
+    theta = yaw (bs,1)), every distribution of the reference with its draws in the reference's order
+    (yaw first; 'hybrid' flips Python's `random.random()` first; anything else is an assertion error)."""
+    hs, vs, hm, vm = horizontal_stddev, vertical_stddev, horizontal_mean, vertical_mean
+    u = lambda: torch.rand((bs, 1), device=device)
+    g = lambda: torch.randn((bs, 1), device=device)
+    if mode == 'uniform':
+        theta = (u() - 0.5) * 2 * hs + hm
+        phi = (u() - 0.5) * 2 * vs + vm
+    elif mode in ('normal', 'gaussian'):
+        theta = g() * hs + hm
+        phi = g() * vs + vm
+    elif mode == 'hybrid':
+        if random.random() < 0.5:
+            theta = (u() - 0.5) * 2 * hs * 2 + hm
+            phi = (u() - 0.5) * 2 * vs * 2 + vm
+        else:
+            theta = g() * hs + hm
+            phi = g() * vs + vm
+    elif mode == 'truncated_gaussian':
+        theta = _truncated_normal((bs, 1), device) * hs + hm
+        phi = _truncated_normal((bs, 1), device) * vs + vm
+    elif mode == 'spherical_uniform':
+        theta = (u() - 0.5) * 2 * hs + hm
+        v = (u() - 0.5) * 2 * (vs / math.pi) + vm / math.pi
+        phi = torch.arccos(1 - 2 * torch.clamp(v, 1e-5, 1 - 1e-5))
+    elif mode == 'mean':
+        theta = torch.ones((bs, 1), device=device) * hm
+        phi = torch.ones((bs, 1), device=device) * vm
+    else:
+        assert 0, f"camera distribution {mode!r}"
+    origin, phi = camera_origin_from_angles(theta, phi, r)
+    return origin, phi, theta
+
+
 def create_cam2world_matrix(forward_vector, origin, up_vector=None):
     """comm_utils.py:538-581"""
     device = origin.device
@@ -432,8 +479,11 @@ class GeneratorNerfINR(nn.Module):
 
         need_cam = camera_pos is None or camera_lookup is None
         mode = sample_dist
-        if need_cam and mode not in ('gaussian', 'normal', 'uniform', 'mean', None):
-            raise NotImplementedError(f"camera sample_dist {mode!r}")
+        # the two distributions the training configs use keep their raw draws separate (rand_override can inject
+        # them); the others go through sample_camera_positions as a whole
+        simple_cam = mode in ('gaussian', 'normal', 'uniform')
+        assert not need_cam or simple_cam or mode in ('hybrid', 'truncated_gaussian', 'spherical_uniform', 'mean'), \
+            f"camera distribution {mode!r}"          # comm_utils.py:526 (`assert 0`), incl. the default None
 
         def cam_angles(th_raw, ph_raw):
             if mode == 'uniform':
@@ -441,9 +491,10 @@ class GeneratorNerfINR(nn.Module):
             return th_raw * h_stddev + h_mean, ph_raw * v_stddev + v_mean
 
         def draw_cam(bs, override=True):
-            """-> the RAW draws (b,1) x 2 (or the fixed angles for mode 'mean')"""
-            if mode == 'mean':
-                return None, None
+            """-> the RAW draws (b,1) x 2, or for the other distributions the finished (theta, phi)"""
+            if not simple_cam:
+                _, ph, th = sample_camera_positions(device, bs, 1, h_stddev, v_stddev, h_mean, v_mean, mode)
+                return th, ph
             fn = torch.rand if mode == 'uniform' else torch.randn
             return draw('theta', fn, (bs, 1), override), draw('phi', fn, (bs, 1), override)
 
@@ -464,7 +515,7 @@ class GeneratorNerfINR(nn.Module):
             js, ths, phs, ncs, us, nfs = [], [], [], [], [], []
             for _ in range(b):
                 js.append(torch.rand((1, n, S, 1), device=device))
-                if need_cam and mode != 'mean':
+                if need_cam:
                     th, ph = draw_cam(1, override=False)
                     ths.append(th); phs.append(ph)
                 head = 0
@@ -476,8 +527,8 @@ class GeneratorNerfINR(nn.Module):
                     nfs.append(torch.randn((1, c, E, 1), device=device))
                     head += forward_points
             jitter = ro.get('jitter', torch.cat(js, 0))
-            th_raw = ro.get('theta', torch.cat(ths, 0) if ths else None) if need_cam else None
-            ph_raw = ro.get('phi', torch.cat(phs, 0) if phs else None) if need_cam else None
+            th_raw = ro.get('theta', torch.cat(ths, 0)) if need_cam else None
+            ph_raw = ro.get('phi', torch.cat(phs, 0)) if need_cam else None
             noise_c = ro.get('noise_c', torch.cat(ncs, 1).view(b, n, S, 1)) if hierarchical_sample else None
             u = ro.get('u', torch.cat(us, 0)) if hierarchical_sample else None
             noise_f = ro.get('noise_f', torch.cat(nfs, 1).view(b, n, E, 1))
@@ -485,11 +536,7 @@ class GeneratorNerfINR(nn.Module):
         # ---------------- camera (O(b) host math) ----------------
         with torch.no_grad():
             if need_cam:
-                if mode == 'mean':
-                    theta = torch.ones((b, 1), device=device) * h_mean
-                    phi = torch.ones((b, 1), device=device) * v_mean
-                else:
-                    theta, phi = cam_angles(th_raw, ph_raw)
+                theta, phi = cam_angles(th_raw, ph_raw) if simple_cam else (th_raw, ph_raw)
                 origin, pitch = camera_origin_from_angles(theta, phi)
                 yaw = theta
                 forward_vector = _normalize(-origin)

@@ -291,6 +291,23 @@ def make_discriminator_case(tag, seed, b, size, alpha, use_aux, diffaug=False):
     print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "out", out.detach().flatten().tolist())
 
 
+def make_camera_cases():
+    """sample_camera_positions (comm_utils.py:451-535), every distribution, under fixed torch / Python seeds on the CPU
+    generator: the test re-seeds and must reproduce the draws."""
+    import random
+    cases = []
+    for i, mode in enumerate(["uniform", "normal", "gaussian", "hybrid", "hybrid", "hybrid", "truncated_gaussian",
+                              "spherical_uniform", "mean"]):
+        seed = 100 + i
+        torch.manual_seed(seed); random.seed(seed)
+        o, phi, theta = comm_utils.sample_camera_positions("cpu", bs=5, r=1.3, horizontal_stddev=0.3, vertical_stddev=0.155,
+                                                           horizontal_mean=1.4, vertical_mean=1.7, mode=mode)
+        cases.append(dict(mode=mode, seed=seed, origin=o, phi=phi, theta=theta))
+    path = os.path.join(OUT, "camera_cases.pt")
+    torch.save(cases, path)
+    print("camera ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def make_op_cases():
     """Known-answer vectors for the two native ops from the reference's own restatement
     (upfirdn2d_native, upfirdn2d.py:152-186) and the kernel's switch (fused_bias_act_kernel.cu:36-47)."""
@@ -326,4 +343,5 @@ if __name__ == "__main__":
     make_discriminator_case("d_r16_aux_alpha", seed=12, b=2, size=16, alpha=0.5, use_aux=True)
     make_discriminator_case("d_r16_diffaug", seed=13, b=2, size=16, alpha=0.7, use_aux=True, diffaug=True)
     make_diffaug_case()
+    make_camera_cases()
     make_op_cases()

@@ -1,5 +1,7 @@
 """GPU: the drop-in generator (HIP path through the C-ABI) against the golden vectors minted
 from the reference and against the CPU oracle, forward and backward."""
+import math
+
 import pytest
 import torch
 
@@ -260,3 +262,22 @@ def test_generator_eval_paths_match_reference_golden(tag, inr_mode):
     assert imgs.shape == fix["imgs"].shape and e < TOL
     assert max_rel(py, fix["pitch_yaw"]) < 1e-5 or float(fix["pitch_yaw"].abs().max()) == 0.0
     assert torch.equal(py.cpu() == 0, fix["pitch_yaw"] == 0)
+
+
+def test_generator_camera_distributions_run():
+    """Every camera distribution of comm_utils.sample_camera_positions goes through the HIP path (one-shot and staged);
+    the default sample_dist=None is the reference's `assert 0`."""
+    d = torch.device("cuda:0")
+    G = seeded_generator(2, device=d)
+    kw = dict(img_size=8, fov=12, ray_start=0.88, ray_end=1.12, num_steps=4, h_stddev=0.3, v_stddev=0.155,
+              hierarchical_sample=True, nerf_noise=0.)
+    zs = G.get_zs(2)
+    with torch.no_grad():
+        for mode in ["uniform", "normal", "hybrid", "truncated_gaussian", "spherical_uniform", "mean"]:
+            for fp in (None, 40):
+                imgs, py = G(zs, sample_dist=mode, forward_points=fp, **kw)
+                assert imgs.shape == (2, 3, 8, 8) and torch.isfinite(imgs).all() and py.shape == (2, 2), (mode, fp)
+                if mode == "mean":
+                    assert torch.allclose(py, torch.full_like(py, math.pi / 2))
+        with pytest.raises(AssertionError):
+            G(zs, **kw)

@@ -99,3 +99,17 @@ def test_upfirdn2d_oracle_matches_reference_native():
         y = y.reshape(mj, mn, y.shape[2], y.shape[3]).permute(0, 2, 3, 1)
         assert y.shape == c["y"].shape
         assert max_rel(y, c["y"]) < 1e-6
+
+
+def test_camera_distributions_match_reference():
+    """sample_camera_positions (host math of the product, comm_utils.py:451-535): every distribution of the reference,
+    same draws in the same order under the same CPU seeds (torch and, for 'hybrid', Python's random)."""
+    import random
+    from cips3d_amd.generator import sample_camera_positions
+    for c in load_golden("camera_cases"):
+        torch.manual_seed(c["seed"]); random.seed(c["seed"])
+        o, phi, theta = sample_camera_positions("cpu", bs=5, r=1.3, horizontal_stddev=0.3, vertical_stddev=0.155,
+                                                horizontal_mean=1.4, vertical_mean=1.7, mode=c["mode"])
+        assert max_rel(o, c["origin"]) < 1e-6 and max_rel(phi, c["phi"]) < 1e-6 and max_rel(theta, c["theta"]) < 1e-6, c["mode"]
+    with pytest.raises(AssertionError):
+        sample_camera_positions("cpu", mode=None)
