@@ -61,6 +61,18 @@ class GemmX3Desc(C.Structure):
     ]
 
 
+class ConvX3Desc(C.Structure):
+    _fields_ = [("w_hi", vp), ("w_lo", vp), ("x_hi", vp), ("x_lo", vp), ("y", vp),
+                ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("O", i32), ("kh", i32), ("kw", i32),
+                ("stride", i32), ("pad", i32)]
+
+
+class ConvWgradDesc(C.Structure):
+    _fields_ = [("dy_hi", vp), ("dy_lo", vp), ("x_hi", vp), ("x_lo", vp), ("part", vp),
+                ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("O", i32), ("kh", i32), ("kw", i32),
+                ("stride", i32), ("pad", i32), ("nchunks", i32)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/cips3d_hip.h
 SIGNATURES = {
     "cips_version": (i32, []),
@@ -83,6 +95,8 @@ SIGNATURES = {
     "cips_gemm_bf16x3_set_wide": (None, [i32]),
     "cips_gemm_bf16x3_km": (i32, [C.POINTER(GemmX3Desc), vp]),
     "cips_gemm_bf16x3_km_grouped": (i32, [C.POINTER(GemmX3Desc), i32, vp]),
+    "cips_conv2d_x3": (i32, [C.POINTER(ConvX3Desc), vp]),
+    "cips_conv2d_x3_wgrad": (i32, [C.POINTER(ConvWgradDesc), vp]),
     "cips_split_planes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
     "cips_modfc_prep_x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cips_torgb_fwd_x3": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),

@@ -32,13 +32,24 @@ constexpr int PF = 36;                           // epilogue scratch pitch (fp32
 constexpr int SMEM_BYTES = NSTAGE * STAGE;
 
 constexpr int MAXG = 4;
+// Convolution weight gradient (CONV instantiation): the contraction runs over ALL output pixels q of the batch; the A
+// operand is dy as NHWC planes (row q, O columns), the B operand's row for (q, tap) is the input pixel
+// (oy*stride - pad + ky, ox*stride - pad + kx) of the NHWC planes of x, or the zero row behind the last image.  A
+// "group" is a tap, a "batch" entry a chunk of the pixel range (partial sums, added up by the caller).
+struct KConv {
+  int C, H, W, kw, stride, pad, Ho, Wo, ntap;
+  long long zero_row;          // row index of the zero row
+  long long kchunk;            // pixels per chunk
+};
 struct KArgs {
   cips_gemm_x3_desc d;               // shape, leading dimensions, strides (common to the group)
   const void *A_hi[MAXG], *A_lo[MAXG], *B_hi[MAXG], *B_lo[MAXG];
   float* C[MAXG];
   int tiles_m, tiles_n, ngroups, total;
+  KConv cv;
 };
 
+template <bool CONV>
 __global__ __launch_bounds__(512) void gemm_bf16x3_km_wide_kernel(KArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cips_gemm_x3_desc& d = g.d;
@@ -65,13 +76,15 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_km_wide_kernel(KArgs g) {
     const int tn = bid % g.tiles_n;
     const int tm = (bid / g.tiles_n) % g.tiles_m;
     const int bz = (bid / (g.tiles_n * g.tiles_m)) % d.batch;
-    const int gi = bid / (g.tiles_n * g.tiles_m * d.batch);       // problem of the group (uniform)
+    const int gi = bid / (g.tiles_n * g.tiles_m * d.batch);       // problem of the group (uniform); CONV: the tap
     const int m0 = tm * BM, n0 = tn * BN;
-    const u16* Ahi = (const u16*)g.A_hi[gi] + (long long)bz * d.strideA;
-    const u16* Alo = (const u16*)g.A_lo[gi] + (long long)bz * d.strideA;
-    const u16* Bhi = (const u16*)g.B_hi[gi] + (long long)bz * d.strideB;
-    const u16* Blo = (const u16*)g.B_lo[gi] + (long long)bz * d.strideB;
-    float* Cg = g.C[gi];
+    const int gp = CONV ? 0 : gi;
+    const u16* Ahi = (const u16*)g.A_hi[gp] + (long long)bz * d.strideA;
+    const u16* Alo = (const u16*)g.A_lo[gp] + (long long)bz * d.strideA;
+    const u16* Bhi = (const u16*)g.B_hi[gp] + (CONV ? 0 : (long long)bz * d.strideB);
+    const u16* Blo = (const u16*)g.B_lo[gp] + (CONV ? 0 : (long long)bz * d.strideB);
+    float* Cg = g.C[gp] + (CONV ? (long long)gi * d.M * d.ldc : 0);       // CONV: strideC spans all taps of a chunk
+    const int tap_ky = CONV ? gi / g.cv.kw : 0, tap_kx = CONV ? gi - tap_ky * g.cv.kw : 0;
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -101,11 +114,34 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_km_wide_kernel(KArgs g) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)p + off),
                                        (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
     };
+    // CONV: byte offset of this lane's B row for contraction row q (a global output-pixel index) — its column part
+    // comes from offB[] with the lane's k-row term removed (computed below with lh = 0 semantics)
+    unsigned colB[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) colB[par] = offB[par] - (unsigned)(lh * d.ldb) * 2u;
+    auto conv_row_off = [&](long long q, int par) -> unsigned {
+      const int hw = g.cv.Ho * g.cv.Wo;
+      const int b = (int)(q / hw), r = (int)(q - (long long)b * hw);
+      const int oy = r / g.cv.Wo, ox = r - oy * g.cv.Wo;
+      const int iy = oy * g.cv.stride - g.cv.pad + tap_ky, ix = ox * g.cv.stride - g.cv.pad + tap_kx;
+      const bool ok = (unsigned)iy < (unsigned)g.cv.H && (unsigned)ix < (unsigned)g.cv.W;
+      const long long row = ok ? ((long long)b * g.cv.H + iy) * g.cv.W + ix : g.cv.zero_row;
+      return (unsigned)(row * d.ldb * 2) + colB[par];
+    };
+    unsigned cvoff[2] = {0, 0};            // offsets of the two B pieces (idx = uw, uw + 8) of the k-tile being issued
+    auto conv_prep = [&](int k0) {
+      if constexpr (CONV) {
+        const long long qb = (long long)bz * g.cv.kchunk + k0 + lh;
+        cvoff[0] = conv_row_off(qb + 2 * uw, uw & 1);
+        cvoff[1] = conv_row_off(qb + 2 * (uw + 8), uw & 1);      // (uw + 8) & 1 == uw & 1
+      }
+    };
     auto dma_piece = [&](int pc, int k0, unsigned char* s) {      // pc = 0..7: pieces uw + 8*(pc>>2) of plane pc&3
       const int idx = uw + 8 * (pc >> 2), which = pc & 3;
       const long long rowoff = (long long)(k0 + 2 * idx);
       if (which == 0) dma(Ahi + rowoff * d.lda, offA[idx & 1], s + OFF_AHI + idx * 1024);
       else if (which == 1) dma(Alo + rowoff * d.lda, offA[idx & 1], s + OFF_ALO + idx * 1024);
+      else if constexpr (CONV) dma(which == 2 ? Bhi : Blo, cvoff[pc >> 2], s + (which == 2 ? OFF_BHI : OFF_BLO) + idx * 1024);
       else if (which == 2) dma(Bhi + rowoff * d.ldb, offB[idx & 1], s + OFF_BHI + idx * 1024);
       else dma(Blo + rowoff * d.ldb, offB[idx & 1], s + OFF_BLO + idx * 1024);
     };
@@ -139,6 +175,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_km_wide_kernel(KArgs g) {
     auto compute = [&](int stage, bool issue_next, int next_stage, int k0n) {
       unsigned char* sn = smem + next_stage * STAGE;
       const int so = stage * STAGE;
+      if (issue_next) conv_prep(k0n);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 ah[2], al[2], bh[4], bl[4];
@@ -162,6 +199,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_km_wide_kernel(KArgs g) {
     };
 
     if (nk > 0) {
+      conv_prep(0);
 #pragma unroll
       for (int pc = 0; pc < 8; ++pc) dma_piece(pc, 0, smem);
     }
@@ -239,9 +277,49 @@ extern "C" int cips_gemm_bf16x3_km_grouped(const cips_gemm_x3_desc* descs, int n
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     if (ncu <= 0) ncu = 256;
     ncu = (ncu / 8) * 8;
-    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_km_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_km_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
   }
   const int grid = g.total < ncu ? g.total : ncu;
-  hipLaunchKernelGGL(gemm_bf16x3_km_wide_kernel, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(gemm_bf16x3_km_wide_kernel<false>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
+  return CIPS_CHECK_LAUNCH();
+}
+
+// Convolution weight gradient (see include/cips3d_hip.h): part[chunk][tap][o][c] = sum over the chunk's output pixels q
+// of dy[q][o] * x[pixel(q) (+) tap][c]
+extern "C" int cips_conv2d_x3_wgrad(const cips_conv_wgrad_desc* c, cips_stream_t stream) {
+  if (!c || c->B <= 0 || c->C <= 0 || c->O <= 0 || c->H <= 0 || c->W <= 0 || c->kh <= 0 || c->kw <= 0 || c->stride <= 0 ||
+      c->pad < 0 || c->nchunks <= 0 || !c->part)
+    return (int)hipErrorInvalidValue;
+  const int Ho = (c->H + 2 * c->pad - c->kh) / c->stride + 1, Wo = (c->W + 2 * c->pad - c->kw) / c->stride + 1;
+  if (Ho <= 0 || Wo <= 0) return (int)hipErrorInvalidValue;
+  const long long Kall = (long long)c->B * Ho * Wo;
+  if ((c->C & 7) || (c->O & 7) || Kall % ((long long)c->nchunks * 32)) return (int)hipErrorNotSupported;
+  const long long rows_x = (long long)c->B * c->H * c->W + 1;
+  if (rows_x * c->C * 2 >= 0xffffffffLL || Kall * c->O * 2 >= 0x7fffffffffffLL) return (int)hipErrorNotSupported;
+  KArgs g = {};
+  cips_gemm_x3_desc& d = g.d;
+  const long long kchunk = Kall / c->nchunks;
+  d.M = c->O; d.N = c->C; d.K = (int)kchunk; d.lda = c->O; d.ldb = c->C; d.batch = c->nchunks;
+  d.strideA = kchunk * c->O; d.strideB = 0;
+  d.ldc = c->C; d.strideC = (long long)c->kh * c->kw * c->O * c->C;
+  g.A_hi[0] = c->dy_hi; g.A_lo[0] = c->dy_lo; g.B_hi[0] = c->x_hi; g.B_lo[0] = c->x_lo; g.C[0] = c->part;
+  g.cv.C = c->C; g.cv.H = c->H; g.cv.W = c->W; g.cv.kw = c->kw; g.cv.stride = c->stride; g.cv.pad = c->pad;
+  g.cv.Ho = Ho; g.cv.Wo = Wo; g.cv.ntap = c->kh * c->kw; g.cv.zero_row = rows_x - 1; g.cv.kchunk = kchunk;
+  g.tiles_m = (d.M + BM - 1) / BM;
+  g.tiles_n = (d.N + BN - 1) / BN;
+  g.ngroups = g.cv.ntap;
+  const long long total = (long long)g.tiles_m * g.tiles_n * d.batch * g.ngroups;
+  if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  g.total = (int)total;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+    ncu = (ncu / 8) * 8;
+    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_km_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+  }
+  const int grid = g.total < ncu ? g.total : ncu;
+  hipLaunchKernelGGL(gemm_bf16x3_km_wide_kernel<true>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
   return CIPS_CHECK_LAUNCH();
 }

@@ -50,9 +50,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <typename F, int... I>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
+// Implicit-GEMM convolution (CONV instantiation): the B operand's rows are output pixels of image `bz`, its
+// contraction index is (tap, channel); row r of k-tile (tap, c0) is the 32-channel slice at input pixel
+// (oy*stride - pad + ky, ox*stride - pad + kx) of the NHWC planes, or the zero row behind the last image.
+struct ConvGeom {
+  int C, H, W, kw, stride, pad, Wo;
+  long long img_stride;        // H*W*C elements
+  long long zero_elem;         // element offset of the zero row from the start of the planes
+};
 struct WArgs {
   cips_gemm_x3_desc d;
   int tiles_m, tiles_n, total, dbg;
+  ConvGeom cv;
 };
 
 __device__ __forceinline__ u16 f2bf(float v) {
@@ -64,7 +73,7 @@ __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned
 
 // HAS_ADD / HAS_MASK / HAS_RES: which global inputs the epilogue reads (fp32 addend, gate plane, residual planes);
 // compile-time so that only their prefetch registers exist.
-template <bool HAS_ADD, bool HAS_MASK, bool HAS_RES>
+template <bool HAS_ADD, bool HAS_MASK, bool HAS_RES, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cips_gemm_x3_desc& d = g.d;
@@ -92,13 +101,19 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
   // the global 16-byte chunk slot ^ ((row>>2)&3) — the swizzle lives in the source address.  Addresses are a uniform
   // plane pointer (advanced by k0 on the scalar side) plus one 32-bit byte offset per piece and lane; rows past
   // M / N are clamped (their products are never stored).
-  struct Src { const u16 *Ahi, *Alo, *Bhi, *Blo; unsigned offA[2], offB[2]; };
+  struct Src { const u16 *Ahi, *Alo, *Bhi, *Blo; unsigned offA[2], offB[2]; int iy0[2], ix0[2]; unsigned chunk[2], zero_rel; };
   auto make_src = [&](int tm, int tn, int bz, int lane, Src& sr) {
     const int m0 = tm * BM, n0 = tn * BN;
     sr.Ahi = (const u16*)d.A_hi + (long long)bz * d.strideA + (long long)m0 * d.lda;
     sr.Alo = (const u16*)d.A_lo + (long long)bz * d.strideA + (long long)m0 * d.lda;
-    sr.Bhi = (const u16*)d.B_hi + (long long)bz * d.strideB + (long long)n0 * d.ldb;
-    sr.Blo = (const u16*)d.B_lo + (long long)bz * d.strideB + (long long)n0 * d.ldb;
+    if constexpr (CONV) {
+      sr.Bhi = (const u16*)d.B_hi + (long long)bz * g.cv.img_stride;
+      sr.Blo = (const u16*)d.B_lo + (long long)bz * g.cv.img_stride;
+      sr.zero_rel = (unsigned)((g.cv.zero_elem - (long long)bz * g.cv.img_stride) * 2);
+    } else {
+      sr.Bhi = (const u16*)d.B_hi + (long long)bz * d.strideB + (long long)n0 * d.ldb;
+      sr.Blo = (const u16*)d.B_lo + (long long)bz * d.strideB + (long long)n0 * d.ldb;
+    }
     const int drow = lane >> 2, dslot = lane & 3;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -106,20 +121,44 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
       const int kcsw = dslot ^ ((row >> 2) & 3);
       const int ra = (row < M - m0) ? row : (M - m0 - 1), rb = (row < N - n0) ? row : (N - n0 - 1);
       sr.offA[p] = (unsigned)(ra * d.lda + kcsw * 8) * 2u;
-      sr.offB[p] = (unsigned)(rb * d.ldb + kcsw * 8) * 2u;
+      if constexpr (CONV) {
+        const int pix = n0 + rb, oy = pix / g.cv.Wo, ox = pix - oy * g.cv.Wo;
+        sr.iy0[p] = oy * g.cv.stride - g.cv.pad;
+        sr.ix0[p] = ox * g.cv.stride - g.cv.pad;
+        sr.chunk[p] = (unsigned)kcsw * 16u;
+      } else {
+        sr.offB[p] = (unsigned)(rb * d.ldb + kcsw * 8) * 2u;
+      }
+    }
+  };
+  // B-side addressing of k-tile k0: returns the element offset to add to the (uniform) plane pointers; for the
+  // convolution it refreshes the two per-lane byte offsets instead (tap = k0 / C, 32 channels from k0 % C)
+  auto prep_b = [&](Src& sr, int k0) -> int {
+    if constexpr (CONV) {
+      const int tap = k0 / g.cv.C, c0 = k0 - tap * g.cv.C;
+      const int ky = tap / g.cv.kw, kx = tap - ky * g.cv.kw;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int iy = sr.iy0[p] + ky, ix = sr.ix0[p] + kx;
+        const bool ok = (unsigned)iy < (unsigned)g.cv.H && (unsigned)ix < (unsigned)g.cv.W;
+        sr.offB[p] = (ok ? (unsigned)(((iy * g.cv.W + ix) * g.cv.C + c0) * 2) : sr.zero_rel) + sr.chunk[p];
+      }
+      return 0;
+    } else {
+      return k0;
     }
   };
   auto dma = [&](const u16* plane_k, unsigned off, unsigned char* lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)plane_k + off),
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
   };
-  auto dma_piece = [&](const Src& sr, int pc, int k0, unsigned char* s) {      // pc = 0..7
+  auto dma_piece = [&](const Src& sr, int pc, int k0, int kb, unsigned char* s) {      // pc = 0..7; kb = prep_b(sr, k0)
     const int pp = pc >> 2, which = pc & 3;
     const int gidx = uw + 8 * pp;                                               // 16 row groups per plane, two per wave
     if (which == 0) dma(sr.Ahi + k0, sr.offA[pp], s + OFF_AHI + gidx * 16 * ROWB);
     else if (which == 1) dma(sr.Alo + k0, sr.offA[pp], s + OFF_ALO + gidx * 16 * ROWB);
-    else if (which == 2) dma(sr.Bhi + k0, sr.offB[pp], s + OFF_BHI + gidx * 16 * ROWB);
-    else dma(sr.Blo + k0, sr.offB[pp], s + OFF_BLO + gidx * 16 * ROWB);
+    else if (which == 2) dma(sr.Bhi + kb, sr.offB[pp], s + OFF_BHI + gidx * 16 * ROWB);
+    else dma(sr.Blo + kb, sr.offB[pp], s + OFF_BLO + gidx * 16 * ROWB);
   };
 
   bool first_issued = false;       // k-tile 0 of the coming tile is already in flight (issued before the last epilogue)
@@ -159,6 +198,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
       asm volatile("" : "+v"(ba[0]), "+v"(ba[1]), "+v"(bb[0]), "+v"(bb[1]));   // one base register per operand and k-step,
                                                                                 // constants go to the offset field
       unsigned char* sn = smem + next_stage * STAGE;
+      const int kbn = issue_next ? prep_b(src, k0n) : 0;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 ah[2], al[2], bh[4], bl[4];
@@ -179,7 +219,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pass == 0 ? al[i] : ah[i], pass == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
           if (ks == 0 && (m % 3) == 2) {
             __builtin_amdgcn_sched_barrier(0);
-            if (issue_next) dma_piece(src, m / 3, k0n, sn);
+            if (issue_next) dma_piece(src, m / 3, k0n, kbn, sn);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -219,8 +259,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
     // ---------------- main loop: two stages, DMA of k-tile kt+1 in flight under the MFMAs of k-tile kt
     Pre pre[2];
     if (nk > 0 && !first_issued && !(g.dbg & 2)) {
+      const int kb0 = prep_b(src, 0);
 #pragma unroll
-      for (int pc = 0; pc < 8; ++pc) dma_piece(src, pc, 0, smem);
+      for (int pc = 0; pc < 8; ++pc) dma_piece(src, pc, 0, kb0, smem);
     }
     for (int kt = 0; kt < nk; ++kt) {
       if (kt == 0 && first_issued) {
@@ -240,8 +281,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
       if (!more) prefetch(0, pre[0]);            // last k-tile: the first sub-tile's epilogue inputs ride under its MFMAs
       if (!(g.dbg & 1)) compute(kt & 1, more && !(g.dbg & 2), (kt + 1) & 1, (kt + 1) * BK);
       else if (more && !(g.dbg & 2)) {
+        const int kb1 = prep_b(src, (kt + 1) * BK);
 #pragma unroll
-        for (int pc = 0; pc < 8; ++pc) dma_piece(src, pc, (kt + 1) * BK, smem + ((kt + 1) & 1) * STAGE);
+        for (int pc = 0; pc < 8; ++pc) dma_piece(src, pc, (kt + 1) * BK, kb1, smem + ((kt + 1) & 1) * STAGE);
       }
     }
     if (nk == 0) prefetch(0, pre[0]);
@@ -254,8 +296,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
       decode(tseq + gridDim.x, tm2, tn2, bz2);
       Src nsrc;
       make_src(tm2, tn2, bz2, lane, nsrc);
+      const int kbn0 = prep_b(nsrc, 0);
 #pragma unroll
-      for (int pc = 0; pc < 8; ++pc) dma_piece(nsrc, pc, 0, smem);
+      for (int pc = 0; pc < 8; ++pc) dma_piece(nsrc, pc, 0, kbn0, smem);
       first_issued = true;
     }
     prefetch(1, pre[1]);
@@ -369,14 +412,52 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
 
 // Internal entry (called by cips_gemm_bf16x3 when the shape and the epilogue qualify): same descriptor,
 // 256x256 tiles.  Returns hipErrorNotSupported for combinations it has no instantiation for.
-template <bool A, bool Mk, bool R>
+template <bool A, bool Mk, bool R, bool CV = false>
 static void launch_wide(const WArgs& g, int grid, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_wide_kernel<A, Mk, R>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_wide_kernel<A, Mk, R, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x3_wide_kernel<A, Mk, R>), dim3(grid), dim3(512), SMEM_BYTES, stream, g);
+  hipLaunchKernelGGL((gemm_bf16x3_wide_kernel<A, Mk, R, CV>), dim3(grid), dim3(512), SMEM_BYTES, stream, g);
+}
+
+static int wide_grid(int total) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+    ncu = (ncu / 8) * 8;
+  }
+  return total < ncu ? total : ncu;
+}
+
+// Implicit-GEMM convolution (see include/cips3d_hip.h): y[b] (O, Ho*Wo) = Wp (O, kh*kw*C) . gather(x[b])^T
+extern "C" int cips_conv2d_x3(const cips_conv_x3_desc* c, cips_stream_t stream) {
+  if (!c || c->B <= 0 || c->C <= 0 || c->O <= 0 || c->H <= 0 || c->W <= 0 || c->kh <= 0 || c->kw <= 0 || c->stride <= 0 || c->pad < 0)
+    return (int)hipErrorInvalidValue;
+  if (c->C & 31) return (int)hipErrorNotSupported;
+  const int Ho = (c->H + 2 * c->pad - c->kh) / c->stride + 1, Wo = (c->W + 2 * c->pad - c->kw) / c->stride + 1;
+  const long long N = (long long)Ho * Wo, K = (long long)c->kh * c->kw * c->C;
+  if (Ho <= 0 || Wo <= 0 || (N & 7)) return (int)hipErrorNotSupported;
+  const long long img = (long long)c->H * c->W * c->C;
+  if ((img * c->B + c->C) * 2 >= 0xffffffffLL || K > 0x7fffffffLL) return (int)hipErrorNotSupported;   // 32-bit lane offsets
+  WArgs g = {};
+  cips_gemm_x3_desc& d = g.d;
+  d.A_hi = c->w_hi; d.A_lo = c->w_lo; d.B_hi = c->x_hi; d.B_lo = c->x_lo;
+  d.M = c->O; d.N = (int)N; d.K = (int)K; d.lda = (int)K; d.ldb = 0; d.strideA = 0; d.strideB = 0; d.batch = c->B;
+  d.C = c->y; d.ldc = (int)N; d.strideC = (long long)c->O * N; d.slope = 0.2f;
+  g.cv.C = c->C; g.cv.H = c->H; g.cv.W = c->W; g.cv.kw = c->kw; g.cv.stride = c->stride; g.cv.pad = c->pad; g.cv.Wo = Wo;
+  g.cv.img_stride = img; g.cv.zero_elem = img * c->B;
+  g.tiles_m = (d.M + BM - 1) / BM;
+  g.tiles_n = (d.N + BN - 1) / BN;
+  const long long total = (long long)g.tiles_m * g.tiles_n * d.batch;
+  if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  g.total = (int)total;
+  g.dbg = 0;
+  launch_wide<false, false, false, true>(g, wide_grid(g.total), (hipStream_t)stream);
+  return CIPS_CHECK_LAUNCH();
 }
 
 extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream) {

@@ -153,11 +153,30 @@ def _x3_ok(K, N, O):
     return CONV_MODE == "bf16x3" and K % 32 == 0 and N % 32 == 0 and O % 32 == 0
 
 
+# Implicit-GEMM form of the x3 convs (CIPS_D_CONV_IMPLICIT=0 keeps the materialised im2col everywhere): the activation is
+# transposed once into NHWC split planes and the NT GEMM's loader gathers the taps; used from 16x16 output planes up
+# (smaller planes leave most of a 256-pixel tile empty).
+IMPLICIT = _os.environ.get("CIPS_D_CONV_IMPLICIT", "1") != "0"
+
+
+def _implicit_ok(C, N, O):
+    return IMPLICIT and CONV_MODE == "bf16x3" and C % 32 == 0 and O % 32 == 0 and N >= 256 and N % 8 == 0
+
+
+def _w_planes(w):
+    """(O, C, kh, kw) -> Planes (O, kh*kw*C): contraction index (tap, channel)"""
+    O, C, kh, kw = w.shape
+    P, _ = ops.split_planes(w.permute(0, 2, 3, 1).reshape(1, O, kh * kw * C).contiguous(), want_p=True, want_t=False)
+    return P
+
+
 def _conv_fwd(x, w, stride, pad):
     B, C, H, W = x.shape
     O, _, kh, kw = w.shape
     x = x.contiguous()
     Ho_, Wo_ = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if _implicit_ok(C, Ho_ * Wo_, O):
+        return ops.conv2d_x3(_w_planes(w), ops.split_planes_nhwc(x), B, C, H, W, O, kh, kw, stride, pad)
     if _x3_ok(C * kh * kw, Ho_ * Wo_, O):
         K, N = C * kh * kw, Ho_ * Wo_
         colP, _, _ = ops.im2col_x3(x, kh, kw, stride, pad)               # planes (B, K, N): k-major B operand
@@ -186,6 +205,10 @@ def _conv_bwd_data(dy, w, in_shape, stride, pad):
     dy = dy.contiguous()
     Ho, Wo = dy.shape[2], dy.shape[3]
     K, N = C * kh * kw, Ho * Wo
+    if stride == 1 and _implicit_ok(O, H * W, C) and Ho + kh - 1 - 2 * pad == H and kh - 1 - pad >= 0:
+        # dx = conv(dy, flipped weights with the channel roles swapped), padding kh-1-pad
+        wf = w.flip(2, 3).transpose(0, 1)                                   # (C, O, kh, kw)
+        return ops.conv2d_x3(_w_planes(wf), ops.split_planes_nhwc(dy), B, O, Ho, Wo, C, kh, kw, 1, kh - 1 - pad)
     if _x3_ok(K, N, O):
         wP, _ = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=True, want_t=False)    # (1, O, K): contraction index o = rows
         dyP, _ = ops.split_planes(dy.view(B, O, N), want_p=True, want_t=False)
@@ -210,6 +233,11 @@ def _conv_bwd_weight(dy, x, w_shape, stride, pad):
     x = x.contiguous()
     dy = dy.contiguous()
     K, N = C * kh * kw, dy.shape[2] * dy.shape[3]
+    if _implicit_ok(C, N, O):
+        dw = ops.conv2d_x3_wgrad(ops.split_planes_nhwc(dy), ops.split_planes_nhwc(x), B, C, x.shape[2], x.shape[3], O, kh, kw,
+                                 stride, pad)
+        if dw is not None:
+            return dw
     if _x3_ok(K, N, O):
         colP, _, _ = ops.im2col_x3(x, kh, kw, stride, pad)
         dyP, _ = ops.split_planes(dy.view(B, O, N), want_p=True, want_t=False)

@@ -565,6 +565,57 @@ def split_planes(x, want_p=True, want_t=True):
     return P, T
 
 
+def split_planes_nhwc(x):
+    """x (B, C, H, W) fp32 NCHW -> NHWC split planes (B*H*W + 1, C): the transposing form of cips_split_planes; the
+    extra last row is zero (the implicit-GEMM convolution reads it wherever a tap falls into the padding)."""
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    n = H * W
+    hi = torch.empty(B * n + 1, C, device=x.device, dtype=BF)
+    lo = torch.empty(B * n + 1, C, device=x.device, dtype=BF)
+    hi[B * n:].zero_(); lo[B * n:].zero_()
+    check(lib.cips_split_planes(_p(x), None, None, _p(hi), _p(lo), C, n, n, n, C, B, C * n, C * n, C * n, _stream()),
+          "cips_split_planes")
+    return Planes(hi, lo)
+
+
+def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad):
+    """Implicit-GEMM convolution: wP Planes (O, kh*kw*C) with contraction index (tap, channel), xP NHWC Planes from
+    split_planes_nhwc -> y (B, O, Ho, Wo) fp32."""
+    lib = _lib.load()
+    from ._lib import ConvX3Desc
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    y = torch.empty(B, O, Ho, Wo, device=xP.hi.device)
+    d = ConvX3Desc()
+    d.w_hi, d.w_lo, d.x_hi, d.x_lo, d.y = _p(wP.hi), _p(wP.lo), _p(xP.hi), _p(xP.lo), _p(y)
+    d.B, d.C, d.H, d.W, d.O, d.kh, d.kw, d.stride, d.pad = B, C, H, W, O, kh, kw, stride, pad
+    check(lib.cips_conv2d_x3(_ct.byref(d), _stream()), "cips_conv2d_x3")
+    return y
+
+
+def conv2d_x3_wgrad(dyP, xP, B, C, H, W, O, kh, kw, stride, pad):
+    """Weight gradient of conv2d_x3: dyP, xP NHWC Planes from split_planes_nhwc -> dW (O, C, kh, kw) fp32, or None when
+    the pixel count does not split into 32-row k-tiles.  The pixel range is cut into chunks so that a 512x512 filter bank
+    still fills the chip (4 tiles per tap and chunk); the partial sums are added here."""
+    lib = _lib.load()
+    from ._lib import ConvWgradDesc
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    K = B * Ho * Wo
+    if K % 32:
+        return None
+    tiles = ((O + 255) // 256) * ((C + 255) // 256) * kh * kw
+    nch = 1
+    while tiles * nch < 256 and K % (64 * nch) == 0 and K // (2 * nch) >= 512:
+        nch *= 2
+    part = torch.empty(nch, kh * kw, O, C, device=xP.hi.device)
+    d = ConvWgradDesc()
+    d.dy_hi, d.dy_lo, d.x_hi, d.x_lo, d.part = _p(dyP.hi), _p(dyP.lo), _p(xP.hi), _p(xP.lo), _p(part)
+    d.B, d.C, d.H, d.W, d.O, d.kh, d.kw, d.stride, d.pad, d.nchunks = B, C, H, W, O, kh, kw, stride, pad, nch
+    check(lib.cips_conv2d_x3_wgrad(_ct.byref(d), _stream()), "cips_conv2d_x3_wgrad")
+    dw = part.sum(0) if nch > 1 else part[0]
+    return dw.permute(1, 2, 0).reshape(O, C, kh, kw)
+
+
 def modfc_prep_x3(W, s, eps=1e-8):
     lib = _lib.load()
     in_dim, out_dim = W.shape

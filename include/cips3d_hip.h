@@ -240,6 +240,31 @@ int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t stream);
  * issue them one by one with cips_gemm_bf16x3_km then. */
 int cips_gemm_bf16x3_km_grouped(const cips_gemm_x3_desc* descs, int ngroups, cips_stream_t stream);
 
+/* Implicit-GEMM convolution on the split-bf16 NT kernel (EqualConv2d forward, exp/cips3d/models/discriminator.py:40-48,
+ * and — with the flipped, transposed weights — its data gradient at stride 1):
+ *   y[b][o][oy*Wo+ox] = sum_{ky,kx,c} w[o][(ky*kw+kx)*C + c] * x[b][oy*stride-pad+ky][ox*stride-pad+kx][c]
+ * x: NHWC split planes of B*H*W + 1 rows of C (the extra LAST ROW MUST BE ZERO: it stands in for the padding),
+ * w: planes [O][kh*kw*C]; y: fp32 NCHW (B, O, Ho, Wo).  C % 32 == 0, Ho*Wo % 8 == 0; else hipErrorNotSupported. */
+typedef struct cips_conv_x3_desc {
+  const void* w_hi; const void* w_lo;
+  const void* x_hi; const void* x_lo;
+  float* y;
+  int B, C, H, W, O, kh, kw, stride, pad;
+} cips_conv_x3_desc;
+int cips_conv2d_x3(const cips_conv_x3_desc* d, cips_stream_t stream);
+/* Weight gradient of the same convolution on the K-major kernel (contraction over all B*Ho*Wo output pixels, split in
+ * `nchunks` ranges whose partial sums the caller adds):
+ *   part[chunk][ky*kw+kx][o][c] = sum_{q in chunk} dy[q][o] * x[pixel(q)*stride - pad + (ky,kx)][c]
+ * dy: NHWC split planes [B*Ho*Wo][O]; x: NHWC split planes [B*H*W + 1][C] with a ZERO LAST ROW; part: fp32
+ * (nchunks, kh*kw, O, C).  O, C multiples of 8, B*Ho*Wo % (32*nchunks) == 0; else hipErrorNotSupported. */
+typedef struct cips_conv_wgrad_desc {
+  const void* dy_hi; const void* dy_lo;
+  const void* x_hi; const void* x_lo;
+  float* part;
+  int B, C, H, W, O, kh, kw, stride, pad, nchunks;
+} cips_conv_wgrad_desc;
+int cips_conv2d_x3_wgrad(const cips_conv_wgrad_desc* d, cips_stream_t stream);
+
 /* fp32 (rows, cols) [ldx] -> split bf16 planes row-major [rows][ldp] and/or transposed [cols][ldt]. */
 int cips_split_planes(const float* x, void* p_hi, void* p_lo, void* t_hi, void* t_lo, int rows, int cols,
                       int ldx, int ldp, int ldt, int batch, long long stride_x, long long stride_p,
