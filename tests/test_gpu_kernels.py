@@ -541,3 +541,24 @@ def test_upfirdn2d_golden_and_fused_bias_act():
         y = ops.fused_bias_act(x.to(d), bb.to(d), rr.to(d), act, grad, 0.2, 2 ** 0.5)
         yr = orc.fused_bias_act(x, bb, rr, act, grad, 0.2, 2 ** 0.5)
         assert torch.equal(y.cpu(), yr) or max_rel(y, yr) < 1e-7
+
+
+@pytest.mark.parametrize("shape,down,pad", [((5, 64, 64), 1, (2, 2)), ((3, 63, 65), 1, (1, 1)), ((2, 200, 260), 1, (2, 2)),
+                                            ((4, 65, 65), 2, (1, 1)), ((2, 130, 258), 2, (2, 2)), ((7, 16, 16), 1, (2, 1)),
+                                            ((3, 33, 31), 2, (1, 2)), ((1, 8, 1030), 1, (2, 2))])
+def test_upfirdn2d_blur_fast_path(shape, down, pad):
+    """The LDS-tiled form of upfirdn2d the Blur layers take (up 1, minor 1, 4x4 kernel, down 1 or 2): whole planes,
+    planes cut in row bands, odd sizes, asymmetric padding — against the oracle's restatement of upfirdn2d_native."""
+    from cips3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(sum(shape) + down)
+    k = torch.tensor([1., 3., 3., 1.]); k = k[None] * k[:, None]; k = k / k.sum()
+    mj, h, w = shape
+    x = torch.randn(mj, h, w, 1, generator=g)
+    y = ops.upfirdn2d_op(x.to(d), k.to(d), 1, 1, down, down, pad[0], pad[1], pad[0], pad[1])
+    yr = orc.upfirdn2d(x.view(1, mj, h, w), k, up=1, down=down, pad=pad)
+    assert y.shape[1:3] == yr.shape[2:] and max_rel(y.view(mj, y.shape[1], y.shape[2]), yr[0]) < 1e-6
+    k3 = torch.randn(3, 2, generator=g)                      # a non-square, non-symmetric kernel: flip conventions
+    y3 = ops.upfirdn2d_op(x.to(d), k3.to(d), 1, 1, down, down, pad[0], pad[1], pad[0], pad[1])
+    y3r = orc.upfirdn2d(x.view(1, mj, h, w), k3, up=1, down=down, pad=pad)
+    assert max_rel(y3.view(mj, y3.shape[1], y3.shape[2]), y3r[0]) < 1e-6
