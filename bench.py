@@ -179,7 +179,9 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # with a process group up, RCCL's watchdog thread may touch the HIP runtime while this thread captures:
+            # only this thread's calls belong to the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
                 fwd_bwd()
         except Exception as e:                      # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
