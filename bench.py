@@ -136,11 +136,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the product path)")
+    # CIPS_BENCH_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks (ranks share
+    # devices, the all-reduce goes through the host); never a measurement
+    backend = os.environ.get("CIPS_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     from cips3d_amd.generator import GeneratorNerfINR
     from cips3d_amd.distributed import GradAllReducer
     from cips3d_amd import ops
@@ -246,6 +253,7 @@ def main():
                                f"batch {b}/GPU, G fwd+bwd, all 9 CIPS blocks",
                    "global_batch": world * b, "parallelism": f"dp{world}", "inr_gemm_mode": mode,
                    "launch": "hipGraph replay" if use_graph[0] else "eager"},
+        **({"backend_note": f"{backend} functional check, not a measurement"} if backend != "nccl" and world > 1 else {}),
     }
     if exact:
         line["exact_f32"] = exact
