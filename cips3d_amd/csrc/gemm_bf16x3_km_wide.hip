@@ -110,9 +110,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_km_wide_kernel(KArgs g) {
       offA[par] = (unsigned)(lh * d.lda + m) * 2u;
       offB[par] = (unsigned)(lh * d.ldb + n) * 2u;
     }
+    // SGPR-base form through asm (see gemm_bf16x3_wide.hip): uniform row pointer + one 32-bit offset per lane
     auto dma = [&](const u16* p, unsigned off, unsigned char* lds_base) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)p + off),
-                                       (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+      const unsigned la = sbase + (unsigned)(lds_base - smem);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(p), "s"(la) : "memory");
     };
     // CONV: byte offset of this lane's B row for contraction row q (a global output-pixel index) — its column part
     // comes from offB[] with the lane's k-row term removed (computed below with lh = 0 semantics)
