@@ -140,31 +140,41 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   // chunk kc = slot ^ ((row>>2)&3) — the swizzle lives in the SOURCE address, the reads apply the same XOR.
   // Rows past M / N are clamped (their products only reach outputs that are never stored); K % 32 == 0.
   // Two LDS stages: the DMA for tile t+1 runs while tile t is multiplied; one barrier per k-tile.
+  // The DMA is issued in the SGPR-base form (asm, see gemm_bf16x3_wide.hip): uniform plane pointer of the k-tile + one
+  // 32-bit byte offset per lane and row group, computed once per output tile.
   const int drow = lane >> 2, dslot = lane & 3;
-  auto dma_group = [&](const u16* plane, int ld, int rows_total, int row_base, int k0, unsigned char* lds_base) {
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  constexpr int NW = 2 * WM;
+  const unsigned sbase_nt = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  auto dma_s = [&](const u16* p, unsigned off, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(p), "s"(lds_addr) : "memory");
+  };
+  auto row_off = [&](int ld, int rows_total, int row_base) -> unsigned {
     const int row = row_base + drow;                                  // row inside the workgroup tile
     const int kcsw = dslot ^ ((row >> 2) & 3);
-    int grow = rows_total - 1;
-    grow = (row < rows_total) ? row : grow;
-    const u16* src = plane + (long long)grow * ld + k0 + kcsw * 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+    const int grow = (row < rows_total) ? row : rows_total - 1;
+    return (unsigned)(grow * ld + kcsw * 8) * 2u;
   };
-  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  unsigned offA_nt[2], offB_nt[NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) offA_nt[i] = row_off(d.lda, M - m0, (uw + NW * i) * 16);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) offB_nt[i] = row_off(d.ldb, N - n0, (uw + NW * i) * 16);
   auto issue_tile = [&](int stage, int k0) {
-    unsigned char* s = smem + stage * STAGE;
-    constexpr int NW = 2 * WM;
+    const unsigned s = sbase_nt + stage * STAGE;
+    const u16 *ah = Ahi + (long long)m0 * d.lda + k0, *al = Alo + (long long)m0 * d.lda + k0;
+    const u16 *bh = Bhi + (long long)n0 * d.ldb + k0, *bl = Blo + (long long)n0 * d.ldb + k0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {            // A: BM/16 row groups per plane, 2 per wave
       const int gidx = uw + NW * i;
-      dma_group(Ahi + (long long)m0 * d.lda, d.lda, M - m0, gidx * 16, k0, s + OFF_AHI + gidx * 16 * ROWB);
-      dma_group(Alo + (long long)m0 * d.lda, d.lda, M - m0, gidx * 16, k0, s + OFF_ALO + gidx * 16 * ROWB);
+      dma_s(ah, offA_nt[i], s + OFF_AHI + gidx * 16 * ROWB);
+      dma_s(al, offA_nt[i], s + OFF_ALO + gidx * 16 * ROWB);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {           // B: 8 row groups per plane
       const int gidx = uw + NW * i;
-      dma_group(Bhi + (long long)n0 * d.ldb, d.ldb, N - n0, gidx * 16, k0, s + OFF_BHI + gidx * 16 * ROWB);
-      dma_group(Blo + (long long)n0 * d.ldb, d.ldb, N - n0, gidx * 16, k0, s + OFF_BLO + gidx * 16 * ROWB);
+      dma_s(bh, offB_nt[i], s + OFF_BHI + gidx * 16 * ROWB);
+      dma_s(bl, offB_nt[i], s + OFF_BLO + gidx * 16 * ROWB);
     }
   };
   auto compute = [&](int stage) {
@@ -499,34 +509,47 @@ __global__ __launch_bounds__(KmCfg<WM>::THREADS, 2) void gemm_bf16x3_km_kernel(A
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto issue_tile = [&](int stage, int k0) {
-    unsigned char* s = smem + stage * STAGE;
+  // LDS-DMA in the SGPR-base form (asm, see gemm_bf16x3_wide.hip): uniform row pointer of the k-tile + one 32-bit
+  // byte offset per lane and piece, computed once per output tile
+  const unsigned sbase_km = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  auto dma_s = [&](const u16* p, unsigned off, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(p), "s"(lds_addr) : "memory");
+  };
+  unsigned offA_km[KC::A_PER_WAVE], offB_km[KC::B_PER_WAVE];
 #pragma unroll
-    for (int i = 0; i < KC::A_PER_WAVE; ++i) {           // A: A_PIECES 1-KiB pieces per plane
+  for (int i = 0; i < KC::A_PER_WAVE; ++i) {             // A: A_PIECES 1-KiB pieces per plane
+    const int idx = uw + NW * i;
+    constexpr int LPR = 64 / KC::A_ROWS_PER_PIECE;       // lanes per k-row of a piece
+    const int k = KC::A_ROWS_PER_PIECE * idx + lane / LPR, c16 = lane % LPR;
+    const int pr = (c16 >> 1) ^ (2 * (k & 3));
+    int m = m0 + (pr * 2 + (c16 & 1)) * 8;
+    m = (m < M) ? m : 0;                                 // clamped columns only feed outputs that are never stored
+    offA_km[i] = (unsigned)(k * d.lda + m) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < KC::B_PER_WAVE; ++i) {             // B: 8 pieces per plane (4 k-rows each)
+    const int idx = uw + NW * i;
+    const int k = 4 * idx + (lane >> 4), c16 = lane & 15;
+    const int pr = (c16 >> 1) ^ (2 * (k & 3));
+    int n = n0 + (pr * 2 + (c16 & 1)) * 8;
+    n = (n < N) ? n : 0;
+    offB_km[i] = (unsigned)(k * d.ldb + n) * 2u;
+  }
+  auto issue_tile = [&](int stage, int k0) {
+    const unsigned s = sbase_km + stage * STAGE;
+    const u16 *ah = Ahi + (long long)k0 * d.lda, *al = Alo + (long long)k0 * d.lda;
+    const u16 *bh = Bhi + (long long)k0 * d.ldb, *bl = Blo + (long long)k0 * d.ldb;
+#pragma unroll
+    for (int i = 0; i < KC::A_PER_WAVE; ++i) {
       const int idx = uw + NW * i;
-      constexpr int LPR = 64 / KC::A_ROWS_PER_PIECE;     // lanes per k-row of a piece
-      const int k = KC::A_ROWS_PER_PIECE * idx + lane / LPR, c16 = lane % LPR;
-      const int pr = (c16 >> 1) ^ (2 * (k & 3));
-      int m = m0 + (pr * 2 + (c16 & 1)) * 8;
-      m = (m < M) ? m : 0;                               // clamped columns only feed outputs that are never stored
-      const long long so = (long long)(k0 + k) * d.lda + m;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ahi + so),
-                                       (__attribute__((address_space(3))) void*)(s + OFF_AHI + idx * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Alo + so),
-                                       (__attribute__((address_space(3))) void*)(s + OFF_ALO + idx * 1024), 16, 0, 0);
+      dma_s(ah, offA_km[i], s + OFF_AHI + idx * 1024);
+      dma_s(al, offA_km[i], s + OFF_ALO + idx * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < KC::B_PER_WAVE; ++i) {           // B: 8 pieces per plane (4 k-rows each)
+    for (int i = 0; i < KC::B_PER_WAVE; ++i) {
       const int idx = uw + NW * i;
-      const int k = 4 * idx + (lane >> 4), c16 = lane & 15;
-      const int pr = (c16 >> 1) ^ (2 * (k & 3));
-      int n = n0 + (pr * 2 + (c16 & 1)) * 8;
-      n = (n < N) ? n : 0;
-      const long long so = (long long)(k0 + k) * d.ldb + n;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bhi + so),
-                                       (__attribute__((address_space(3))) void*)(s + OFF_BHI + idx * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Blo + so),
-                                       (__attribute__((address_space(3))) void*)(s + OFF_BLO + idx * 1024), 16, 0, 0);
+      dma_s(bh, offB_km[i], s + OFF_BHI + idx * 1024);
+      dma_s(bl, offB_km[i], s + OFF_BLO + idx * 1024);
     }
   };
   // transpose-read one 32(m) x 16(k) fragment: two ds_read_b64_tr_b16 (rows kb.. and kb+4..)
