@@ -163,6 +163,39 @@ def _implicit_ok(C, N, O):
     return IMPLICIT and CONV_MODE == "bf16x3" and C % 32 == 0 and O % 32 == 0 and N >= 256 and N % 8 == 0
 
 
+# NHWC planes of an activation / gradient are shared between the convolution ops that read the same tensor inside ONE
+# autograd node (dy feeds both the data and the weight gradient; the forward's planes of x feed its weight gradient):
+# a memo that only lives while that node's backward runs, keyed by the tensor's storage address and shape.
+_shared = {}
+_sharing = [0]
+
+
+class _share_planes:
+    def __init__(self, *pairs):                 # (tensor, Planes or None) whose planes are already known
+        self.pairs = pairs
+
+    def __enter__(self):
+        _sharing[0] += 1
+        for t, p in self.pairs:
+            if p is not None:
+                _shared[(t.data_ptr(), tuple(t.shape))] = p
+
+    def __exit__(self, *exc):
+        _sharing[0] -= 1
+        if _sharing[0] == 0:
+            _shared.clear()
+
+
+def _nhwc(t):
+    key = (t.data_ptr(), tuple(t.shape))
+    p = _shared.get(key)
+    if p is None:
+        p = ops.split_planes_nhwc(t)
+        if _sharing[0]:
+            _shared[key] = p
+    return p
+
+
 def _w_planes(w):
     """(O, C, kh, kw) -> Planes (O, kh*kw*C): contraction index (tap, channel)"""
     O, C, kh, kw = w.shape
@@ -176,7 +209,7 @@ def _conv_fwd(x, w, stride, pad):
     x = x.contiguous()
     Ho_, Wo_ = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     if _implicit_ok(C, Ho_ * Wo_, O):
-        return ops.conv2d_x3(_w_planes(w), ops.split_planes_nhwc(x), B, C, H, W, O, kh, kw, stride, pad)
+        return ops.conv2d_x3(_w_planes(w), _nhwc(x), B, C, H, W, O, kh, kw, stride, pad)
     if _x3_ok(C * kh * kw, Ho_ * Wo_, O):
         K, N = C * kh * kw, Ho_ * Wo_
         colP, _, _ = ops.im2col_x3(x, kh, kw, stride, pad)               # planes (B, K, N): k-major B operand
@@ -208,7 +241,7 @@ def _conv_bwd_data(dy, w, in_shape, stride, pad):
     if stride == 1 and _implicit_ok(O, H * W, C) and Ho + kh - 1 - 2 * pad == H and kh - 1 - pad >= 0:
         # dx = conv(dy, flipped weights with the channel roles swapped), padding kh-1-pad
         wf = w.flip(2, 3).transpose(0, 1)                                   # (C, O, kh, kw)
-        return ops.conv2d_x3(_w_planes(wf), ops.split_planes_nhwc(dy), B, O, Ho, Wo, C, kh, kw, 1, kh - 1 - pad)
+        return ops.conv2d_x3(_w_planes(wf), _nhwc(dy), B, O, Ho, Wo, C, kh, kw, 1, kh - 1 - pad)
     if _x3_ok(K, N, O):
         wP, _ = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=True, want_t=False)    # (1, O, K): contraction index o = rows
         dyP, _ = ops.split_planes(dy.view(B, O, N), want_p=True, want_t=False)
@@ -234,8 +267,7 @@ def _conv_bwd_weight(dy, x, w_shape, stride, pad):
     dy = dy.contiguous()
     K, N = C * kh * kw, dy.shape[2] * dy.shape[3]
     if _implicit_ok(C, N, O):
-        dw = ops.conv2d_x3_wgrad(ops.split_planes_nhwc(dy), ops.split_planes_nhwc(x), B, C, x.shape[2], x.shape[3], O, kh, kw,
-                                 stride, pad)
+        dw = ops.conv2d_x3_wgrad(_nhwc(dy), _nhwc(x), B, C, x.shape[2], x.shape[3], O, kh, kw, stride, pad)
         if dw is not None:
             return dw
     if _x3_ok(K, N, O):
@@ -255,16 +287,22 @@ class Conv2dFunction(Function):
     def forward(ctx, x, w, stride, pad):
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.pad = stride, pad
-        return _conv_fwd(x, w, stride, pad)
+        with _share_planes():
+            y = _conv_fwd(x, w, stride, pad)
+            ctx.xP = _shared.get((x.data_ptr(), tuple(x.shape))) if ctx.needs_input_grad[1] else None
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = Conv2dBwdDataFunction.apply(dy, w, x.shape, ctx.stride, ctx.pad)
-        if ctx.needs_input_grad[1]:
-            dw = Conv2dBwdWeightFunction.apply(dy, x, w.shape, ctx.stride, ctx.pad)
+        dy = dy.contiguous()
+        with _share_planes((x, ctx.xP)):
+            if ctx.needs_input_grad[0]:
+                dx = Conv2dBwdDataFunction.apply(dy, w, x.shape, ctx.stride, ctx.pad)
+            if ctx.needs_input_grad[1]:
+                dw = Conv2dBwdWeightFunction.apply(dy, x, w.shape, ctx.stride, ctx.pad)
+        ctx.xP = None
         return dx, dw, None, None
 
 
@@ -279,10 +317,12 @@ class Conv2dBwdDataFunction(Function):
     def backward(ctx, ggx):
         dy, w = ctx.saved_tensors
         g_dy = g_w = None
-        if ctx.needs_input_grad[0]:
-            g_dy = Conv2dFunction.apply(ggx, w, ctx.stride, ctx.pad)
-        if ctx.needs_input_grad[1]:
-            g_w = Conv2dBwdWeightFunction.apply(dy, ggx, w.shape, ctx.stride, ctx.pad)
+        ggx = ggx.contiguous()
+        with _share_planes():
+            if ctx.needs_input_grad[0]:
+                g_dy = Conv2dFunction.apply(ggx, w, ctx.stride, ctx.pad)
+            if ctx.needs_input_grad[1]:
+                g_w = Conv2dBwdWeightFunction.apply(dy, ggx, w.shape, ctx.stride, ctx.pad)
         return g_dy, g_w, None, None, None
 
 
