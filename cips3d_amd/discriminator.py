@@ -159,6 +159,9 @@ def _x3_ok(K, N, O):
 IMPLICIT = _os.environ.get("CIPS_D_CONV_IMPLICIT", "1") != "0"
 
 
+_RGB_STREAM = _os.environ.get("CIPS_D_RGB_STREAM", "1") != "0"
+
+
 def _implicit_ok(C, N, O):
     return IMPLICIT and CONV_MODE == "bf16x3" and C % 32 == 0 and O % 32 == 0 and N >= 256 and N % 8 == 0
 
@@ -208,6 +211,8 @@ def _conv_fwd(x, w, stride, pad):
     O, _, kh, kw = w.shape
     x = x.contiguous()
     Ho_, Wo_ = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if _RGB_STREAM and kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
+        return ops.conv1x1_smallk(x, w.reshape(O, C).contiguous())      # RGB input convs: streaming, no GEMM
     if _implicit_ok(C, Ho_ * Wo_, O):
         return ops.conv2d_x3(_w_planes(w), _nhwc(x), B, C, H, W, O, kh, kw, stride, pad)
     if _x3_ok(C * kh * kw, Ho_ * Wo_, O):

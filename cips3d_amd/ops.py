@@ -565,6 +565,16 @@ def split_planes(x, want_p=True, want_t=True):
     return P, T
 
 
+def conv1x1_smallk(x, w):
+    """x (B, C<=4, H, W), w (O, C) -> y (B, O, H, W): the RGB input convs as a streaming kernel"""
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    O = w.shape[0]
+    y = torch.empty(B, O, H, W, device=x.device)
+    check(lib.cips_conv1x1_smallk(_p(x), _p(w), _p(y), B, C, O, H * W, _stream()), "cips_conv1x1_smallk")
+    return y
+
+
 def split_planes_nhwc(x):
     """x (B, C, H, W) fp32 NCHW -> NHWC split planes (B*H*W + 1, C): the transposing form of cips_split_planes; the
     extra last row is zero (the implicit-GEMM convolution reads it wherever a tap falls into the padding)."""

@@ -346,6 +346,10 @@ int cips_upfirdn2d(const float* input, const float* kernel, float* out,
                    int up_x, int up_y, int down_x, int down_y,
                    int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream);
 
+/* 1x1 convolution with C <= 4 input channels (EqualConv2d of the RGB input layers, discriminator.py:457-459):
+ * y (B, O, HW) = w (O, C) . x (B, C, HW); HW % 4 == 0.  Streaming kernel, no GEMM. */
+int cips_conv1x1_smallk(const float* x, const float* w, float* y, int B, int C, int O, int HW, cips_stream_t stream);
+
 /* im2col for the EqualConv2d GEMM path (exp/cips3d/models/discriminator.py:40-48).
  * x (B,C,H,W) NCHW -> col (B, C*kh*kw, Ho*Wo) row-major ("colT": k-major B operand, so that
  * out[b] (O, Ho*Wo) = W (O, C*kh*kw) @ col[b] lands directly in NCHW).  col2im is the adjoint
