@@ -613,10 +613,16 @@ def conv2d_x3_wgrad(dyP, xP, B, C, H, W, O, kh, kw, stride, pad):
     K = B * Ho * Wo
     if K % 32:
         return None
+    # chunks of the pixel range: the persistent grid runs ceil(tiles*nch / 256) rounds of K/nch rows each (+ an
+    # epilogue worth ~512 rows); 36 tiles x 8 chunks = 288 would leave the second round 7/8 empty
     tiles = ((O + 255) // 256) * ((C + 255) // 256) * kh * kw
-    nch = 1
-    while tiles * nch < 256 and K % (64 * nch) == 0 and K // (2 * nch) >= 512:
-        nch *= 2
+    nch, best = 1, None
+    for cand in (1, 2, 4, 8, 16, 32, 64):
+        if K % (32 * cand) or (cand > 1 and K // cand < 256):
+            continue
+        cost = -(-tiles * cand // 256) * (K // cand + 512)
+        if best is None or cost < best:
+            nch, best = cand, cost
     part = torch.empty(nch, kh * kw, O, C, device=xP.hi.device)
     d = ConvWgradDesc()
     d.dy_hi, d.dy_lo, d.x_hi, d.x_lo, d.part = _p(dyP.hi), _p(dyP.lo), _p(xP.hi), _p(xP.lo), _p(part)
