@@ -160,6 +160,29 @@ IMPLICIT = _os.environ.get("CIPS_D_CONV_IMPLICIT", "1") != "0"
 
 
 _RGB_STREAM = _os.environ.get("CIPS_D_RGB_STREAM", "1") != "0"
+# Small output planes (8x8, 4x4: fewer than 256 pixels per image): the batch is folded into the pixel dimension, one
+# GEMM over B*Ho*Wo columns with the shared weights instead of B GEMMs whose 16- or 64-column tiles are mostly padding
+# (the 4x4 layers spent 14 ms per GAN step in the fp32 GEMM for 5 GFLOP).  CIPS_D_CONV_FOLD=0 restores that.
+_FOLD = _os.environ.get("CIPS_D_CONV_FOLD", "1") != "0"
+
+
+def _fold_ok(K, N, B, O):
+    return _FOLD and CONV_MODE == "bf16x3" and N < 256 and (B * N) % 32 == 0 and K % 32 == 0 and O % 32 == 0
+
+
+def _folded_col_planes(x, kh, kw, stride, pad):
+    """im2col with the batch folded into the columns: Planes (1, K, B*N), k-major"""
+    col, Ho, Wo = ops.im2col(x, kh, kw, stride, pad)                  # (B, K, N) fp32
+    B, K, N = col.shape
+    colP, _ = ops.split_planes(col.permute(1, 0, 2).reshape(1, K, B * N).contiguous(), want_p=True, want_t=False)
+    return colP, Ho, Wo
+
+
+def _folded_rows_planes(t):
+    """(B, O, Ho, Wo) -> Planes (1, O, B*N)"""
+    B, O = t.shape[0], t.shape[1]
+    P, _ = ops.split_planes(t.reshape(B, O, -1).permute(1, 0, 2).reshape(1, O, -1).contiguous(), want_p=True, want_t=False)
+    return P
 
 
 def _implicit_ok(C, N, O):
@@ -215,6 +238,13 @@ def _conv_fwd(x, w, stride, pad):
         return ops.conv1x1_smallk(x, w.reshape(O, C).contiguous())      # RGB input convs: streaming, no GEMM
     if _implicit_ok(C, Ho_ * Wo_, O):
         return ops.conv2d_x3(_w_planes(w), _nhwc(x), B, C, H, W, O, kh, kw, stride, pad)
+    if _fold_ok(C * kh * kw, Ho_ * Wo_, B, O):
+        K, N = C * kh * kw, Ho_ * Wo_
+        colP, _, _ = _folded_col_planes(x, kh, kw, stride, pad)
+        _, wT = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=False, want_t=True)   # (1, K, O)
+        y2 = torch.empty(O, B * N, device=x.device)
+        ops.gemm_x3_km(wT, colP, O, B * N, K, O, B * N, 1, 0, 0, y2)     # y (O, B*N) = W (O,K) @ col (K, B*N)
+        return y2.view(O, B, Ho_, Wo_).permute(1, 0, 2, 3).contiguous()
     if _x3_ok(C * kh * kw, Ho_ * Wo_, O):
         K, N = C * kh * kw, Ho_ * Wo_
         colP, _, _ = ops.im2col_x3(x, kh, kw, stride, pad)               # planes (B, K, N): k-major B operand
@@ -247,6 +277,11 @@ def _conv_bwd_data(dy, w, in_shape, stride, pad):
         # dx = conv(dy, flipped weights with the channel roles swapped), padding kh-1-pad
         wf = w.flip(2, 3).transpose(0, 1)                                   # (C, O, kh, kw)
         return ops.conv2d_x3(_w_planes(wf), _nhwc(dy), B, O, Ho, Wo, C, kh, kw, 1, kh - 1 - pad)
+    if _fold_ok(K, N, B, O):
+        wP, _ = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=True, want_t=False)    # (1, O, K)
+        dcol2 = torch.empty(K, B * N, device=dy.device)
+        ops.gemm_x3_km(wP, _folded_rows_planes(dy), K, B * N, O, K, B * N, 1, 0, 0, dcol2)       # dcol (K, B*N) = W^T dy
+        return ops.col2im(dcol2.view(K, B, N).permute(1, 0, 2).contiguous(), B, C, H, W, kh, kw, stride, pad)
     if _x3_ok(K, N, O):
         wP, _ = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=True, want_t=False)    # (1, O, K): contraction index o = rows
         dyP, _ = ops.split_planes(dy.view(B, O, N), want_p=True, want_t=False)
@@ -275,6 +310,11 @@ def _conv_bwd_weight(dy, x, w_shape, stride, pad):
         dw = ops.conv2d_x3_wgrad(_nhwc(dy), _nhwc(x), B, C, x.shape[2], x.shape[3], O, kh, kw, stride, pad)
         if dw is not None:
             return dw
+    if _fold_ok(K, N, B, O):
+        colP, _, _ = _folded_col_planes(x, kh, kw, stride, pad)
+        part = torch.empty(O, K, device=x.device)
+        ops.gemm_x3(_folded_rows_planes(dy), colP, O, K, B * N, B * N, B * N, 1, 0, 0, C=part)   # dW (O,K) = dy (O,B*N) col^T
+        return part.view(O, C, kh, kw)
     if _x3_ok(K, N, O):
         colP, _, _ = ops.im2col_x3(x, kh, kw, stride, pad)
         dyP, _ = ops.split_planes(dy.view(B, O, N), want_p=True, want_t=False)

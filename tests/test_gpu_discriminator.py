@@ -45,7 +45,9 @@ def test_conv2d_x3_eligible_shapes_double_backward(mode, monkeypatch):
     # pixel counts (400, 576 of 256-pixel tiles), 3 k-tiles per tap (C = 96), stride 2 without padding, 1x1 stride 2
     for (B, C, O, H, k, stride, pad) in [(3, 32, 64, 16, 3, 1, 1), (2, 64, 32, 17, 3, 2, 0), (2, 32, 32, 16, 1, 1, 0),
                                          (2, 64, 96, 33, 3, 2, 0), (2, 32, 64, 20, 3, 1, 1), (1, 96, 96, 24, 3, 1, 1),
-                                         (2, 64, 32, 31, 1, 2, 0)]:
+                                         (2, 64, 32, 31, 1, 2, 0),
+                                         # small planes: the batch folded into the pixel dimension (4x4, 8x8 outputs)
+                                         (8, 64, 32, 4, 3, 1, 1), (4, 32, 64, 9, 3, 2, 0), (2, 32, 32, 8, 1, 1, 0)]:
         x = torch.randn(B, C, H, H, generator=g, dtype=torch.float64, requires_grad=True)
         w = (torch.randn(O, C, k, k, generator=g, dtype=torch.float64) / (C * k * k) ** 0.5).requires_grad_(True)
         y = torch.nn.functional.conv2d(x, w, stride=stride, padding=pad)
