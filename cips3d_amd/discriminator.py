@@ -170,6 +170,15 @@ def _fold_ok(K, N, B, O):
     return _FOLD and CONV_MODE == "bf16x3" and N < 256 and (B * N) % 32 == 0 and K % 32 == 0 and O % 32 == 0
 
 
+def _split_count(tiles, length):
+    """Folded GEMMs are single problems of few 256x128 tiles (16 for a 4x4 plane): cut the contraction (`length` rows,
+    in 32-row k-tiles) into chunks that become the GEMM's batch, partial sums added by the caller."""
+    n = 1
+    while tiles * n < 192 and length % (64 * n) == 0 and length // (2 * n) >= 128:
+        n *= 2
+    return n
+
+
 def _folded_col_planes(x, kh, kw, stride, pad):
     """im2col with the batch folded into the columns: Planes (1, K, B*N), k-major"""
     col, Ho, Wo = ops.im2col(x, kh, kw, stride, pad)                  # (B, K, N) fp32
@@ -242,8 +251,11 @@ def _conv_fwd(x, w, stride, pad):
         K, N = C * kh * kw, Ho_ * Wo_
         colP, _, _ = _folded_col_planes(x, kh, kw, stride, pad)
         _, wT = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=False, want_t=True)   # (1, K, O)
-        y2 = torch.empty(O, B * N, device=x.device)
-        ops.gemm_x3_km(wT, colP, O, B * N, K, O, B * N, 1, 0, 0, y2)     # y (O, B*N) = W (O,K) @ col (K, B*N)
+        nch = _split_count(((O + 255) // 256) * ((B * N + 127) // 128), K)
+        kc = K // nch
+        y2 = torch.empty(nch, O, B * N, device=x.device)
+        ops.gemm_x3_km(wT, colP, O, B * N, kc, O, B * N, nch, kc * O, kc * B * N, y2)   # y (O, B*N) = W (O,K) @ col (K, B*N)
+        y2 = y2.sum(0) if nch > 1 else y2[0]
         return y2.view(O, B, Ho_, Wo_).permute(1, 0, 2, 3).contiguous()
     if _x3_ok(C * kh * kw, Ho_ * Wo_, O):
         K, N = C * kh * kw, Ho_ * Wo_
@@ -312,9 +324,11 @@ def _conv_bwd_weight(dy, x, w_shape, stride, pad):
             return dw
     if _fold_ok(K, N, B, O):
         colP, _, _ = _folded_col_planes(x, kh, kw, stride, pad)
-        part = torch.empty(O, K, device=x.device)
-        ops.gemm_x3(_folded_rows_planes(dy), colP, O, K, B * N, B * N, B * N, 1, 0, 0, C=part)   # dW (O,K) = dy (O,B*N) col^T
-        return part.view(O, C, kh, kw)
+        nch = _split_count(((O + 255) // 256) * ((K + 127) // 128), B * N)
+        nc = B * N // nch
+        part = torch.empty(nch, O, K, device=x.device)
+        ops.gemm_x3(_folded_rows_planes(dy), colP, O, K, nc, B * N, B * N, nch, nc, nc, C=part)   # dW (O,K) = dy (O,B*N) col^T
+        return (part.sum(0) if nch > 1 else part[0]).view(O, C, kh, kw)
     if _x3_ok(K, N, O):
         colP, _, _ = ops.im2col_x3(x, kh, kw, stride, pad)
         dyP, _ = ops.split_planes(dy.view(B, O, N), want_p=True, want_t=False)
