@@ -162,6 +162,53 @@ __global__ __launch_bounds__(256) void conv1x1_smallk_kernel(const float* __rest
   }
 }
 
+// Data gradient of the same layer: dx[b][c][p] = sum_o w[o][c] dy[b][o][p] — a reduction over the O channel planes,
+// streamed once.  A workgroup owns 256 consecutive pixels of one image; its four waves each reduce a quarter of the
+// channels (16-byte loads, lane = 4 pixels), and the four partial sums are added in wave order through LDS.
+__global__ __launch_bounds__(256) void conv1x1_smallk_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                      float* __restrict__ dx, int C, int O, int hw4) {
+  __shared__ float4 red[3][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blocks_per_img = (hw4 + 63) / 64;
+  const int b = blockIdx.x / blocks_per_img, p4 = (blockIdx.x % blocks_per_img) * 64 + lane;
+  const bool ok = p4 < hw4;
+  float4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int o_per = (O + 3) / 4, o0 = wave * o_per, o1 = min(O, o0 + o_per);
+  const float4* src = reinterpret_cast<const float4*>(dy) + (long long)b * O * hw4 + p4;
+  if (ok) {
+#pragma unroll 4
+    for (int o = o0; o < o1; ++o) {
+      const float4 g = src[(long long)o * hw4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < C) {
+          const float wv = w[o * C + c];
+          acc[c].x = fmaf(wv, g.x, acc[c].x); acc[c].y = fmaf(wv, g.y, acc[c].y);
+          acc[c].z = fmaf(wv, g.z, acc[c].z); acc[c].w = fmaf(wv, g.w, acc[c].w);
+        }
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave - 1][c][lane] = acc[c];
+  }
+  __syncthreads();
+  if (wave == 0 && ok) {
+    for (int c = 0; c < C; ++c) {
+      float4 v = acc[c];
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) {
+        const float4 t = red[s2][c][lane];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      reinterpret_cast<float4*>(dx)[((long long)b * C + c) * hw4 + p4] = v;
+    }
+  }
+}
+
 // colT[b][(c,ky,kx)][(oy,ox)] = x[b][c][oy*s+ky-p][ox*s+kx-p]   (zero outside)
 // X3: write the k-major matrix as split-bf16 planes (x = hi + lo) — the B operand of the K-major / NT bf16x3 GEMMs —
 // instead of fp32 (same bytes)
@@ -281,6 +328,16 @@ extern "C" int cips_conv1x1_smallk(const float* x, const float* w, float* y, int
   if (B <= 0 || C <= 0 || C > 4 || O <= 0 || HW <= 0 || (HW & 3)) return (int)hipErrorInvalidValue;
   const long long total = (long long)B * O * (HW / 4);
   hipLaunchKernelGGL(conv1x1_smallk_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, w, y, B, C, O, HW / 4);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_conv1x1_smallk_bwd_data(const float* dy, const float* w, float* dx, int B, int C, int O, int HW,
+                                            cips_stream_t stream) {
+  if (B <= 0 || C <= 0 || C > 4 || O <= 0 || HW <= 0 || (HW & 3)) return (int)hipErrorInvalidValue;
+  const int hw4 = HW / 4;
+  const long long blocks = (long long)B * ((hw4 + 63) / 64);
+  if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(conv1x1_smallk_bwd_data_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, w, dx, C, O, hw4);
   return CIPS_CHECK_LAUNCH();
 }
 

@@ -285,6 +285,8 @@ def _conv_bwd_data(dy, w, in_shape, stride, pad):
     dy = dy.contiguous()
     Ho, Wo = dy.shape[2], dy.shape[3]
     K, N = C * kh * kw, Ho * Wo
+    if _RGB_STREAM and kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
+        return ops.conv1x1_smallk_bwd_data(dy, w.reshape(O, C).contiguous(), C)
     if stride == 1 and _implicit_ok(O, H * W, C) and Ho + kh - 1 - 2 * pad == H and kh - 1 - pad >= 0:
         # dx = conv(dy, flipped weights with the channel roles swapped), padding kh-1-pad
         wf = w.flip(2, 3).transpose(0, 1)                                   # (C, O, kh, kw)

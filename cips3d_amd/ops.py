@@ -575,6 +575,15 @@ def conv1x1_smallk(x, w):
     return y
 
 
+def conv1x1_smallk_bwd_data(dy, w, C):
+    """dy (B, O, H, W), w (O, C<=4) -> dx (B, C, H, W)"""
+    lib = _lib.load()
+    B, O, H, W = dy.shape
+    dx = torch.empty(B, C, H, W, device=dy.device)
+    check(lib.cips_conv1x1_smallk_bwd_data(_p(dy), _p(w), _p(dx), B, C, O, H * W, _stream()), "cips_conv1x1_smallk_bwd_data")
+    return dx
+
+
 def split_planes_nhwc(x):
     """x (B, C, H, W) fp32 NCHW -> NHWC split planes (B*H*W + 1, C): the transposing form of cips_split_planes; the
     extra last row is zero (the implicit-GEMM convolution reads it wherever a tap falls into the padding)."""

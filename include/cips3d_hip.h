@@ -349,6 +349,9 @@ int cips_upfirdn2d(const float* input, const float* kernel, float* out,
 /* 1x1 convolution with C <= 4 input channels (EqualConv2d of the RGB input layers, discriminator.py:457-459):
  * y (B, O, HW) = w (O, C) . x (B, C, HW); HW % 4 == 0.  Streaming kernel, no GEMM. */
 int cips_conv1x1_smallk(const float* x, const float* w, float* y, int B, int C, int O, int HW, cips_stream_t stream);
+/* its data gradient: dx (B, C, HW) = w^T (C, O) . dy (B, O, HW) */
+int cips_conv1x1_smallk_bwd_data(const float* dy, const float* w, float* dx, int B, int C, int O, int HW,
+                                 cips_stream_t stream);
 
 /* im2col for the EqualConv2d GEMM path (exp/cips3d/models/discriminator.py:40-48).
  * x (B,C,H,W) NCHW -> col (B, C*kh*kw, Ho*Wo) row-major ("colT": k-major B operand, so that
