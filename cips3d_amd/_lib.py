@@ -57,7 +57,7 @@ class GemmX3Desc(C.Structure):
         ("P_hi", vp), ("P_lo", vp), ("ldp", i32), ("strideP", i64),
         ("T_hi", vp), ("T_lo", vp), ("ldt", i32), ("strideT", i64),
         ("mask_out", vp), ("add", vp), ("rgb_g", vp), ("rgb_w", vp), ("C_unmasked", vp), ("mask", vp),
-        ("act", i32), ("slope", f32), ("res_hi", vp), ("res_lo", vp),
+        ("act", i32), ("slope", f32), ("res_hi", vp), ("res_lo", vp), ("gate_bits", i32),
     ]
 
 

@@ -356,7 +356,21 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
     tile_out_f32(d.C_unmasked);
     WAVE_SYNC();
   }
-  if (d.mask) {
+  if (d.mask && (d.gate_bits & 1)) {
+    // bit plane: the 32 columns of an MFMA tile row are one dword (N, ldp, strideP multiples of 32), bit = lane & 31
+    const unsigned char* mbase = (const unsigned char*)d.mask + (pb >> 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wrow0 + i * 32 + mfma_row(r, hf), colb = wcol0 + j * 32;
+          unsigned w = 0;
+          if (row < M && colb < N) w = *reinterpret_cast<const unsigned*>(mbase + (((long long)row * d.ldp + colb) >> 3));
+          v[i][j][r] *= ((w >> l31) & 1u) ? 1.f : d.slope;
+        }
+  } else if (d.mask) {
     tile_in_bf16((const u16*)d.mask, sc_hi);
     WAVE_SYNC();
     CIPS_FOR_ELEMS(
@@ -366,7 +380,20 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
     WAVE_SYNC();
   }
   if (d.act) { CIPS_FOR_ELEMS(v[i][j][r] = lrelu(v[i][j][r], d.slope); (void)so;) }
-  if (d.mask_out) {
+  if (d.mask_out && (d.gate_bits & 2)) {
+    unsigned char* obase = (unsigned char*)d.mask_out + (pb >> 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned long long bal = __ballot(v[i][j][r] > 0.f);      // lanes 0..31: row of hf 0, 32..63: row of hf 1
+          const int row = wrow0 + i * 32 + mfma_row(r, hf), colb = wcol0 + j * 32;
+          if (l31 == 0 && row < M && colb < N)
+            *reinterpret_cast<unsigned*>(obase + (((long long)row * d.ldp + colb) >> 3)) = (unsigned)(hf ? (bal >> 32) : bal);
+        }
+  } else if (d.mask_out) {
     CIPS_FOR_ELEMS(sc_hi[so] = f2bf(v[i][j][r]);)
     WAVE_SYNC();
     tile_out_bf16((u16*)d.mask_out, sc_hi);
@@ -672,6 +699,7 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
   if ((d->K & 31) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
     return (int)hipErrorInvalidValue;
+  if (d->gate_bits && ((d->N & 31) || (d->ldp & 31) || (d->strideP & 31))) return (int)hipErrorInvalidValue;
   // large square-ish problems: 256x256 tiles (less operand traffic per flop, prefetched epilogue inputs);
   // CIPS_X3_WIDE=0 keeps everything on the 256x128 kernel below
   if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }

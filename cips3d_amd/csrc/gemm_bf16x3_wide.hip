@@ -251,7 +251,13 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
           p.add[2 * c + 1] = ok ? *reinterpret_cast<const float4*>(q + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const long long o = pb + (long long)row * d.ldp + col;
-        if constexpr (HAS_MASK) p.mask[c] = ok ? *reinterpret_cast<const uint4*>((const u16*)d.mask + o) : make_uint4(0, 0, 0, 0);
+        if constexpr (HAS_MASK) {
+          if (d.gate_bits & 1) {       // bit plane: this lane's 8 columns are one byte
+            p.mask[c] = make_uint4(ok ? (unsigned)((const unsigned char*)d.mask)[o >> 3] : 0u, 0, 0, 0);
+          } else {
+            p.mask[c] = ok ? *reinterpret_cast<const uint4*>((const u16*)d.mask + o) : make_uint4(0, 0, 0, 0);
+          }
+        }
         if constexpr (HAS_RES) {
           p.rh[c] = ok ? *reinterpret_cast<const uint4*>((const u16*)d.res_hi + o) : make_uint4(0, 0, 0, 0);
           p.rl[c] = ok ? *reinterpret_cast<const uint4*>((const u16*)d.res_lo + o) : make_uint4(0, 0, 0, 0);
@@ -371,11 +377,16 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
         }
         if constexpr (HAS_MASK) {
           const unsigned w[4] = {cur.mask[c].x, cur.mask[c].y, cur.mask[c].z, cur.mask[c].w};
+          if (d.gate_bits & 1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const unsigned mb = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
-            const bool pos = ((mb & 0x8000u) == 0) && ((mb & 0x7fffu) != 0);
-            y[e] *= pos ? 1.f : d.slope;
+            for (int e = 0; e < 8; ++e) y[e] *= ((w[0] >> e) & 1u) ? 1.f : d.slope;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const unsigned mb = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+              const bool pos = ((mb & 0x8000u) == 0) && ((mb & 0x7fffu) != 0);
+              y[e] *= pos ? 1.f : d.slope;
+            }
           }
         }
         if (d.act) {
@@ -383,7 +394,16 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
           for (int e = 0; e < 8; ++e) y[e] = lrelu(y[e], d.slope);
         }
         const long long po = pb + (long long)row * d.ldp + col;
-        if (d.mask_out && ok) *reinterpret_cast<uint4*>((u16*)d.mask_out + po) = pack8(y);
+        if (d.mask_out && ok) {
+          if (d.gate_bits & 2) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bits |= (y[e] > 0.f ? 1u : 0u) << e;
+            ((unsigned char*)d.mask_out)[po >> 3] = (unsigned char)bits;
+          } else {
+            *reinterpret_cast<uint4*>((u16*)d.mask_out + po) = pack8(y);
+          }
+        }
         if constexpr (HAS_RES) {
           float rh[8], rl[8];
           unpack8(cur.rh[c], rh); unpack8(cur.rl[c], rl);
@@ -470,6 +490,7 @@ extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t s
   if (d->T_hi || (d->N & 7) || (d->ldc & 3) || (d->strideC & 3) || (d->ldp & 7) || (d->strideP & 7)) return (int)hipErrorNotSupported;
   const bool a = d->add != nullptr, m = d->mask != nullptr, r = d->res_hi != nullptr;
   if ((a && !m) || (r && (a || m))) return (int)hipErrorNotSupported;
+  if (d->gate_bits && ((d->N & 31) || (d->ldp & 31) || (d->strideP & 31))) return (int)hipErrorInvalidValue;
   WArgs g;
   g.d = *d;
   g.tiles_m = (d->M + BM - 1) / BM;

@@ -502,7 +502,7 @@ class Planes:
 
 
 def gemm_x3(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, T=None, ldt=0, strideT=0,
-            mask_out=None, add=None, rgb_g=None, rgb_w=None, C_unmasked=None, mask=None, act=0, res=None):
+            mask_out=None, add=None, rgb_g=None, rgb_w=None, C_unmasked=None, mask=None, act=0, res=None, gate_bits=0):
     """C[b][m][n] = epi(sum_k A[b][m][k] * B[b][n][k]); A, B, P, T, res: Planes; row-major aux use ld = N."""
     lib = _lib.load()
     d = GemmX3Desc()
@@ -518,6 +518,7 @@ def gemm_x3(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, T
     d.C_unmasked, d.mask = _p(C_unmasked), _p(mask)
     d.act, d.slope = act, LRELU_SLOPE
     d.res_hi, d.res_lo = (_p(res.hi), _p(res.lo)) if res is not None else (None, None)
+    d.gate_bits = gate_bits        # bit 0: `mask` is a uint8 bit plane (M, N/8); bit 1: `mask_out` is written as one
     check(lib.cips_gemm_bf16x3(_ct.byref(d), _stream()), "cips_gemm_bf16x3")
 
 
@@ -726,6 +727,11 @@ def torgb_bwd_w_x3(xp, drgb2d):
     return dw, db
 
 
+# LeakyReLU gates of the head kept as bit planes (1 bit per activation, written by the forward GEMMs' epilogues) instead
+# of bf16 planes: 2.5 GB less HBM traffic per C2 step.  CIPS_INR_GATE_BITS=0: bf16 gate planes / sign of the hi plane.
+INR_GATE_BITS = _os.environ.get("CIPS_INR_GATE_BITS", "1") != "0"
+
+
 class InrHeadX3Function(torch.autograd.Function):
     """Same contract as InrHeadFunction, on the bf16x3 GEMM.  Every activation / gradient lives in HBM
     as bf16 hi/lo planes in both orientations (row-major for the forward / dX operand, transposed for
@@ -756,13 +762,19 @@ class InrHeadX3Function(torch.autograd.Function):
             wb1, wbt1, d1 = prepped[2 * k]
             a1P = Planes.empty(B, n, cout, device=dev)
             a1T = Planes.empty(B, cout, n, device=dev) if want_t else None
+            bits = train and INR_GATE_BITS and cout % 32 == 0
+            a1g = torch.empty(B, n, cout // 8, device=dev, dtype=torch.uint8) if bits else None
             gemm_x3(xP, wbt1, n, cout, cin, cin, cin, B, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
-                    act=1)
+                    act=1, mask_out=a1g, gate_bits=2 if bits else 0)
             wb2, wbt2, d2 = prepped[2 * k + 1]
             skip = (k >= 4) and (cin == cout)
             oP = Planes.empty(B, n, cout, device=dev)
             oT = Planes.empty(B, cout, n, device=dev) if want_t else None
-            if skip:
+            if bits:
+                m2 = torch.empty(B, n, cout // 8, device=dev, dtype=torch.uint8)
+                gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
+                        strideT=cout * n, act=1, res=xP if skip else None, mask_out=m2, gate_bits=2)
+            elif skip:
                 m2 = torch.empty(B, n, cout, device=dev, dtype=BF) if train else None
                 gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
                         strideT=cout * n, act=1, res=xP, mask_out=m2)
@@ -775,8 +787,8 @@ class InrHeadX3Function(torch.autograd.Function):
                 first_rgb = False
             if train:
                 # keep for backward: xT (dW1), a1 gate + a1T (dW2), out planes (ToRGB grad), m2 gate, weights
-                saved.append(dict(xT=xT, xP=xP, a1P=a1P, a1m=a1P.hi, a1T=a1T, oP=oP, m2=m2, wb1=wb1, d1=d1, wb2=wb2, d2=d2,
-                                  skip=skip))
+                saved.append(dict(xT=xT, xP=xP, a1P=a1P, a1m=a1g if bits else a1P.hi, a1T=a1T, oP=oP, m2=m2, wb1=wb1, d1=d1,
+                                  wb2=wb2, d2=d2, skip=skip, bits=bits))
             xP, xT = oP, oT
         if first_rgb:
             rgb.zero_()
@@ -809,7 +821,7 @@ class InrHeadX3Function(torch.autograd.Function):
             tP, _ = split_planes(tpad, want_t=False)
             Dout = torch.empty(B, n, width, device=dev) if saved[k]["skip"] else None
             gemm_x3(dP, tP, n, width, 32, 32, 32, B, n * 32, 0, P=gP, T=gT, ldt=n, strideT=width * n,
-                    C_unmasked=Dout, mask=saved[k]["m2"])
+                    C_unmasked=Dout, mask=saved[k]["m2"], gate_bits=1 if saved[k]["bits"] else 0)
         else:
             gP.hi.zero_(); gP.lo.zero_()
             if gT is not None:
@@ -827,7 +839,7 @@ class InrHeadX3Function(torch.autograd.Function):
             # ---- mod2: gradient through the gate of a1 ----
             g1P, g1T = Planes.empty(B, n, cout, device=dev), PT(cout)
             gemm_x3(gP, sv["wb2"], n, cout, cout, cout, cout, B, n * cout, cout * cout, P=g1P, T=g1T, ldt=n,
-                    strideT=cout * n, mask=sv["a1m"])
+                    strideT=cout * n, mask=sv["a1m"], gate_bits=1 if sv["bits"] else 0)
             # ---- weight gradients of both layers: dWb2 = a1^T g, dWb1 = x^T g1 ----
             gwb2 = torch.empty(B, cout, cout, device=dev)
             gwb1 = torch.empty(B, cin, cout, device=dev)
@@ -865,7 +877,7 @@ class InrHeadX3Function(torch.autograd.Function):
                 gemm_x3(g1P, sv["wb1"], n, cin, cout, cout, cout, B, n * cout, cin * cout, P=gP, T=gT, ldt=n,
                         strideT=cin * n, add=Dout if sv["skip"] else None,
                         rgb_g=drgb2 if k - 1 >= 3 else None, rgb_w=rgbp[2 * (k - 1 - 3)] if k - 1 >= 3 else None,
-                        C_unmasked=newD, mask=pv["m2"])
+                        C_unmasked=newD, mask=pv["m2"], gate_bits=1 if pv["bits"] else 0)
                 Dout = newD
         res = modfc_prep_bwd_batch(pending)          # pending order: block nblocks-1 (mod2, mod1), ..., block 0
         for i, k in enumerate(range(nblocks - 1, -1, -1)):

@@ -226,6 +226,10 @@ typedef struct cips_gemm_x3_desc {
   const void* mask;            /* bf16 plane [M][ldp]: v *= (mask > 0 ? 1 : slope) */
   int act; float slope;        /* act 1: leaky_relu(slope) */
   const void* res_hi; const void* res_lo;   /* residual planes [M][ldp], added after act */
+  /* gate planes as BIT planes (1 bit per element, bit c&7 of byte [m][c>>3], rows of ldp/8 bytes, batch stride
+   * strideP/8): bit 0 of gate_bits = `mask` is one, bit 1 = `mask_out` is written as one (value > 0).  Needs
+   * N % 32 == 0, ldp % 32 == 0, strideP % 32 == 0.  0 = bf16 planes as above. */
+  int gate_bits;
 } cips_gemm_x3_desc;
 
 int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream);

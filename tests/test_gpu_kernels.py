@@ -325,9 +325,21 @@ def test_gemm_bf16x3_kmajor(M, N, K, batch):
     assert torch.isfinite(C).all() and e < 3e-5
 
 
-@pytest.mark.parametrize("M,N,K,batch", [(256, 256, 64, 1), (520, 264, 96, 2), (4096, 512, 512, 20), (1024, 768, 32, 3)])
+def _pack_bits(b):
+    """bool (..., N) -> uint8 (..., N/8), bit c&7 of byte c>>3"""
+    w = (1 << torch.arange(8)).to(torch.int32)
+    return (b.reshape(*b.shape[:-1], -1, 8).to(torch.int32) * w).sum(-1).to(torch.uint8)
+
+
+def _unpack_bits(u, N):
+    return ((u.to(torch.int32).unsqueeze(-1) >> torch.arange(8)) & 1).reshape(*u.shape[:-1], N).bool()
+
+
+@pytest.mark.parametrize("tile_mode", [2, 0])       # 2: 256x256-tile kernel wherever supported; 0: 256x128 kernel only
+@pytest.mark.parametrize("M,N,K,batch", [(256, 256, 64, 1), (520, 264, 96, 2), (4096, 512, 512, 20), (1024, 768, 32, 3),
+                                         (300, 96, 64, 2)])
 @pytest.mark.parametrize("flavour", ["plain", "res", "mask", "add"])
-def test_gemm_bf16x3_wide(M, N, K, batch, flavour):
+def test_gemm_bf16x3_wide(M, N, K, batch, flavour, tile_mode):
     """256x256-tile form (gemm_bf16x3_wide.hip), forced on: every epilogue flavour, ragged edges, and enough tiles
     per workgroup (4096x512x20 -> 640 tiles on 256 CUs) to exercise the prefetched first k-tile + counted wait."""
     from cips3d_amd import ops, _lib
@@ -342,7 +354,7 @@ def test_gemm_bf16x3_wide(M, N, K, batch, flavour):
     rg = torch.randn(batch * M, 3, generator=g); rw = torch.randn(3, N, generator=g)
     resP = ops.Planes(*[t.to(d) for t in _planes(res)])
     P = ops.Planes.empty(batch, M, N, device=d)
-    lib.cips_gemm_bf16x3_set_wide(2)
+    lib.cips_gemm_bf16x3_set_wide(tile_mode)
     try:
         if flavour == "plain":          # forward FC1: lrelu + planes, and the plain fp32 output
             C = torch.full((batch, M, N), float("nan"), device=d)
@@ -355,10 +367,20 @@ def test_gemm_bf16x3_wide(M, N, K, batch, flavour):
             a = torch.nn.functional.leaky_relu(acc, 0.2)
             assert rel_err(P.float(), a + resP.float().cpu().double()) < 3e-5
             assert ((mo.float().cpu() > 0) == (a > 0)).float().mean() > 0.9999
+            if N % 32 == 0:             # the same with the gate written as a bit plane
+                mb = torch.zeros(batch, M, N // 8, device=d, dtype=torch.uint8)
+                P.hi.fill_(float("nan"))
+                ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P, act=1, res=resP, mask_out=mb, gate_bits=2)
+                assert rel_err(P.float(), a + resP.float().cpu().double()) < 3e-5
+                assert (_unpack_bits(mb.cpu(), N) == (a > 0)).float().mean() > 0.9999
         elif flavour == "mask":         # backward through FC2: gate from a saved plane
             ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P, mask=mask.bfloat16().to(d))
             want = acc * torch.where(mask.bfloat16().float() > 0, 1.0, 0.2).double()
             assert rel_err(P.float(), want) < 3e-5
+            if N % 32 == 0:             # gate read from a bit plane
+                P.hi.fill_(float("nan"))
+                ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P, mask=_pack_bits(mask > 0).to(d), gate_bits=1)
+                assert rel_err(P.float(), acc * torch.where(mask > 0, 1.0, 0.2).double()) < 3e-5
         else:                           # backward through FC1 of a skip block: add + rank-3 rgb term + unmasked copy + gate
             CU = torch.empty(batch, M, N, device=d)
             ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P, add=add.to(d), rgb_g=rg.to(d), rgb_w=rw.to(d),
@@ -370,6 +392,12 @@ def test_gemm_bf16x3_wide(M, N, K, batch, flavour):
             ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P, add=add.to(d), C_unmasked=CU, mask=mask.bfloat16().to(d))
             s2 = acc + add.double()
             assert rel_err(CU, s2) < 3e-5
+            if N % 32 == 0:
+                P.hi.fill_(float("nan"))
+                ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P, add=add.to(d), C_unmasked=CU,
+                            mask=_pack_bits(mask > 0).to(d), gate_bits=1)
+                assert rel_err(CU, s2) < 3e-5
+                assert rel_err(P.float(), s2 * torch.where(mask > 0, 1.0, 0.2).double()) < 3e-5
         torch.cuda.synchronize()
     finally:
         lib.cips_gemm_bf16x3_set_wide(-1)
