@@ -66,3 +66,43 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} references the oracle"
+
+
+def test_entry_points_validate_arguments_before_touching_the_device():
+    """Malformed descriptors are refused with hipErrorInvalidValue (1) / hipErrorNotSupported (801) before any HIP
+    call — so this runs without a GPU.  (Contraction lengths must be multiples of 32 bf16, planes 16-byte aligned,
+    bit-plane gates need 32-column rows, the implicit-GEMM conv 32-channel slices, ...)"""
+    import ctypes
+    from cips3d_amd import _lib
+    lib = _lib.load()
+    INVALID, UNSUPPORTED = 1, 801
+    d = _lib.GemmX3Desc()
+    d.M, d.N, d.K, d.lda, d.ldb, d.batch = 64, 64, 48, 48, 48, 1          # K not a multiple of 32
+    assert lib.cips_gemm_bf16x3(ctypes.byref(d), None) == INVALID
+    assert lib.cips_gemm_bf16x3_km(ctypes.byref(d), None) == INVALID
+    d.K, d.lda, d.ldb = 64, 60, 64                                        # rows not 16-byte aligned
+    assert lib.cips_gemm_bf16x3(ctypes.byref(d), None) == INVALID
+    d.lda, d.batch = 64, 0
+    assert lib.cips_gemm_bf16x3(ctypes.byref(d), None) == INVALID
+    d.batch, d.N, d.ldp, d.gate_bits = 1, 72, 72, 1                       # bit-plane gate with 72-column rows
+    assert lib.cips_gemm_bf16x3(ctypes.byref(d), None) == INVALID
+    assert lib.cips_gemm_bf16x3(None, None) == INVALID
+    assert lib.cips_gemm_bf16x3_km_grouped(ctypes.byref(d), 0, None) == INVALID
+    assert lib.cips_gemm_bf16x3_km_grouped(ctypes.byref(d), 9, None) == UNSUPPORTED   # more than one launch holds
+    c = _lib.ConvX3Desc()
+    c.B, c.C, c.H, c.W, c.O, c.kh, c.kw, c.stride, c.pad = 2, 48, 16, 16, 64, 3, 3, 1, 1   # 48 channels: no 32-slices
+    assert lib.cips_conv2d_x3(ctypes.byref(c), None) == UNSUPPORTED
+    c.C, c.stride = 64, 0
+    assert lib.cips_conv2d_x3(ctypes.byref(c), None) == INVALID
+    w = _lib.ConvWgradDesc()
+    w.B, w.C, w.H, w.W, w.O, w.kh, w.kw, w.stride, w.pad, w.nchunks = 2, 64, 15, 15, 64, 3, 3, 1, 1, 1
+    assert lib.cips_conv2d_x3_wgrad(ctypes.byref(w), None) == INVALID    # no output buffer
+    buf = (ctypes.c_float * 4)()
+    w.part = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.cips_conv2d_x3_wgrad(ctypes.byref(w), None) == UNSUPPORTED   # 450 pixels: no 32-row k-tiles
+    assert lib.cips_conv1x1_smallk(None, None, None, 2, 5, 8, 64, None) == INVALID      # more than 4 input channels
+    assert lib.cips_conv1x1_smallk(None, None, None, 2, 3, 8, 30, None) == INVALID      # pixels not a multiple of 4
+    assert lib.cips_upfirdn2d(None, None, None, 1, 8, 8, 1, 9, 9, 1, 1, 1, 1, 0, 0, 0, 0, None) == INVALID   # > 64 taps
+    assert lib.cips_torgb_fwd(None, None, None, None, 16, 30, 0, None) == INVALID       # K not a multiple of 4
+    assert lib.cips_fused_bias_act(None, buf, None, None, 16, 0, 1, 3, 0, 0.2, 1.0, None) == INVALID   # bias without its size
+    assert lib.cips_fused_bias_act(None, None, None, None, 0, 0, 0, 3, 0, 0.2, 1.0, None) == 0          # empty tensor: no-op
