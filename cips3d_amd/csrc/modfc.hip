@@ -238,7 +238,130 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const void* __restrict__
   }
 }
 
+// Split-plane form for K = 512 (the head's width): a lane owns 8 consecutive k (one 16-byte load per plane and row),
+// the three weight rows of its k-range stay in registers for all rows of the wave, four rows are in flight per iteration.
+// (The generic kernel above re-reads the weights per row and moves 8 bytes per load: 79 us = 3.4 TB/s at C2.)
+__device__ __forceinline__ void ld8x3(const u16* hi, const u16* lo, long long e, float (&v)[8]) {
+  const uint4 h = *reinterpret_cast<const uint4*>(hi + e);
+  const uint4 l = *reinterpret_cast<const uint4*>(lo + e);
+  const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[2 * q] = __uint_as_float(hw[q] << 16) + __uint_as_float(lw[q] << 16);
+    v[2 * q + 1] = __uint_as_float(hw[q] & 0xffff0000u) + __uint_as_float(lw[q] & 0xffff0000u);
+  }
+}
+
+__global__ __launch_bounds__(256) void torgb_fwd_x3_k512_kernel(const u16* __restrict__ xh, const u16* __restrict__ xl,
+                                                                const float* __restrict__ w, const float* __restrict__ bias,
+                                                                float* __restrict__ rgb, long long M, int accumulate) {
+  constexpr int K = 512, R = 4;
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
+  float wr[3][8];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wr[c][q] = w[c * K + lane * 8 + q];
+  const float bv = (bias && lane < 3) ? bias[lane] : 0.f;
+  for (long long m0 = wave0 * R; m0 < M; m0 += nwaves * R) {
+    float a[R][3];
+    float v[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long long m = (m0 + r < M) ? m0 + r : M - 1;
+      ld8x3(xh, xl, m * K + lane * 8, v[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t = fmaf(v[r][q], wr[c][q], t);
+        a[r][c] = t;
+      }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[r][c] += __shfl_xor(a[r][c], off);
+    if (lane < 3) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (m0 + r < M) {
+          const float t = ((lane == 0) ? a[r][0] : (lane == 1 ? a[r][1] : a[r][2])) + bv;
+          float* o = rgb + (m0 + r) * 3 + lane;
+          *o = accumulate ? (*o + t) : t;
+        }
+      }
+    }
+  }
+}
+
 constexpr int TORGB_ROWS = 128;  // rows per partial chunk
+
+// Same for the weight gradient: partial[chunk][c][k] = sum over the chunk's 128 rows of drgb[m][c] x[m][k], K = 512.
+// 64 lanes x 8 k cover a row; the four waves take rows m0 + wave, + 4, ... (32 each), combined in wave order via LDS.
+__global__ __launch_bounds__(256) void torgb_bwd_w_partial_x3_k512_kernel(const u16* __restrict__ xh, const u16* __restrict__ xl,
+                                                                          const float* __restrict__ drgb,
+                                                                          float* __restrict__ partial, long long M) {
+  constexpr int K = 512;
+  __shared__ float sh[3][3][K];                 // waves 1..3
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: drgb comes
+  const long long m0 = (long long)blockIdx.x * TORGB_ROWS;                                       // through scalar loads
+  const long long m1 = (m0 + TORGB_ROWS < M) ? m0 + TORGB_ROWS : M;
+  float acc[3][8];
+  float gs[3] = {0.f, 0.f, 0.f};                            // sum of drgb over this wave's rows (the bias gradient)
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[c][q] = 0.f;
+  for (long long m = m0 + wave; m < m1; m += 16) {          // 4 rows in flight: m, m+4, m+8, m+12
+    float v[4][8], g[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long mm = m + 4 * r;
+      const bool ok = mm < m1;
+      ld8x3(xh, xl, (ok ? mm : m) * K + lane * 8, v[r]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[r][c] = ok ? drgb[mm * 3 + c] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gs[c] += g[r][c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[c][q] = fmaf(g[r][c], v[r][q], acc[c][q]);
+      }
+  }
+  __shared__ float shg[3][3];
+  if (wave > 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sh[wave - 1][c][lane * 8 + q] = acc[c][q];
+      if (lane == 0) shg[wave - 1][c] = gs[c];
+    }
+  }
+  __syncthreads();
+  float* out = partial + (long long)blockIdx.x * 4 * K;
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = ((acc[c][q] + sh[0][c][lane * 8 + q]) + sh[1][c][lane * 8 + q]) + sh[2][c][lane * 8 + q];
+      *reinterpret_cast<float4*>(out + c * K + lane * 8) = make_float4(t[0], t[1], t[2], t[3]);
+      *reinterpret_cast<float4*>(out + c * K + lane * 8 + 4) = make_float4(t[4], t[5], t[6], t[7]);
+      if (lane == 0) out[3 * K + c] = ((gs[c] + shg[0][c]) + shg[1][c]) + shg[2][c];
+    }
+  }
+}
+
 
 // partial[chunk][c][k] = sum_{m in chunk} drgb[m][c] x[m][k] ; partial[chunk][3][0..2] = sum drgb
 // 256 threads: thread -> 4 consecutive k (float4) x row parity group; K <= 512 per pass.
@@ -529,6 +652,13 @@ extern "C" int cips_torgb_fwd_x3(const void* x_hi, const void* x_lo, const float
   if (M <= 0 || K <= 0 || (K & 3)) return (int)hipErrorInvalidValue;
   long long blocks = (M + 3) / 4;
   if (blocks > 16384) blocks = 16384;
+  if (K == 512) {
+    long long b4 = (M + 15) / 16;                      // 4 waves x 4 rows per iteration
+    if (b4 > 8192) b4 = 8192;
+    hipLaunchKernelGGL(torgb_fwd_x3_k512_kernel, dim3((unsigned)b4), dim3(256), 0, (hipStream_t)stream, (const u16*)x_hi,
+                       (const u16*)x_lo, w, bias, rgb, M, accumulate);
+    return CIPS_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(torgb_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_hi, x_lo,
                      w, bias, rgb, M, K, accumulate);
   return CIPS_CHECK_LAUNCH();
@@ -567,8 +697,12 @@ extern "C" int cips_torgb_bwd_w_x3(const void* x_hi, const void* x_lo, const flo
   if (M <= 0 || K <= 0 || (K & 3) || K > 512) return (int)hipErrorInvalidValue;
   int chunks = cips_torgb_bwd_partials(M);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(torgb_bwd_w_partial_kernel<true>, dim3(chunks), dim3(256), 0, st, x_hi, x_lo, drgb, partials,
-                     M, K);
+  if (K == 512)
+    hipLaunchKernelGGL(torgb_bwd_w_partial_x3_k512_kernel, dim3(chunks), dim3(256), 0, st, (const u16*)x_hi, (const u16*)x_lo,
+                       drgb, partials, M);
+  else
+    hipLaunchKernelGGL(torgb_bwd_w_partial_kernel<true>, dim3(chunks), dim3(256), 0, st, x_hi, x_lo, drgb, partials,
+                       M, K);
   hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 7) / 8), dim3(256), 0, st, partials, dw,
                      dbias, chunks, K);
   return CIPS_CHECK_LAUNCH();

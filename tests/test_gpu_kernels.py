@@ -590,3 +590,27 @@ def test_upfirdn2d_blur_fast_path(shape, down, pad):
     y3 = ops.upfirdn2d_op(x.to(d), k3.to(d), 1, 1, down, down, pad[0], pad[1], pad[0], pad[1])
     y3r = orc.upfirdn2d(x.view(1, mj, h, w), k3, up=1, down=down, pad=pad)
     assert max_rel(y3.view(mj, y3.shape[1], y3.shape[2]), y3r[0]) < 1e-6
+
+
+@pytest.mark.parametrize("M,K", [(1000, 512), (4096 * 3 + 5, 512), (777, 256), (130, 64)])
+def test_torgb_x3_forward_and_weight_gradient(M, K):
+    """ToRGB on split planes (generator.py:983-1006): rgb (+)= x T^T + bias and dT = drgb^T x, dbias = sum drgb; the
+    K = 512 specialisation (16-byte loads, weights in registers) and the generic form, ragged row counts."""
+    from cips3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(1, M, K, generator=g); w = torch.randn(3, K, generator=g); b = torch.randn(3, generator=g)
+    drgb = torch.randn(M, 3, generator=g)
+    xP, _ = ops.split_planes(x.to(d), want_t=False)
+    rgb = torch.full((M, 3), 0.5, device=d)
+    ops.torgb_fwd_x3(xP, w.to(d), b.to(d), rgb, accumulate=True)
+    want = 0.5 + x[0].double() @ w.double().t() + b.double()
+    assert rel_err(rgb, want) < 1e-5                       # the planes carry x to 2^-17
+    rgb2 = torch.full((M, 3), float("nan"), device=d)
+    ops.torgb_fwd_x3(xP, w.to(d), b.to(d), rgb2, accumulate=False)
+    assert rel_err(rgb2, want - 0.5) < 1e-5
+    dw, db = ops.torgb_bwd_w_x3(xP, drgb.to(d))
+    assert rel_err(dw, drgb.double().t() @ x[0].double()) < 1e-5
+    assert rel_err(db, drgb.double().sum(0)) < 2e-6
+    dw2, db2 = ops.torgb_bwd_w_x3(xP, drgb.to(d))
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)          # fixed combine order
