@@ -283,12 +283,20 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a) {
   __syncthreads();
 
   const float4 G = *reinterpret_cast<const float4*>(a.dfea + ray * 32 + 4 * sub);
+  // white_back adds (1 - sum_k w_k) to every channel, last_back adds (1 - sum_k w_k) f_last (pigan_utils.py:261-268,
+  // weights_sum taken before the last weight is topped up): dL/dw_k = G.f_k - [last_back] G.f_last - [white_back] sum(G)
+  float gsum = G.x + G.y + G.z + G.w;
+  gsum += __shfl_xor(gsum, 1);
+  gsum += __shfl_xor(gsum, 2);
+  gsum += __shfl_xor(gsum, 4);
+  float wsum = 0.f;
   double T = 1.0;
   for (int k = 0; k < E; ++k) {
     const float delta = (k + 1 < E) ? (zall[k + 1] - zall[k]) : 1e10f;
     const float dens = clamp_density(xs[k], a.clamp_mode);
     const float alpha = 1.f - expf(-delta * dens);
     const float Tf = (float)T;
+    wsum += alpha * Tf;
     T *= (double)(1.f - alpha + 1e-10f);
     const float4 f = *reinterpret_cast<const float4*>(feat_row(a, ray, ord[k]) + 4 * sub);
     float s = G.x * f.x + G.y * f.y + G.z * f.z + G.w * f.w;
@@ -299,10 +307,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a) {
   }
   __syncthreads();
   float Q = 0.f;
+  const float s_off = ((a.flags & 1) ? ss[E - 1] : 0.f) + ((a.flags & 2) ? gsum : 0.f);
   for (int k = E - 1; k >= 0; --k) {
     const int i = ord[k];
-    const float alpha = al[k], Tk = Ts[k], s = ss[k];
-    const float w = alpha * Tk;
+    const float alpha = al[k], Tk = Ts[k], s = ss[k] - s_off;
+    float w = alpha * Tk;
+    if ((a.flags & 1) && k == E - 1) w += 1.f - wsum;       // the feature gradient of the last sample sees the topped-up weight
+
     const float dalpha = Tk * (s - Q);
     Q = fmaf(alpha, s, (1.f - alpha + 1e-10f) * Q);
     float* drow;
@@ -385,7 +396,6 @@ extern "C" int cips_composite_bwd(const float* feat_c, const float* sig_c, const
                                   float* dfeat_c, float* dsig_c, float* dfeat_f, float* dsig_f, int R, int S,
                                   int clamp_mode, int flags, cips_stream_t stream) {
   if (R <= 0 || S <= 0) return (int)hipErrorInvalidValue;
-  if (flags != 0) return (int)hipErrorNotSupported;  // last_back / white_back: forward only (off in every shipped config)
   CompArgs a = {};
   a.feat_c = feat_c; a.sig_c = sig_c; a.z_c = z_c; a.feat_f = feat_f; a.sig_f = sig_f; a.z_f = z_f;
   a.noise = noise; a.noise_std = noise_std; a.order_in = order; a.dfea = dfea;

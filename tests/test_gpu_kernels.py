@@ -212,13 +212,16 @@ def test_resample_matches_oracle_bookkeeping(noise_std, clamp):
     assert max_rel(fp_d.cpu().view(b * n, S, 3)[good], fp.view(b * n, S, 3)[good]) < 1e-4
 
 
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])            # bit 0 last_back, bit 1 white_back (pigan_utils.py:261-268)
 @pytest.mark.parametrize("hier,noise_std,clamp", [(False, 0.0, "relu"), (False, 0.3, "relu"), (True, 0.0, "relu"), (True, 0.3, "relu"),
                                                   (True, 0.1, "softplus")])
-def test_composite_forward_backward(hier, noise_std, clamp):
+def test_composite_forward_backward(hier, noise_std, clamp, flags):
     from cips3d_amd import ops
     b, n, S = 2, 203, 12
     g = torch.Generator().manual_seed(3)
     coarse = (torch.randn(b, n, S, 33, generator=g)); coarse[..., 32] *= 20
+    if flags:
+        coarse[..., 32] -= 15        # thin media: 1 - sum(weights) must matter
     zc = (torch.linspace(0.88, 1.12, S).view(1, 1, S, 1) + (torch.rand(b, n, S, 1, generator=g) - 0.5) * 0.02)
     E = 2 * S if hier else S
     noise = torch.randn(b, n, E, 1, generator=g)
@@ -233,7 +236,8 @@ def test_composite_forward_backward(hier, noise_std, clamp):
         all_z = torch.gather(all_z, -2, idx); all_o = torch.gather(all_o, -2, idx.expand(-1, -1, -1, 33))
     else:
         all_o, all_z, idx = coarse_r, zc, None
-    rgb, depth, w = orc.integrate(all_o, all_z, noise, noise_std, clamp_mode=clamp)
+    rgb, depth, w = orc.integrate(all_o, all_z, noise, noise_std, clamp_mode=clamp, last_back=bool(flags & 1),
+                                  white_back=bool(flags & 2))
     (rgb * up).sum().backward()
     d = dev()
     R = b * n
@@ -244,7 +248,7 @@ def test_composite_forward_backward(hier, noise_std, clamp):
     else:
         ff = sf = zfd = None
     fea, dep, wts, order, zs = ops.CompositeFunction.apply(fc, sc, zc.view(R, S).to(d), ff, sf, zfd,
-                                                           noise.view(R, E).to(d), noise_std, ops._CLAMP[clamp], 0)
+                                                           noise.view(R, E).to(d), noise_std, ops._CLAMP[clamp], flags)
     (fea * up.view(R, 32).to(d)).sum().backward()
     torch.cuda.synchronize()
     if hier:
