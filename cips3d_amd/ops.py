@@ -891,7 +891,10 @@ class InrHeadX3Function(torch.autograd.Function):
 
 
 def inr_head(nblocks, x0, *params):
-    fn = InrHeadX3Function if INR_MODE == "bf16x3" else InrHeadFunction
+    # the split-bf16 kernels tile pixels and features by 32; anything else (part_grad_forward with an arbitrary
+    # grad_points, generator.py:1591-1593) runs on the exact fp32 MFMA path, which has no such granule
+    x3 = INR_MODE == "bf16x3" and x0.shape[1] % 32 == 0 and x0.shape[2] % 32 == 0
+    fn = InrHeadX3Function if x3 else InrHeadFunction
     return fn.apply(nblocks, x0, *params)
 
 

@@ -333,6 +333,8 @@ if __name__ == "__main__":
     make_generator_case("g_r8_freeze", seed=3, b=2, img_size=8, S=4, hier=True, nerf_noise=0.0, aux=False, freeze=True)
     make_generator_part_case("g_r16_part", seed=21, b=2, img_size=16, S=5, hier=True, nerf_noise=0.2, aux=True,
                              grad_points=96)
+    make_generator_part_case("g_r16_part_odd", seed=22, b=2, img_size=16, S=4, hier=True, nerf_noise=0.0, aux=False,
+                             grad_points=100)
     make_generator_eval_case("g_r8_eval_psi_staged", seed=31, b=2, img_size=8, S=4, hier=True, psi=0.7, forward_points=24,
                              nerf_noise=0.0, aux=True, clamp_mode="relu", last_back=True, white_back=False)
     make_generator_eval_case("g_r8_eval_camera", seed=32, b=2, img_size=8, S=5, hier=True, psi=1.0, forward_points=None,

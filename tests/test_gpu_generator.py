@@ -10,7 +10,8 @@ from oracle import cips3d_oracle as orc
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze", "g_r16_part"]   # _part: part_grad_forward
+CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze", "g_r16_part",
+         "g_r16_part_odd"]   # _part: part_grad_forward (96 of 256 pixels; _odd: 100, not a multiple of the 32-pixel GEMM granule)
 
 
 @pytest.fixture(params=["f32", "bf16x3"])
@@ -60,6 +61,31 @@ def test_generator_matches_reference_golden(tag, inr_mode):
         torch.set_default_dtype(torch.float32)
     (o64["imgs"] * fix["G0"].double()).sum().backward()
     g64 = {n: p.grad for n, p in G64.named_parameters()}
+    # part_grad_forward sends gradients through ~100 pixels per image only: a single flipped LeakyReLU gate then moves
+    # EVERY upstream gradient by up to a few per cent (in pure fp64, perturbing the weights by 1e-7 relative — fp32
+    # rounding — moves siren.final_layer.bias of g_r16_part_odd by 3.9e-2).  Measure that conditioning floor here:
+    # three fp64 runs with the weights jittered at fp32 rounding level.
+    floor = {}
+    if fix.get("grad_points") is not None:
+        for seed in (1, 2, 3):
+            Gp = seeded_generator(fix["seed"], freeze=fix["freeze"]).double()
+            gen = torch.Generator().manual_seed(seed)
+            with torch.no_grad():
+                for p_ in Gp.parameters():
+                    p_.mul_(1 + 1e-7 * torch.randn(p_.shape, generator=gen, dtype=torch.float64))
+            torch.set_default_dtype(torch.float64)
+            try:
+                op = orc.generator_forward(dict(Gp.named_parameters()), dbl(fix["zs"]), dbl(fix["rand"]), fix["img_size"],
+                                           kw["fov"], kw["ray_start"], kw["ray_end"], kw["num_steps"], kw["h_stddev"],
+                                           kw["v_stddev"], kw["hierarchical_sample"], nerf_noise=fix["nerf_noise"],
+                                           return_aux_img=fix["aux"], freeze_nerf=fix["freeze"], grad_points=fix["grad_points"])
+            finally:
+                torch.set_default_dtype(torch.float32)
+            (op["imgs"] * fix["G0"].double()).sum().backward()
+            for n_, p_ in Gp.named_parameters():
+                if p_.grad is not None and g64.get(n_) is not None:
+                    dev_ = float((p_.grad - g64[n_]).norm() / g64[n_].norm().clamp_min(1e-300))
+                    floor[n_] = max(floor.get(n_, 0.0), dev_)
     rows, bad = [], []
     for name, p in G.named_parameters():
         dg = fix["grads"][name]
@@ -86,7 +112,7 @@ def test_generator_matches_reference_golden(tag, inr_mode):
         # (forward agreement stays ~3e-6).  DESIGN.md §3 "numerics".
         if inr_mode == "bf16x3":
             gate_tol = max(3e-2, 3 * gate_tol)
-        if e_hip > max(TOL, 3 * e_ref, gate_tol):
+        if e_hip > max(TOL, 3 * e_ref, gate_tol, 3 * floor.get(name, 0.0)):
             bad.append((name, e_hip, e_ref))
     import os
     os.makedirs("gpurun_out", exist_ok=True)

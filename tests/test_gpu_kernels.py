@@ -22,7 +22,10 @@ def dev():
 # GEMM
 # --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,batch", [(128, 128, 32, 1), (256, 512, 512, 3), (200, 36, 64, 2), (64, 512, 32, 2),
-                                         (4096, 512, 512, 2)])
+                                         (4096, 512, 512, 2),
+                                         # contraction lengths that are not multiples of the 32-wide k-tile (part_grad_forward
+                                         # with an arbitrary grad_points: dW contracts over 100 pixels)
+                                         (512, 512, 100, 2), (100, 512, 512, 2), (512, 36, 148, 1), (32, 512, 12, 3)])
 @pytest.mark.parametrize("a_k,b_n", [(False, False), (True, False), (False, True), (True, True)])
 def test_gemm_variants(M, N, K, batch, a_k, b_n):
     from cips3d_amd import ops
@@ -479,10 +482,11 @@ def test_gemm_bf16x3_epilogues():
     assert rel_err(C, s_ * torch.where(mask.bfloat16().float() > 0, 1.0, 0.2).double()) < 3e-5
 
 
+@pytest.mark.parametrize("n", [192, 100, 37])          # 100, 37: pixel counts off the 32-row granule (-> fp32 path)
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
-def test_inr_head_forward_backward(mode):
+def test_inr_head_forward_backward(mode, n):
     from cips3d_amd import ops
-    b, n = 2, 192
+    b = 2
     G = seeded_generator(6)
     g = torch.Generator().manual_seed(6)
     fea = torch.randn(b, n, 32, generator=g).requires_grad_(True)

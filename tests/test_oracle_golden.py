@@ -7,7 +7,8 @@ import torch
 from conftest import load_golden, seeded_generator, check_checksums, max_rel
 from oracle import cips3d_oracle as orc
 
-CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze", "g_r16_part"]   # _part: part_grad_forward
+CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze", "g_r16_part",
+         "g_r16_part_odd"]   # _part: part_grad_forward (96 of 256 pixels; _odd: 100, not a multiple of the 32-pixel GEMM granule)
 
 
 @pytest.mark.parametrize("tag", CASES)
