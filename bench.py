@@ -51,63 +51,106 @@ def parse():
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
 
 
-def gemm_roofline(dev, b, n, mode):
-    """Dominant kernel of the step (>= 54 % of GPU time): the modulated-FC 512x512 layer GEMM of the CIPS
-    head, forward form, timed live with events on the launch stream (torch's current stream).
-    bf16x3 mode: gemm_bf16x3_kernel — every fp32 product is 3 bf16 MFMA passes, so the roof for ALGORITHMIC
-    (fp32-equivalent) flops is the dense bf16 MFMA peak / 3.  f32 mode: gemm_f32_kernel on fp32 MFMA."""
-    from cips3d_amd import ops
-    x = torch.randn(b, n, 512, device=dev)
-    w = torch.randn(b, 512, 512, device=dev) * 0.04
-    flops = 2.0 * b * n * 512 * 512
-    if mode == "bf16x3":
-        xP, _ = ops.split_planes(x, want_t=False)
-        wP, _ = ops.split_planes(w, want_t=False)
-        oP = ops.Planes.empty(b, n, 512, device=dev)
-        fn = lambda: ops.gemm_x3(xP, wP, n, 512, 512, 512, 512, b, n * 512, 512 * 512, P=oP, act=1)
-        name, peak = "gemm_bf16x3_wide_kernel<0,0,0> (modfc 512x512 fwd: 256x256 tiles, lrelu + split-bf16 planes out)", \
-            BF16_MFMA_PEAK_TFLOPS / 3.0
-    else:
-        out = torch.empty(b, n, 512, device=dev)
-        fn = lambda: ops.bmm_nn(x, w, out=out, act=1)
-        name, peak = "gemm_f32_kernel<false,false> (modfc 512x512 fwd, act=lrelu)", F32_MFMA_PEAK_TFLOPS
+def _time_launches(fn, reps=20):
+    """average launch duration (s) with HIP events on the launch stream (torch's current stream)"""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    reps = 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / reps * 1e-3
-    ach = flops / t / 1e12
-    r = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-         "frac": round(ach / peak, 4), "traffic": None, "launch_us": round(t * 1e6, 1), "flops_per_launch": flops}
-    if mode == "bf16x3":
-        r["note"] = "algorithmic fp32-equivalent flops; raw bf16 MFMA rate = 3x achieved vs 2500 dense peak"
-        # HBM bytes per launch of exactly this kernel/shape from the PMC counters, collected in their own
-        # rocprofv3 --pmc passes (scripts/pmc_roofline.sh -> profiles/r1_roofline_pmc.json); null if absent
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+HBM_PEAK_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E
+
+
+def gemm_roofline(dev, b, n, mode):
+    """Dominant kernel FAMILY of the step (~45 % of GPU time): the 512x512 modulated-FC layer GEMMs of the CIPS head,
+    every epilogue flavour the step launches, each timed live with events on the launch stream; `frac` is the
+    launch-count-weighted family value (sum of algorithmic flops / sum of time / peak), the per-flavour rows are under
+    `flavours`.  bf16x3 mode: every fp32 product is 3 bf16 MFMA passes, so the roof for ALGORITHMIC (fp32-equivalent)
+    flops is the dense bf16 MFMA peak / 3.  f32 mode: gemm_f32_kernel on fp32 MFMA (forward form only)."""
+    from cips3d_amd import ops
+    x = torch.randn(b, n, 512, device=dev)
+    w = torch.randn(b, 512, 512, device=dev) * 0.04
+    flops = 2.0 * b * n * 512 * 512
+    act_b = b * n * 512 * 4          # bytes of one (b, n, 512) fp32-equivalent tensor (two bf16 planes)
+    w_b = b * 512 * 512 * 4
+    if mode != "bf16x3":
+        out = torch.empty(b, n, 512, device=dev)
+        t = _time_launches(lambda: ops.bmm_nn(x, w, out=out, act=1))
+        ach = flops / t / 1e12
+        return {"bound": "mfma", "kernel": "gemm_f32_kernel<false,false> (modfc 512x512 fwd, act=lrelu)",
+                "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launch_us": round(t * 1e6, 1),
+                "flops_per_launch": flops, "hbm_frac": round((2 * act_b + w_b) / t / 1e12 / HBM_PEAK_TBS, 4)}
+    peak = BF16_MFMA_PEAK_TFLOPS / 3.0
+    xP, _ = ops.split_planes(x, want_t=False)
+    wP, _ = ops.split_planes(w, want_t=False)
+    oP = ops.Planes.empty(b, n, 512, device=dev)
+    bits = torch.empty(b, n, 64, device=dev, dtype=torch.uint8)
+    gate = (torch.rand(b, n, 64, device=dev) * 256).to(torch.uint8)
+    add = torch.randn(b, n, 512, device=dev)
+    cu = torch.empty(b, n, 512, device=dev)
+    rg = torch.randn(b * n, 3, device=dev)
+    rw = torch.randn(3, 512, device=dev)
+    G = lambda **kw: ops.gemm_x3(xP, wP, n, 512, 512, 512, 512, b, n * 512, 512 * 512, P=oP, **kw)
+    # (name, launches per G fwd+bwd step at 9 blocks, callable, algorithmic HBM bytes per launch)
+    nbits = b * n * 64
+    flav = [
+        ("fwd: lrelu, gate bits out, planes out  <ADD0,MASK0,RES0>", 13, lambda: G(act=1, mask_out=bits, gate_bits=2),
+         2 * act_b + w_b + nbits),
+        ("fwd + residual planes  <0,0,1>", 5, lambda: G(act=1, res=xP, mask_out=bits, gate_bits=2), 3 * act_b + w_b + nbits),
+        ("dX: gate bits in, planes out  <0,1,0>", 13, lambda: G(mask=gate, gate_bits=1), 2 * act_b + w_b + nbits),
+        ("dX + skip addend + ToRGB term + unmasked copy + gate  <1,1,0>", 5,
+         lambda: G(add=add, rgb_g=rg, rgb_w=rw, C_unmasked=cu, mask=gate, gate_bits=1), 4 * act_b + w_b + nbits),
+    ]
+    rows, tot_t, tot_f = [], 0.0, 0.0
+    for name, count, fn, bytes_ in flav:
+        t = _time_launches(fn)
+        rows.append({"flavour": name, "launches_per_step": count, "launch_us": round(t * 1e6, 1),
+                     "achieved": round(flops / t / 1e12, 2), "frac": round(flops / t / 1e12 / peak, 4),
+                     "algorithmic_bytes": bytes_, "hbm_frac": round(bytes_ / t / 1e12 / HBM_PEAK_TBS, 4)})
+        tot_t += count * t
+        tot_f += count * flops
+    ach = tot_f / tot_t / 1e12
+    r = {"bound": "mfma", "kernel": "gemm_bf16x3_wide_kernel family (modfc 512x512 layer GEMMs of the CIPS head, 256x256 tiles): "
+                                    "launch-count-weighted over the four epilogue flavours of the step",
+         "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+         "traffic": None, "launch_us": round(tot_t / sum(f[1] for f in flav) * 1e6, 1), "flops_per_launch": flops,
+         "hbm_frac": round(sum(f[1] * f[3] for f in flav) / tot_t / 1e12 / HBM_PEAK_TBS, 4),
+         "flavours": rows,
+         "note": "algorithmic fp32-equivalent flops; raw bf16 MFMA rate = 3x achieved vs 2500 dense peak; hbm_frac = "
+                 "algorithmic bytes / time / 8 TB/s"}
+    # HBM bytes per launch of the forward flavour from the PMC counters, collected in their own rocprofv3 --pmc passes
+    # (scripts/pmc_roofline.sh -> profiles/r2_roofline_pmc.json, r1 as fallback); null if absent
+    for f in ("r2_roofline_pmc.json", "r1_roofline_pmc.json"):
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_roofline_pmc.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", f)))
             if b == 32 and n == 4096:
                 r["traffic"] = pm["hbm_bytes"]
                 r["traffic_algorithmic_bytes"] = pm["algorithmic_bytes"]
+                r["traffic_kernel"] = pm["kernel"]
+                break
         except Exception:
             pass
     return r
 
 
 def cpu_baseline(img_size, S, hier):
-    """Oracle (CPU restatement of the reference path, kind 'port') on this host's cores, bounded
-    sample: b=1 image at the bench geometry, 1 warm-up + 2 timed fwd+bwd."""
+    """Oracle (CPU restatement of the reference path, kind 'port': /root/reference does not exist on the GPU box) on
+    this host's cores, bounded sample per SURVEY.md §8d: b=4 images at the bench geometry (b=32 needs ~20 GB of
+    autograd state on the CPU), 1 warm-up + 3 timed fwd+bwd, median, reported per image."""
     from oracle import cips3d_oracle as orc
     from cips3d_amd.generator import GeneratorNerfINR
     torch.manual_seed(1234)
     G = GeneratorNerfINR(**G_CFG, device="cpu")
     sd = dict(G.named_parameters())
-    b, n = 1, img_size * img_size
+    b, n = (4 if img_size <= 64 else 1), img_size * img_size
     E = 2 * S if hier else S
     g = torch.Generator().manual_seed(1)
 
@@ -117,20 +160,40 @@ def cpu_baseline(img_size, S, hier):
                     phi=torch.randn(b, 1, generator=g), noise_c=torch.randn(b, n, S, 1, generator=g),
                     u=torch.rand(b * n, S, generator=g), noise_f=torch.randn(b, n, E, 1, generator=g))
         G.zero_grad()
+        t0 = time.time()
         out = orc.generator_forward(sd, zs, rand, img_size, 12, 0.88, 1.12, S, 0.3, 0.155, hier)
         out["imgs"].backward(torch.ones_like(out["imgs"]) / out["imgs"].numel())
+        return time.time() - t0
     one()
-    t0 = time.time()
-    reps = 2
-    for _ in range(reps):
-        one()
-    dt = (time.time() - t0) / reps
+    reps = 3
+    ts = sorted(one() for _ in range(reps))
+    dt = ts[len(ts) // 2]
     return {"value": round(b / dt, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle G fwd+bwd, {img_size}x{img_size}, E={E} evals/ray, b=1, {reps} timed iters"}
+            "sample": f"oracle G fwd+bwd, {img_size}x{img_size}, E={E} evals/ray, b={b}, median of {reps} timed iters "
+                      f"after 1 warm-up (min {b / ts[-1]:.3f}, max {b / ts[0]:.3f} img/s)"}
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU over RCCL
+    (the form the driver's contract names); rank 0 of the child job prints the JSON line."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -140,6 +203,11 @@ def main():
     # devices, the all-reduce goes through the host); never a measurement
     backend = os.environ.get("CIPS_BENCH_BACKEND", "nccl")
     local = local % torch.cuda.device_count() if backend != "nccl" else local
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} GPUs on this node, found {torch.cuda.device_count()} "
+                         "(CIPS_BENCH_BACKEND=gloo runs a functional check with ranks sharing devices)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -251,7 +319,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"FFHQ r{img}, {E} SIREN evals/ray (num_steps {S}, hierarchical {a.hier}), "
                                f"batch {b}/GPU, G fwd+bwd, all 9 CIPS blocks",
-                   "global_batch": world * b, "parallelism": f"dp{world}", "inr_gemm_mode": mode,
+                   "global_batch": world * b, "parallelism": f"dp{world}", "rccl_ranks": world if backend == "nccl" else 0,
+                   "inr_gemm_mode": mode,
                    "launch": "hipGraph replay" if use_graph[0] else "eager"},
         **({"backend_note": f"{backend} functional check, not a measurement"} if backend != "nccl" and world > 1 else {}),
     }

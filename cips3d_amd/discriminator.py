@@ -24,6 +24,33 @@ from . import ops
 # ------------------------------------------------------------------------------------------
 # fused bias + leaky relu  (mirrors exp/comm/op/fused_act.py:19-86)
 # ------------------------------------------------------------------------------------------
+# LeakyReLU gate instrumentation (parity tests; never set in production) — the discriminator's counterpart of
+# ops.GATE_PIN / ops.GATE_REC: GATE_PIN is an iterator of bool tensors shaped like the activations, one per
+# fused_leaky_relu call in call order; the op then applies `gate ? 1 : slope` from the tensor (cips_fused_bias_act
+# in its gradient form: y = (refer > 0 ? x + b : (x + b) * slope) * scale) and every backward order uses the same
+# gate.  GATE_REC receives the bool gates actually used.
+GATE_PIN = None
+GATE_REC = None
+
+
+class gate_debug:
+    def __init__(self, pin=None, rec=None):
+        self.pin, self.rec = pin, rec
+
+    def __enter__(self):
+        global GATE_PIN, GATE_REC
+        self.old = (GATE_PIN, GATE_REC)
+        GATE_PIN = iter(self.pin) if self.pin is not None else None
+        GATE_REC = self.rec
+        return self
+
+    def __exit__(self, *exc):
+        global GATE_PIN, GATE_REC
+        if exc[0] is None and GATE_PIN is not None:
+            assert next(GATE_PIN, None) is None, "pinned gates left over"
+        GATE_PIN, GATE_REC = self.old
+
+
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, out, negative_slope, scale):
@@ -46,8 +73,16 @@ class FusedLeakyReLUFunction(Function):
     @staticmethod
     def forward(ctx, input, bias, negative_slope, scale):
         empty = input.new_empty(0)
-        out = ops.fused_bias_act(input, bias, empty, 3, 0, negative_slope, scale)
-        ctx.save_for_backward(out)
+        if GATE_PIN is not None:
+            gate = next(GATE_PIN).to(input.device).reshape(input.shape)
+            refer = torch.where(gate, 1.0, -1.0).to(input.dtype)       # only its sign is read
+            out = ops.fused_bias_act(input, bias, refer, 3, 1, negative_slope, scale)
+        else:
+            out = ops.fused_bias_act(input, bias, empty, 3, 0, negative_slope, scale)
+            refer = out                                                    # sign(out) = sign(input + bias)
+        if GATE_REC is not None:
+            GATE_REC.append((refer > 0).clone())
+        ctx.save_for_backward(refer)
         ctx.negative_slope, ctx.scale = negative_slope, scale
         return out
 

@@ -370,6 +370,59 @@ def torgb_bwd_x(drgb2d, w, add, mask, out_unmasked, out):
                                _stream()), "cips_torgb_bwd_x")
 
 
+# ---- LeakyReLU gate instrumentation of the head (parity tests; never set in production) --------------------------
+# A LeakyReLU gate (pre-activation > 0) is the one discontinuity of the head: two fp32 evaluations of the same layer
+# may disagree on it for pre-activations within rounding of zero, and each disagreement moves the gradients by a
+# finite amount.  Gradient parity is therefore stated for a GIVEN set of gates:
+#   GATE_PIN: iterator of uint8 bit planes (B, n, C/8) (bit c&7 of byte c>>3 = gate of column c), one per modulated-FC
+#             layer in call order; the forward epilogues then apply `gate ? 1 : slope` from the plane instead of
+#             deciding by the sign they computed, and the backward uses the same plane.
+#   GATE_REC: list that receives the bit plane every layer actually used, in call order.
+GATE_PIN = None
+GATE_REC = None
+
+
+class gate_debug:
+    """with gate_debug(pin=planes or None, rec=list or None): ..."""
+
+    def __init__(self, pin=None, rec=None):
+        self.pin, self.rec = pin, rec
+
+    def __enter__(self):
+        global GATE_PIN, GATE_REC
+        self.old = (GATE_PIN, GATE_REC)
+        GATE_PIN = iter(self.pin) if self.pin is not None else None
+        GATE_REC = self.rec
+        return self
+
+    def __exit__(self, *exc):
+        global GATE_PIN, GATE_REC
+        if exc[0] is None and GATE_PIN is not None:
+            assert next(GATE_PIN, None) is None, "pinned gate planes left over"
+        GATE_PIN, GATE_REC = self.old
+
+
+def _next_pin(B, n, C, dev):
+    if GATE_PIN is None:
+        return None
+    p = next(GATE_PIN)
+    assert p.dtype == torch.uint8 and tuple(p.shape) == (B, n, C // 8), (tuple(p.shape), (B, n, C // 8))
+    return p.to(dev).contiguous()
+
+
+def _bits_to_pm1(p):
+    """uint8 bit plane (..., C/8) -> fp32 (..., C) of +1 / -1 (the fp32 GEMM's `mask` operand reads the sign)"""
+    sh = torch.arange(8, device=p.device)
+    g = ((p.unsqueeze(-1).to(torch.int32) >> sh) & 1).reshape(*p.shape[:-1], p.shape[-1] * 8)
+    return (g * 2 - 1).float()
+
+
+def _sign_to_bits(a):
+    """fp32 (..., C) -> uint8 bit plane (..., C/8) of a > 0"""
+    w = (1 << torch.arange(8, device=a.device)).to(torch.int32)
+    return ((a > 0).reshape(*a.shape[:-1], a.shape[-1] // 8, 8).to(torch.int32) * w).sum(-1).to(torch.uint8)
+
+
 class InrHeadFunction(torch.autograd.Function):
     """rgb_pre (B,n,3) = CIPSNet body (generator.py:1107-1153, before the final tanh).
 
@@ -395,20 +448,31 @@ class InrHeadFunction(torch.autograd.Function):
         first_rgb = True
         for k, (W1, s1, W2, s2) in enumerate(blocks):
             skip = k >= 4
+            cout = W1.shape[1]
             wb1, wbt1, d1 = modfc_prep(W1, s1)
-            a1 = bmm_nn(x, wb1, act=1)
+            pin1 = _next_pin(B, n, cout, dev)
+            # pinned (tests): gate from the supplied plane (`mask` operand: C = acc * (mask > 0 ? 1 : slope))
+            m1 = _bits_to_pm1(pin1) if pin1 is not None else None
+            a1 = bmm_nn(x, wb1, mask=m1) if pin1 is not None else bmm_nn(x, wb1, act=1)
             wb2, wbt2, d2 = modfc_prep(W2, s2)
+            pin2 = _next_pin(B, n, cout, dev)
+            m2 = _bits_to_pm1(pin2) if pin2 is not None else None
+            e2 = dict(mask=m2) if pin2 is not None else dict(act=1)
             if skip and a1.shape[-1] == x.shape[-1]:
                 out = torch.empty_like(a1)
-                a2 = bmm_nn(a1, wb2, act=1, resid=x, C2=out)
+                a2 = bmm_nn(a1, wb2, resid=x, C2=out, **e2)
             else:
-                a2 = bmm_nn(a1, wb2, act=1)
+                a2 = bmm_nn(a1, wb2, **e2)
                 out = a2
+            if GATE_REC is not None:
+                GATE_REC.append(pin1 if pin1 is not None else _sign_to_bits(a1))
+                GATE_REC.append(pin2 if pin2 is not None else _sign_to_bits(a2))
             if k >= 3:
                 T, tau = rgbp[2 * (k - 3)], rgbp[2 * (k - 3) + 1]
                 torgb_fwd(out.view(B * n, -1), T, tau, rgb.view(B * n, 3), accumulate=not first_rgb)
                 first_rgb = False
-            saved.append((x, a1, a2, out, wbt1, d1, wbt2, d2))
+            # the backward's gate operands: the sign of the stored activations, or the pinned planes
+            saved.append((x, a1 if m1 is None else m1, a2 if m2 is None else m2, out, wbt1, d1, wbt2, d2, a1))
             x = out
         if first_rgb:
             rgb.zero_()
@@ -432,7 +496,7 @@ class InrHeadFunction(torch.autograd.Function):
         Dout = None     # unmasked grad wrt out_k (kept while block k has a skip)
         dx0 = None
         for k in range(nblocks - 1, -1, -1):
-            xin, a1, a2, out, wbt1, d1, wbt2, d2 = saved[k]
+            xin, m1, a2, out, wbt1, d1, wbt2, d2, a1 = saved[k]      # m1, a2: gate operands (sign); a1: activation
             W1, s1, W2, s2 = blocks[k]
             skip = (k >= 4) and (a1.shape[-1] == xin.shape[-1])
             if k == nblocks - 1:
@@ -449,7 +513,7 @@ class InrHeadFunction(torch.autograd.Function):
             # ---- mod2: y2 = a1 @ wb2 ----
             gwb2 = bmm_tn(a1, g2)                                  # (B, out, out) = a1^T @ g2
             dW2, ds2 = modfc_prep_bwd(W2, s2, d2, gwb2)
-            g1 = bmm_nn(g2, wbt2, mask=a1)                         # dL/dy1 = (g2 @ wb2^T) * lrelu'(a1)
+            g1 = bmm_nn(g2, wbt2, mask=m1)                         # dL/dy1 = (g2 @ wb2^T) * lrelu'(a1)
             # ---- mod1: y1 = xin @ wb1 ----
             gwb1 = bmm_tn(xin, g1)
             dW1, ds1 = modfc_prep_bwd(W1, s1, d1, gwb1)
@@ -762,15 +826,29 @@ class InrHeadX3Function(torch.autograd.Function):
             wb1, wbt1, d1 = prepped[2 * k]
             a1P = Planes.empty(B, n, cout, device=dev)
             a1T = Planes.empty(B, cout, n, device=dev) if want_t else None
-            bits = train and INR_GATE_BITS and cout % 32 == 0
-            a1g = torch.empty(B, n, cout // 8, device=dev, dtype=torch.uint8) if bits else None
-            gemm_x3(xP, wbt1, n, cout, cin, cin, cin, B, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
-                    act=1, mask_out=a1g, gate_bits=2 if bits else 0)
+            dbg = GATE_PIN is not None or GATE_REC is not None          # gate instrumentation (tests): bit planes always
+            bits = (train or dbg) and (INR_GATE_BITS or dbg) and cout % 32 == 0
+            pin1 = _next_pin(B, n, cout, dev)
+            pin2 = _next_pin(B, n, cout, dev)
+            if (pin1 is not None or GATE_REC is not None) and not bits:
+                raise RuntimeError("gate instrumentation needs layer widths that are multiples of 32")
+            a1g = pin1 if pin1 is not None else (torch.empty(B, n, cout // 8, device=dev, dtype=torch.uint8) if bits else None)
+            if pin1 is not None:
+                # pinned: `gate ? 1 : slope` from the supplied plane in place of the LeakyReLU on the computed sign
+                gemm_x3(xP, wbt1, n, cout, cin, cin, cin, B, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
+                        mask=pin1, gate_bits=1)
+            else:
+                gemm_x3(xP, wbt1, n, cout, cin, cin, cin, B, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
+                        act=1, mask_out=a1g, gate_bits=2 if bits else 0)
             wb2, wbt2, d2 = prepped[2 * k + 1]
             skip = (k >= 4) and (cin == cout)
             oP = Planes.empty(B, n, cout, device=dev)
             oT = Planes.empty(B, cout, n, device=dev) if want_t else None
-            if bits:
+            if pin2 is not None:
+                m2 = pin2
+                gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
+                        strideT=cout * n, res=xP if skip else None, mask=pin2, gate_bits=1)
+            elif bits:
                 m2 = torch.empty(B, n, cout // 8, device=dev, dtype=torch.uint8)
                 gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
                         strideT=cout * n, act=1, res=xP if skip else None, mask_out=m2, gate_bits=2)
@@ -782,6 +860,9 @@ class InrHeadX3Function(torch.autograd.Function):
                 m2 = oP.hi
                 gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
                         strideT=cout * n, act=1)
+            if GATE_REC is not None:
+                GATE_REC.append(a1g)
+                GATE_REC.append(m2)
             if k >= 3:
                 torgb_fwd_x3(oP, rgbp[2 * (k - 3)], rgbp[2 * (k - 3) + 1], rgb.view(B * n, 3), accumulate=not first_rgb)
                 first_rgb = False

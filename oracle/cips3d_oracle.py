@@ -26,6 +26,61 @@ LRELU = 0.2
 
 
 # ----------------------------------------------------------------------------------------
+# LeakyReLU gate tape (test instrumentation).  LeakyReLU is the only discontinuity on the gradient
+# path that sees ~1e6+ activations per call (nn.LeakyReLU in SinBlock, generator.py:922/936;
+# FusedLeakyReLU in the discriminator, fused_act.py:51-86).  A pre-activation within rounding of 0 may
+# take either branch in two fp32 evaluations, so gradient parity is only well-defined for a GIVEN set
+# of gates.  The tape records the gates (pre-activation > 0) of every such LeakyReLU in call order, or
+# replays ("pins") gates recorded elsewhere — from the reference run (tests/golden/gates_*.pt) or from
+# the HIP path — making this restatement evaluate the same piecewise-linear branch.
+# ----------------------------------------------------------------------------------------
+class GateTape:
+    def __init__(self, pin=None):
+        """pin=None: record; else an iterable of bool tensors replayed in call order."""
+        self.rec = []
+        self.preact = []           # |pre-activation| kept alongside when recording (ambiguity of a gate)
+        self._pin = iter(pin) if pin is not None else None
+        self.keep_preact = False
+
+    def lrelu(self, y, slope):
+        if self._pin is None:
+            self.rec.append((y > 0).detach())
+            if self.keep_preact:
+                self.preact.append(y.detach().abs())
+            return F.leaky_relu(y, slope)
+        g = next(self._pin).to(y.device).reshape(y.shape)
+        self.rec.append(g)
+        if self.keep_preact:
+            self.preact.append(y.detach().abs())
+        return y * torch.where(g, torch.ones((), dtype=y.dtype), torch.full((), slope, dtype=y.dtype))
+
+    def done(self):
+        assert self._pin is None or next(self._pin, None) is None, "pinned gates left over"
+
+
+_TAPE = [None]
+
+
+class gate_tape:
+    """with gate_tape(tape): every head / discriminator LeakyReLU below goes through `tape`."""
+
+    def __init__(self, tape):
+        self.tape = tape
+
+    def __enter__(self):
+        self.old = _TAPE[0]
+        _TAPE[0] = self.tape
+        return self.tape
+
+    def __exit__(self, *exc):
+        _TAPE[0] = self.old
+
+
+def _gated_lrelu(y, slope=LRELU):
+    return F.leaky_relu(y, slope) if _TAPE[0] is None else _TAPE[0].lrelu(y, slope)
+
+
+# ----------------------------------------------------------------------------------------
 # mapping networks — exp/cips3d/models/multi_head_mapping.py:13-19 (PixelNorm), :130-153
 # ----------------------------------------------------------------------------------------
 def pixel_norm(z):
@@ -220,8 +275,8 @@ def inr_head(sd, fea, w_inr, prefix="inr_net.", return_all=False):
     outs = []
     for idx, name in enumerate(INR_NAMES):
         x0 = x
-        x = F.leaky_relu(mod_fc(sd, f"{prefix}network.{name}.mod1.", x, w_inr), LRELU)
-        x = F.leaky_relu(mod_fc(sd, f"{prefix}network.{name}.mod2.", x, w_inr), LRELU)
+        x = _gated_lrelu(mod_fc(sd, f"{prefix}network.{name}.mod1.", x, w_inr), LRELU)
+        x = _gated_lrelu(mod_fc(sd, f"{prefix}network.{name}.mod2.", x, w_inr), LRELU)
         if idx >= 4 and x.shape[-1] == x0.shape[-1]:
             x = x + x0
         if idx >= 3:
@@ -347,7 +402,7 @@ def generator_forward(sd, zs, rand, img_size, fov, ray_start, ray_end, num_steps
 # ----------------------------------------------------------------------------------------
 def fused_leaky_relu(x, bias, slope=0.2, scale=2 ** 0.5):
     rest = [1] * (x.ndim - bias.ndim - 1)
-    return F.leaky_relu(x + bias.view(1, bias.shape[0], *rest), slope) * scale
+    return _gated_lrelu(x + bias.view(1, bias.shape[0], *rest), slope) * scale
 
 
 def fused_bias_act(x, bias, ref, act, grad, alpha, scale):

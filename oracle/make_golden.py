@@ -69,6 +69,56 @@ class Capture:
         torch.rand, torch.randn, torch.randperm, torch.randint = self._rand, self._randn, self._randperm, self._randint
 
 
+def pack_gate(g):
+    """bool tensor -> dict(shape, bits): flat little-endian bit packing (bit i&7 of byte i>>3); for a (b,n,C) head
+    activation with C % 8 == 0 this is the kernels' gate bit-plane layout (include/cips3d_hip.h: gate_bits)."""
+    import numpy as np
+    return dict(shape=tuple(g.shape), bits=torch.from_numpy(np.packbits(g.reshape(-1).numpy(), bitorder="little")))
+
+
+class HeadGates:
+    """Record the gate (input > 0) of every LeakyReLU of the reference's CIPS head (SinBlock.act1 / act2,
+    generator.py:922, 936) in call order."""
+
+    def __init__(self, G):
+        self.gates, self.handles = [], []
+        for name, m in G.inr_net.named_modules():
+            if isinstance(m, torch.nn.LeakyReLU):
+                self.handles.append(m.register_forward_pre_hook(lambda mod, inp: self.gates.append(pack_gate(inp[0].detach() > 0))))
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+
+
+class LeakyGates:
+    """Record the gate of every F.leaky_relu call (the discriminator: all of them are FusedLeakyReLU /
+    fused_leaky_relu, fused_act.py:51-86) in call order."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.gates, self._orig = [], F.leaky_relu
+
+        def leaky_relu(input, negative_slope=0.01, inplace=False):
+            self.gates.append(pack_gate(input.detach() > 0))
+            return self._orig(input, negative_slope, inplace)
+        F.leaky_relu = leaky_relu
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        F.leaky_relu = self._orig
+
+
+def save_gates(tag, gates, check_key, value):
+    """gates-only minting: the rerun must reproduce the committed fixture bit for bit"""
+    fix = torch.load(os.path.join(OUT, f"{tag}.pt"), map_location="cpu", weights_only=False)
+    assert torch.equal(fix[check_key], value), f"{tag}: rerun does not reproduce the committed fixture"
+    path = os.path.join(OUT, f"gates_{tag}.pt")
+    torch.save(dict(tag=tag, gates=gates), path)
+    print("gates", tag, "->", path, os.path.getsize(path) // 1024, "KiB", len(gates), "layers")
+
+
 def checksums(sd):
     return {k: (float(v.double().sum()), float(v.double().abs().sum())) for k, v in sd.items()}
 
@@ -86,7 +136,7 @@ def grad_digest(named_params, stride=97):
     return d
 
 
-def make_generator_part_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, grad_points):
+def make_generator_part_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, grad_points, mint="fixture"):
     """part_grad_forward (generator.py:1536-1657): gradients through a random pixel subset only."""
     torch.manual_seed(seed)
     G = ref_gen.GeneratorNerfINR(**g_cfg(), device="cpu")
@@ -95,9 +145,13 @@ def make_generator_part_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, g
     zs = G.get_zs(b)
     kw = dict(fov=12, ray_start=0.88, ray_end=1.12, num_steps=S, h_stddev=0.3, v_stddev=0.155,
               hierarchical_sample=hier, psi=1., sample_dist="gaussian")
+    hg = HeadGates(G)
     with Capture() as cap:
         imgs, pitch_yaw = G(zs, img_size=img_size, nerf_noise=nerf_noise, return_aux_img=aux,
                             grad_points=grad_points, forward_points=None, **kw)
+    hg.close()
+    if mint == "gates":
+        return save_gates(tag, hg.gates, "imgs", imgs.detach())
     per = (["noise_c", "u"] if hier else []) + ["noise_f"]
     names = ["jitter", "theta", "phi", "rand_idx"] + [n + "_grad" for n in per] + [n + "_rest" for n in per]
     assert len(cap.draws) == len(names), (len(cap.draws), names)
@@ -114,7 +168,7 @@ def make_generator_part_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, g
     print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "imgs", tuple(imgs.shape))
 
 
-def make_generator_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, freeze=False):
+def make_generator_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, freeze=False, mint="fixture"):
     torch.manual_seed(seed)
     cls = ref_gen.GeneratorNerfINR_freeze_NeRF if freeze else ref_gen.GeneratorNerfINR
     G = cls(**g_cfg(), device="cpu")
@@ -144,14 +198,18 @@ def make_generator_case(tag, seed, b, img_size, S, hier, nerf_noise, aux, freeze
     pigan_utils.fancy_integration = fi
     pigan_utils.sample_pdf = sp
     comm_utils.get_world_points_and_direction = rays
+    hg = HeadGates(G)
     try:
         with Capture() as cap:
             imgs, pitch_yaw = G(zs, img_size=img_size, nerf_noise=nerf_noise, return_aux_img=aux,
                                 grad_points=None, forward_points=None, **kw)
     finally:
+        hg.close()
         G.siren.forward = o_siren
         pigan_utils.fancy_integration, pigan_utils.sample_pdf = o_fi, o_sp
         comm_utils.get_world_points_and_direction = o_rays
+    if mint == "gates":
+        return save_gates(tag, hg.gates, "imgs", imgs.detach())
     draws = cap.draws
     names = ["jitter", "theta", "phi"] + (["noise_c", "u"] if hier else []) + ["noise_f"]
     assert len(draws) == len(names), (len(draws), names)
@@ -267,7 +325,7 @@ def make_diffaug_case():
     print("diffaug ->", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def make_discriminator_case(tag, seed, b, size, alpha, use_aux, diffaug=False):
+def make_discriminator_case(tag, seed, b, size, alpha, use_aux, diffaug=False, mint="fixture"):
     torch.manual_seed(seed)
     cfg = d_cfg()
     cfg["diffaug"] = diffaug
@@ -275,8 +333,10 @@ def make_discriminator_case(tag, seed, b, size, alpha, use_aux, diffaug=False):
     sums = checksums(D.state_dict())
     torch.manual_seed(seed + 1)
     x = (torch.rand(b * (2 if use_aux else 1), 3, size, size) * 2 - 1).requires_grad_(True)
-    with Capture() as cap:
+    with Capture() as cap, LeakyGates() as lg:
         out, _, _ = D(x, alpha=alpha, use_aux_disc=use_aux)
+    if mint == "gates":
+        return save_gates(tag, lg.gates, "out", out.detach())
     # R1 path of train.py:385-409
     grad_real, = torch.autograd.grad(outputs=out.sum(), inputs=x, create_graph=True)
     pen = grad_real.flatten(1).pow(2).sum(1)
@@ -325,25 +385,38 @@ def make_op_cases():
     print("upfirdn2d ->", path, os.path.getsize(path) // 1024, "KiB")
 
 
-if __name__ == "__main__":
+def main(mint):
+    """mint = "fixture": everything; "gates": only tests/golden/gates_<tag>.pt (the LeakyReLU gates of the reference's
+    run of every training-path case; each rerun is checked bit for bit against the committed fixture)."""
     os.makedirs(OUT, exist_ok=True)
-    make_generator_case("g_r16_hier", seed=1234, b=2, img_size=16, S=6, hier=True, nerf_noise=0.0, aux=True)
-    make_generator_case("g_r8_flat_noise", seed=0, b=2, img_size=8, S=4, hier=False, nerf_noise=0.3, aux=False)
-    make_generator_case("g_r8_hier_noise", seed=5, b=1, img_size=8, S=5, hier=True, nerf_noise=0.25, aux=False)
-    make_generator_case("g_r8_freeze", seed=3, b=2, img_size=8, S=4, hier=True, nerf_noise=0.0, aux=False, freeze=True)
-    make_generator_part_case("g_r16_part", seed=21, b=2, img_size=16, S=5, hier=True, nerf_noise=0.2, aux=True,
-                             grad_points=96)
-    make_generator_part_case("g_r16_part_odd", seed=22, b=2, img_size=16, S=4, hier=True, nerf_noise=0.0, aux=False,
-                             grad_points=100)
+    G, D = make_generator_case, make_discriminator_case
+    for m in (["fixture", "gates"] if mint == "fixture" else ["gates"]):
+        G("g_r16_hier", seed=1234, b=2, img_size=16, S=6, hier=True, nerf_noise=0.0, aux=True, mint=m)
+        G("g_r8_flat_noise", seed=0, b=2, img_size=8, S=4, hier=False, nerf_noise=0.3, aux=False, mint=m)
+        G("g_r8_hier_noise", seed=5, b=1, img_size=8, S=5, hier=True, nerf_noise=0.25, aux=False, mint=m)
+        G("g_r8_freeze", seed=3, b=2, img_size=8, S=4, hier=True, nerf_noise=0.0, aux=False, freeze=True, mint=m)
+        make_generator_part_case("g_r16_part", seed=21, b=2, img_size=16, S=5, hier=True, nerf_noise=0.2, aux=True,
+                                 grad_points=96, mint=m)
+        make_generator_part_case("g_r16_part_odd", seed=22, b=2, img_size=16, S=4, hier=True, nerf_noise=0.0, aux=False,
+                                 grad_points=100, mint=m)
+        D("d_r16", seed=11, b=2, size=16, alpha=1.0, use_aux=False, mint=m)
+        D("d_r16_aux_alpha", seed=12, b=2, size=16, alpha=0.5, use_aux=True, mint=m)
+        D("d_r16_diffaug", seed=13, b=2, size=16, alpha=0.7, use_aux=True, diffaug=True, mint=m)
+    if mint == "fixture":
+        make_rest()
+
+
+def make_rest():
     make_generator_eval_case("g_r8_eval_psi_staged", seed=31, b=2, img_size=8, S=4, hier=True, psi=0.7, forward_points=24,
                              nerf_noise=0.0, aux=True, clamp_mode="relu", last_back=True, white_back=False)
     make_generator_eval_case("g_r8_eval_camera", seed=32, b=2, img_size=8, S=5, hier=True, psi=1.0, forward_points=None,
                              nerf_noise=0.15, aux=False, clamp_mode="softplus", last_back=False, white_back=True, camera=True)
     make_generator_eval_case("g_r8_eval_camera_staged", seed=33, b=1, img_size=8, S=4, hier=True, psi=1.0, forward_points=40,
                              nerf_noise=0.1, aux=True, clamp_mode="relu", last_back=False, white_back=False, camera=True)
-    make_discriminator_case("d_r16", seed=11, b=2, size=16, alpha=1.0, use_aux=False)
-    make_discriminator_case("d_r16_aux_alpha", seed=12, b=2, size=16, alpha=0.5, use_aux=True)
-    make_discriminator_case("d_r16_diffaug", seed=13, b=2, size=16, alpha=0.7, use_aux=True, diffaug=True)
     make_diffaug_case()
     make_camera_cases()
     make_op_cases()
+
+
+if __name__ == "__main__":
+    main("gates" if "gates" in sys.argv[1:] else "fixture")

@@ -31,6 +31,33 @@ def load_golden(name):
     return torch.load(os.path.join(GOLDEN, name + ".pt"), map_location="cpu", weights_only=False)
 
 
+def load_gates(tag):
+    """LeakyReLU gates of the reference's run of golden case `tag` (oracle/make_golden.py gates) -> list of bool
+    tensors in call order (head: (b, n, C) per modulated-FC layer; discriminator: the activation's shape)."""
+    import numpy as np
+    out = []
+    for e in load_golden("gates_" + tag)["gates"]:
+        n = 1
+        for s_ in e["shape"]:
+            n *= s_
+        bits = np.unpackbits(e["bits"].numpy(), count=n, bitorder="little")
+        out.append(torch.from_numpy(bits).bool().reshape(e["shape"]))
+    return out
+
+
+def pack_bitplane(g):
+    """bool (..., C) with C % 8 == 0 -> uint8 (..., C/8), bit c&7 of byte c>>3: the kernels' gate bit-plane layout"""
+    w = (1 << torch.arange(8, device=g.device)).to(torch.uint8)
+    return (g.reshape(*g.shape[:-1], g.shape[-1] // 8, 8).to(torch.uint8) * w).sum(-1).to(torch.uint8)
+
+
+def unpack_bitplane(p, C=None):
+    """uint8 (..., C/8) -> bool (..., C)"""
+    sh = torch.arange(8, device=p.device)
+    g = ((p.unsqueeze(-1).to(torch.int32) >> sh) & 1).bool().reshape(*p.shape[:-1], p.shape[-1] * 8)
+    return g if C is None else g[..., :C]
+
+
 def seeded_generator(seed, freeze=False, device="cpu"):
     """Product module under the reference's seed: reproduces the reference's initial state_dict
     bit-for-bit (verified against the per-key checksums stored in the golden fixtures)."""

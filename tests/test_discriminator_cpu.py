@@ -4,7 +4,7 @@ oracle's discriminator restatement is pinned to the golden vectors minted from t
 import pytest
 import torch
 
-from conftest import load_golden, check_checksums, max_rel, D_CFG, ReplayDraws
+from conftest import load_golden, load_gates, check_checksums, max_rel, D_CFG, ReplayDraws
 from oracle import cips3d_oracle as orc
 
 
@@ -49,3 +49,58 @@ def test_discriminator_oracle_matches_reference(tag):
     assert max_rel(g, fix["grad_real"]) < 1e-4
     loss = torch.nn.functional.softplus(-out).mean() + 0.5 * 10. * g.flatten(1).pow(2).sum(1).mean()
     assert abs(float(loss) - fix["loss"]) < 1e-5 * max(1.0, abs(fix["loss"]))
+
+
+def d_loss_grads(fix, dtype, tape):
+    """full d_loss of train.py:385-409 (logits, R1 penalty through the double-backward graph) on the oracle -> logits,
+    grad_real, {name: parameter gradient}"""
+    D = seeded_discriminator(fix["seed"], diffaug=fix.get("diffaug", False))
+    if dtype == torch.float64:
+        D = D.double()
+    sd = dict(D.state_dict())
+    sd.update(dict(D.named_parameters()))
+    x = fix["x"].to(dtype).clone().requires_grad_(True)
+    draws = [t.to(dtype) if torch.is_floating_point(t) else t for _, t in fix["draws"]] if fix.get("diffaug") else None
+    torch.set_default_dtype(dtype)
+    try:
+        with orc.gate_tape(tape):
+            out = orc.discriminator_forward(sd, x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"], draws=draws)
+        g, = torch.autograd.grad(out.sum(), x, create_graph=True)
+        loss = torch.nn.functional.softplus(-out).mean() + 0.5 * 10. * g.flatten(1).pow(2).sum(1).mean()
+        loss.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return out.detach(), g.detach(), {n: p.grad for n, p in D.named_parameters()}
+
+
+@pytest.mark.parametrize("tag", ["d_r16", "d_r16_aux_alpha", "d_r16_diffaug"])
+def test_discriminator_oracle_gates_pinned(tag):
+    """With the reference's LeakyReLU gates pinned (tests/golden/gates_*.pt), the oracle's R1 input gradient and the
+    parameter gradients of the full d_loss equal the reference's to fp32 rounding — in fp32 and in fp64 (the GPU
+    tests' yardstick): no gate allowance."""
+    fix = load_golden(tag)
+    gates = load_gates(tag)
+    free = orc.GateTape()
+    d_loss_grads(fix, torch.float32, free)
+    flips = sum(int((a != b).sum()) for a, b in zip(free.rec, gates))
+    total = sum(g.numel() for g in gates)
+    print(f"{tag}: oracle fp32 vs reference fp32: {flips} of {total} gates differ")
+    assert len(free.rec) == len(gates) and flips <= 2
+    for dtype in (torch.float32, torch.float64):
+        tape = orc.GateTape(pin=gates)
+        out, g, grads = d_loss_grads(fix, dtype, tape)
+        tape.done()
+        assert max_rel(out.float(), fix["out"]) < 1e-5
+        assert max_rel(g.float(), fix["grad_real"]) < 1e-4
+        worst = 0.0
+        for name, gr in grads.items():
+            dg = fix["grads"][name]
+            if dg is None:
+                assert gr is None or float(gr.abs().max()) == 0.0, name
+                continue
+            v = gr.reshape(-1).double()
+            got = v[::dg["stride"]] if dg["stride"] > 1 else v
+            e = float((got - dg["sample"].double()).norm() / dg["sample"].double().norm().clamp_min(1e-300))
+            worst = max(worst, e)
+            assert e < 1e-4 and abs(float(v.norm()) - dg["norm"]) <= 1e-4 * dg["norm"], (name, e)
+        print(f"{tag}: {dtype} oracle, reference gates pinned: worst parameter-gradient error {worst:.2e}")

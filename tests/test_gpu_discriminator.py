@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from conftest import load_golden, check_checksums, max_rel, rel_err, D_CFG
+from oracle import cips3d_oracle as orc
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -62,62 +63,98 @@ def test_conv2d_x3_eligible_shapes_double_backward(mode, monkeypatch):
         assert rel_err(xd.grad, x.grad) < 3 * tol and rel_err(wd.grad, w.grad) < 3 * tol, (mode, C, O, H, k, stride)
 
 
+def _d_oracle64(fix, gates):
+    """fp64 oracle of the full d_loss (train.py:385-409) with pinned LeakyReLU gates -> logits, grad_real, {grads}"""
+    from test_discriminator_cpu import d_loss_grads
+    tape = orc.GateTape(pin=gates)
+    tape.keep_preact = True
+    out, g, grads = d_loss_grads(fix, torch.float64, tape)
+    tape.done()
+    return out, g, grads, tape
+
+
 @pytest.mark.parametrize("conv_mode", ["bf16x3", "f32"])
 @pytest.mark.parametrize("tag", ["d_r16", "d_r16_aux_alpha", "d_r16_diffaug"])
 def test_discriminator_matches_reference_golden(tag, conv_mode, monkeypatch):
+    """Logits, R1 input gradient (double-backward graph) and the parameter gradients of the full d_loss against the
+    reference, for the SAME LeakyReLU gates, no gate allowance:
+      (A) gates pinned to the reference's (tests/golden/gates_*.pt): everything within 1e-3 of the reference;
+      (B) free-running: the product's own gates differ from the reference's at a handful of pre-activations that are
+          ambiguous at the conv arithmetic's precision, and its gradients match the fp64 oracle at ITS gates."""
     from cips3d_amd import discriminator as dmod
     from cips3d_amd.discriminator import Discriminator_MultiScale_Aux
+    from conftest import load_gates
     monkeypatch.setattr(dmod, "CONV_MODE", conv_mode)
     fix = load_golden(tag)
+    ref_gates = load_gates(tag)
     d = torch.device("cuda:0")
     torch.manual_seed(fix["seed"])
     D = Discriminator_MultiScale_Aux(**dict(D_CFG, diffaug=fix.get("diffaug", False)))
     check_checksums(D.state_dict(), fix["state_checksums"])
     D = D.to(d)
-    x = fix["x"].to(d).requires_grad_(True)
-    if fix.get("diffaug"):                 # DiffAugment on the input, with the draws the reference made
-        from conftest import ReplayDraws
-        with ReplayDraws(fix["draws"]):
-            out, _, _ = D(x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"])
-    else:
-        out, _, _ = D(x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"])
-    e = max_rel(out, fix["out"])
-    print(f"{tag}: logits max_rel {e:.3e}")
-    assert e < TOL
-    grad_real, = torch.autograd.grad(outputs=out.sum(), inputs=x, create_graph=True)
-    # LeakyReLU gates are discontinuous: a pre-activation within fp32 rounding of 0 may take the other
-    # branch than the reference's fp32 run did, which perturbs a local patch of ONE image's gradient by ~1e-2
-    # (seen here and between the reference's own fp32 and fp64 runs).  Require: almost all elements agree
-    # tightly, no element is far off.
-    scale = fix["grad_real"].abs().max()
-    diff = (grad_real.detach().cpu() - fix["grad_real"]).abs() / scale
-    frac_bad = float((diff > TOL).float().mean())
-    per_img = [float((diff[i] > TOL).float().mean()) for i in range(diff.shape[0])]
-    print(f"{tag}: R1 input-gradient max_rel {float(diff.max()):.3e}, fraction of elements off by >1e-3: {frac_bad:.4f} "
-          f"(per image {[round(f, 3) for f in per_img]})")
-    # Images are independent in D, so a flipped gate stays inside its image: at least half of the images must agree
-    # tightly everywhere, the perturbed ones must stay small.  Seen only in the DiffAugment case on the split-bf16 convs:
-    # next to the zero regions of translation / cutout many pre-activations are tiny, and two of them (convs.16.conv1,
-    # one image) change sign under the 1e-5 relative GEMM error; exact zeros stay exact.  The fp32 MFMA convs flip
-    # a gate as well now and then (d_r16_aux_alpha, one image): any fp32 evaluation order does.
-    assert float(diff.max()) < 5e-2 and frac_bad < 0.1
-    assert sum(f < 1e-3 for f in per_img) * 2 >= len(per_img)
-    loss = torch.nn.functional.softplus(-out).mean() + 0.5 * 10. * grad_real.flatten(1).pow(2).sum(1).mean()
-    assert abs(float(loss.detach()) - fix["loss"]) < TOL * max(1.0, abs(fix["loss"]))
-    loss.backward()
-    torch.cuda.synchronize()
-    worst = ("", 0.0)
-    GATE_TOL = 2e-2      # one flipped gate in a 2..4-image batch (see above)
-    for name, p in D.named_parameters():
-        dg = fix["grads"][name]
-        if dg is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
-            continue
-        g = p.grad.reshape(-1).cpu()
-        got = g[::dg["stride"]] if dg["stride"] > 1 else g
-        en = abs(float(g.double().norm()) - dg["norm"]) / max(dg["norm"], 1e-30)
-        es = float((got - dg["sample"]).double().norm() / dg["sample"].double().norm().clamp_min(1e-30))
-        if es > worst[1]:
-            worst = (name, es)
-        assert en < GATE_TOL and es < GATE_TOL, (name, en, es)
-    print(f"{tag}: worst param-grad sample rel err {worst[1]:.3e} at {worst[0]}")
+
+    def run(pin=None, rec=None):
+        for p in D.parameters():
+            p.grad = None
+        x = fix["x"].to(d).requires_grad_(True)
+        with dmod.gate_debug(pin=pin, rec=rec):
+            if fix.get("diffaug"):                 # DiffAugment on the input, with the draws the reference made
+                from conftest import ReplayDraws
+                with ReplayDraws(fix["draws"]):
+                    out, _, _ = D(x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"])
+            else:
+                out, _, _ = D(x, alpha=fix["alpha"], use_aux_disc=fix["use_aux"])
+        grad_real, = torch.autograd.grad(outputs=out.sum(), inputs=x, create_graph=True)
+        loss = torch.nn.functional.softplus(-out).mean() + 0.5 * 10. * grad_real.flatten(1).pow(2).sum(1).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach().cpu(), grad_real.detach().cpu(), float(loss.detach()), \
+            {n: (None if p.grad is None else p.grad.detach().cpu().double()) for n, p in D.named_parameters()}
+
+    def check(out, grad_real, loss, grads, want_out, want_g, want_grads, what, digest):
+        e = max_rel(out, want_out)
+        eg = max_rel(grad_real, want_g)
+        worst = ("", 0.0)
+        for name, g in grads.items():
+            dg = fix["grads"][name]
+            if dg is None:
+                assert g is None or float(g.abs().max()) == 0.0, name
+                continue
+            t = want_grads[name].reshape(-1).double()
+            es = float((g.reshape(-1) - t).norm() / t.norm().clamp_min(1e-300))
+            if digest:
+                v = g.reshape(-1)
+                got = v[::dg["stride"]] if dg["stride"] > 1 else v
+                es = max(es, float((got - dg["sample"].double()).norm() / dg["sample"].double().norm().clamp_min(1e-300)),
+                         abs(float(v.norm()) - dg["norm"]) / max(dg["norm"], 1e-300))
+            if es > worst[1]:
+                worst = (name, es)
+        print(f"{tag} [{conv_mode}] {what}: logits max_rel {e:.3e}, R1 input-gradient max_rel {eg:.3e}, worst "
+              f"parameter-gradient error {worst[1]:.3e} at {worst[0]}")
+        assert e < TOL and eg < 1e-4 and worst[1] < 1e-4, what      # measured <= 9e-6 on MI355X
+
+    o64, g64, grads64, tape_ref = _d_oracle64(fix, ref_gates)
+    # (A) pinned
+    out, grad_real, loss, grads = run(pin=ref_gates)
+    assert abs(loss - fix["loss"]) < TOL * max(1.0, abs(fix["loss"]))
+    assert max_rel(out, fix["out"]) < TOL and max_rel(grad_real, fix["grad_real"]) < TOL
+    check(out, grad_real, loss, grads, o64.float(), g64.float(), grads64, "reference gates pinned (vs fp64 oracle + reference digest)", True)
+    # (B) free-running
+    rec = []
+    out, grad_real, loss, grads = run(rec=rec)
+    assert max_rel(out, fix["out"]) < TOL and abs(loss - fix["loss"]) < TOL * max(1.0, abs(fix["loss"]))
+    own = [g.cpu() for g in rec]
+    assert [tuple(g.shape) for g in own] == [tuple(g.shape) for g in ref_gates]
+    flips, worst_amb = 0, 0.0
+    for a, b, y in zip(own, ref_gates, tape_ref.preact):
+        diff = a != b
+        if int(diff.sum()):
+            flips += int(diff.sum())
+            worst_amb = max(worst_amb, float(y[diff].max() / y.pow(2).mean().sqrt()))
+    total = sum(g.numel() for g in ref_gates)
+    print(f"{tag} [{conv_mode}] free: {flips} of {total} gates differ from the reference's; largest |pre-activation| / rms "
+          f"among them {worst_amb:.2e}")
+    assert worst_amb < (2e-4 if conv_mode == "bf16x3" else 2e-5) and flips <= 4 + total * 1e-4
+    if flips:
+        o64, g64, grads64, _ = _d_oracle64(fix, own)
+    check(out, grad_real, loss, grads, o64.float(), g64.float(), grads64, "free-running (vs fp64 oracle at the product's gates)", False)

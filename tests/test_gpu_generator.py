@@ -5,11 +5,13 @@ import math
 import pytest
 import torch
 
-from conftest import load_golden, seeded_generator, check_checksums, max_rel, rel_err, G_CFG
+from conftest import (load_golden, load_gates, seeded_generator, check_checksums, max_rel, rel_err, G_CFG, pack_bitplane,
+                      unpack_bitplane)
 from oracle import cips3d_oracle as orc
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+GRAD_TOL = 2e-4    # parameter gradients for fixed gates: measured <= 7.3e-5 (bf16x3), <= 1.7e-5 (f32) on MI355X; the bar is 1e-3
 CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze", "g_r16_part",
          "g_r16_part_odd"]   # _part: part_grad_forward (96 of 256 pixels; _odd: 100, not a multiple of the 32-pixel GEMM granule)
 
@@ -26,108 +28,133 @@ def inr_mode(request):
     ops.INR_MODE, ops.SIREN_FWD_MODE = old
 
 
-@pytest.mark.parametrize("tag", CASES)
-def test_generator_matches_reference_golden(tag, inr_mode):
-    fix = load_golden(tag)
-    d = torch.device("cuda:0")
-    G = seeded_generator(fix["seed"], freeze=fix["freeze"], device=d)
-    check_checksums({k: v.cpu() for k, v in G.state_dict().items()}, fix["state_checksums"])
-    zs = {k: v.to(d) for k, v in fix["zs"].items()}
-    rand = {k: v.to(d) for k, v in fix["rand"].items()}
-    imgs, pitch_yaw = G(zs, img_size=fix["img_size"], nerf_noise=fix["nerf_noise"], return_aux_img=fix["aux"],
-                        grad_points=fix.get("grad_points"), forward_points=None, rand_override=rand, **fix["G_kwargs"])
-    torch.cuda.synchronize()
-    assert imgs.shape == fix["imgs"].shape
-    e = max_rel(imgs, fix["imgs"])
-    print(f"{tag} [{inr_mode}]: imgs max_rel vs reference {e:.3e}")
-    assert e < TOL
-    assert max_rel(pitch_yaw, fix["pitch_yaw"]) < 1e-5
-    (imgs * fix["G0"].to(d)).sum().backward()
-    torch.cuda.synchronize()
-    # Yardstick for gradients: an fp64 evaluation of the (reference-pinned) oracle.  The HIP path must
-    # be within 1e-3 of it, or as close to it as the reference's own fp32 gradients are (some tiny
-    # noisy cases are ill-conditioned in fp32: 1 - exp(-delta*sigma) with delta*sigma ~ 1e-4).
+def _oracle64(fix, gates, keep_preact=False):
+    """fp64 evaluation of the (reference-pinned) oracle with the given LeakyReLU gates pinned -> ({name: grad}, tape).
+    With the gates fixed the gradient is a smooth function of the inputs, so this is a yardstick without any
+    conditioning caveat (tests/test_oracle_golden.py: it agrees with the reference's own fp32 gradients to < 1e-5
+    when given the reference's gates)."""
     G64 = seeded_generator(fix["seed"], freeze=fix["freeze"]).double()
     kw = fix["G_kwargs"]
     dbl = lambda dd: {k: (v.double() if torch.is_floating_point(v) else v) for k, v in dd.items()}
+    tape = orc.GateTape(pin=gates)
+    tape.keep_preact = keep_preact
     torch.set_default_dtype(torch.float64)
     try:
-        o64 = orc.generator_forward(dict(G64.named_parameters()), dbl(fix["zs"]), dbl(fix["rand"]), fix["img_size"],
-                                    kw["fov"], kw["ray_start"], kw["ray_end"], kw["num_steps"], kw["h_stddev"],
-                                    kw["v_stddev"], kw["hierarchical_sample"], nerf_noise=fix["nerf_noise"],
-                                    return_aux_img=fix["aux"], freeze_nerf=fix["freeze"],
-                                    grad_points=fix.get("grad_points"))
+        with orc.gate_tape(tape):
+            o64 = orc.generator_forward(dict(G64.named_parameters()), dbl(fix["zs"]), dbl(fix["rand"]), fix["img_size"],
+                                        kw["fov"], kw["ray_start"], kw["ray_end"], kw["num_steps"], kw["h_stddev"],
+                                        kw["v_stddev"], kw["hierarchical_sample"], nerf_noise=fix["nerf_noise"],
+                                        return_aux_img=fix["aux"], freeze_nerf=fix["freeze"],
+                                        grad_points=fix.get("grad_points"))
     finally:
         torch.set_default_dtype(torch.float32)
+    tape.done()
     (o64["imgs"] * fix["G0"].double()).sum().backward()
-    g64 = {n: p.grad for n, p in G64.named_parameters()}
-    # part_grad_forward sends gradients through ~100 pixels per image only: a single flipped LeakyReLU gate then moves
-    # EVERY upstream gradient by up to a few per cent (in pure fp64, perturbing the weights by 1e-7 relative — fp32
-    # rounding — moves siren.final_layer.bias of g_r16_part_odd by 3.9e-2).  Measure that conditioning floor here:
-    # three fp64 runs with the weights jittered at fp32 rounding level.
-    floor = {}
-    if fix.get("grad_points") is not None:
-        for seed in (1, 2, 3):
-            Gp = seeded_generator(fix["seed"], freeze=fix["freeze"]).double()
-            gen = torch.Generator().manual_seed(seed)
-            with torch.no_grad():
-                for p_ in Gp.parameters():
-                    p_.mul_(1 + 1e-7 * torch.randn(p_.shape, generator=gen, dtype=torch.float64))
-            torch.set_default_dtype(torch.float64)
-            try:
-                op = orc.generator_forward(dict(Gp.named_parameters()), dbl(fix["zs"]), dbl(fix["rand"]), fix["img_size"],
-                                           kw["fov"], kw["ray_start"], kw["ray_end"], kw["num_steps"], kw["h_stddev"],
-                                           kw["v_stddev"], kw["hierarchical_sample"], nerf_noise=fix["nerf_noise"],
-                                           return_aux_img=fix["aux"], freeze_nerf=fix["freeze"], grad_points=fix["grad_points"])
-            finally:
-                torch.set_default_dtype(torch.float32)
-            (op["imgs"] * fix["G0"].double()).sum().backward()
-            for n_, p_ in Gp.named_parameters():
-                if p_.grad is not None and g64.get(n_) is not None:
-                    dev_ = float((p_.grad - g64[n_]).norm() / g64[n_].norm().clamp_min(1e-300))
-                    floor[n_] = max(floor.get(n_, 0.0), dev_)
-    rows, bad = [], []
-    for name, p in G.named_parameters():
+    return {n: p.grad for n, p in G64.named_parameters()}, tape
+
+
+_REF64 = {}
+
+
+def _run_product(G, fix, d, pin=None, rec=None):
+    from cips3d_amd import ops
+    zs = {k: v.to(d) for k, v in fix["zs"].items()}
+    rand = {k: v.to(d) for k, v in fix["rand"].items()}
+    for p in G.parameters():
+        p.grad = None
+    with ops.gate_debug(pin=pin, rec=rec):
+        imgs, pitch_yaw = G(zs, img_size=fix["img_size"], nerf_noise=fix["nerf_noise"], return_aux_img=fix["aux"],
+                            grad_points=fix.get("grad_points"), forward_points=None, rand_override=rand, **fix["G_kwargs"])
+    (imgs * fix["G0"].to(d)).sum().backward()
+    torch.cuda.synchronize()
+    return imgs.detach(), pitch_yaw.detach(), {n: (None if p.grad is None else p.grad.detach().cpu().double())
+                                                for n, p in G.named_parameters()}
+
+
+def _grad_errors(fix, grads, g64):
+    """-> rows (name, err vs the fp64 yardstick over the whole tensor, err vs the reference's fp32 digest sample)"""
+    rows = []
+    for name, g in grads.items():
         dg = fix["grads"][name]
         if dg is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            assert g is None or float(g.abs().max()) == 0.0, name
             continue
-        assert p.grad is not None, name
+        assert g is not None, name
+        g = g.reshape(-1)
         t64 = g64[name].reshape(-1)
-        g = p.grad.reshape(-1).cpu().double()
-        e_hip = float((g - t64).norm() / t64.norm().clamp_min(1e-300))
-        st = dg["stride"]
+        e64 = float((g - t64).norm() / t64.norm().clamp_min(1e-300))
         ref32 = dg["sample"].double()
-        e_ref = float((ref32 - t64[::st]).norm() / t64[::st].norm().clamp_min(1e-300))
-        e_vs_ref = float((g[::st] - ref32).norm() / ref32.norm().clamp_min(1e-300))
-        rows.append((name, e_hip, e_ref, e_vs_ref))
-        # LeakyReLU gates are discontinuous: with ~1e6 activations per tiny case, about one pre-activation
-        # lands within fp32 rounding of 0 and its gate (1 vs 0.2) is arbitrary in ANY fp32 evaluation (the
-        # reference's own fp32 gradients show the same jumps vs fp64).  One flipped gate moves an INR-side
-        # weight gradient by ~0.8/sqrt(rows*512) relative; allow for it on the parameters behind the gates.
-        rows_px = fix["b"] * fix["img_size"] ** 2
-        gate_tol = 2.0 / (rows_px * 512) ** 0.5 if ("inr" in name) else 0.0
-        # bf16x3 carries pre-activations to ~5e-6 instead of ~3e-7: ~15x more ambiguous gates; measured
-        # gradient noise 0.5-1 % on every parameter upstream of the INR head, independent of problem size
-        # (forward agreement stays ~3e-6).  DESIGN.md §3 "numerics".
-        if inr_mode == "bf16x3":
-            gate_tol = max(3e-2, 3 * gate_tol)
-        if e_hip > max(TOL, 3 * e_ref, gate_tol, 3 * floor.get(name, 0.0)):
-            bad.append((name, e_hip, e_ref))
+        eref = float((g[::dg["stride"]] - ref32).norm() / ref32.norm().clamp_min(1e-300))
+        enorm = abs(float(g.norm()) - dg["norm"]) / max(dg["norm"], 1e-300)
+        rows.append((name, e64, max(eref, enorm)))
+    return rows
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_generator_matches_reference_golden(tag, inr_mode):
+    """Images within 1e-3 of the reference; parameter gradients within 1e-3 of the reference for the SAME LeakyReLU
+    gates, in both numeric modes, with no gate allowance:
+      (A) head gates pinned to the reference's (tests/golden/gates_*.pt): every parameter gradient matches the
+          reference's fp32 gradient digest and the fp64 oracle (same gates) — this holds everything upstream of the
+          head (SIREN, composite, mapping networks, part-grad bookkeeping) to the bar as well;
+      (B) free-running (the product decides its own gates): the gates it chose differ from the reference's only at
+          pre-activations that are ambiguous at the mode's arithmetic precision (count and |pre-activation| bounded),
+          and its gradients match the fp64 oracle evaluated AT THE PRODUCT'S gates."""
+    fix = load_golden(tag)
+    ref_gates = load_gates(tag)
+    d = torch.device("cuda:0")
+    G = seeded_generator(fix["seed"], freeze=fix["freeze"], device=d)
+    check_checksums({k: v.cpu() for k, v in G.state_dict().items()}, fix["state_checksums"])
+    if tag not in _REF64:
+        _REF64[tag] = _oracle64(fix, ref_gates, keep_preact=True)
+    g64_ref, tape_ref = _REF64[tag]
+    total = sum(g.numel() for g in ref_gates)
+
+    # ---- (A) pinned to the reference's gates ----
+    imgs, pitch_yaw, grads = _run_product(G, fix, d, pin=[pack_bitplane(g) for g in ref_gates])
+    assert imgs.shape == fix["imgs"].shape
+    e = max_rel(imgs, fix["imgs"])
+    assert e < TOL and max_rel(pitch_yaw, fix["pitch_yaw"]) < 1e-5
+    rows_a = _grad_errors(fix, grads, g64_ref)
+    wa = max(rows_a, key=lambda r: max(r[1], r[2]))
+    print(f"{tag} [{inr_mode}] pinned: imgs max_rel {e:.3e}; worst gradient error {wa[1]:.3e} vs fp64 oracle, "
+          f"{wa[2]:.3e} vs the reference's fp32 digest, at {wa[0]} ({len(rows_a)} parameters)")
+    bad = [r for r in rows_a if max(r[1], r[2]) > GRAD_TOL]
+    assert not bad, bad
+
+    # ---- (B) free-running ----
+    rec = []
+    imgs, pitch_yaw, grads = _run_product(G, fix, d, rec=rec)
+    e = max_rel(imgs, fix["imgs"])
+    print(f"{tag} [{inr_mode}] free: imgs max_rel vs reference {e:.3e}")
+    assert e < TOL and max_rel(pitch_yaw, fix["pitch_yaw"]) < 1e-5
+    own = [unpack_bitplane(p.cpu()) for p in rec]
+    assert [tuple(g.shape) for g in own] == [tuple(g.shape) for g in ref_gates]
+    # gates that differ from the reference's: few, and only where the fp64 pre-activation is within the mode's
+    # arithmetic error of zero (relative to the layer's rms pre-activation)
+    amb = 2e-4 if inr_mode == "bf16x3" else 2e-5
+    flips, worst_amb = 0, 0.0
+    for a, b, y in zip(own, ref_gates, tape_ref.preact):
+        diff = a != b
+        k = int(diff.sum())
+        if k:
+            flips += k
+            worst_amb = max(worst_amb, float(y[diff].max() / y.pow(2).mean().sqrt()))
+    print(f"{tag} [{inr_mode}] free: {flips} of {total} gates differ from the reference's; largest |pre-activation| / rms "
+          f"among them {worst_amb:.2e}")
+    assert worst_amb < amb and flips <= 4 + total * (1e-4 if inr_mode == "bf16x3" else 1e-5)
+    g64_own, _ = _oracle64(fix, own) if flips else (g64_ref, None)
+    rows_b = _grad_errors(fix, grads, g64_own)
+    wb = max(rows_b, key=lambda r: r[1])
+    print(f"{tag} [{inr_mode}] free: worst gradient error vs the fp64 oracle at the product's gates {wb[1]:.3e} at {wb[0]}")
+    bad = [r for r in rows_b if r[1] > GRAD_TOL]
     import os
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/gradtable_{tag}_{inr_mode}.txt", "w") as fh:
-        fh.write("name  err_hip_vs_fp64  err_ref32_vs_fp64  err_hip_vs_ref32  max_abs_diff/max_abs  argmax\n")
-        for name, p in G.named_parameters():
-            if fix["grads"][name] is None:
-                continue
-            t64 = g64[name].reshape(-1); g = p.grad.reshape(-1).cpu().double()
-            diff = (g - t64).abs()
-            r = [x for x in rows if x[0] == name][0]
-            fh.write(f"{name} {r[1]:.3e} {r[2]:.3e} {r[3]:.3e} {float(diff.max() / t64.abs().max()):.3e} {int(diff.argmax())}\n")
-    worst = max(rows, key=lambda r: r[1])
-    print(f"{tag} [{inr_mode}]: worst grad err vs fp64 {worst[1]:.3e} (reference fp32 vs fp64 {worst[2]:.3e}, hip vs ref32 "
-          f"{worst[3]:.3e}) at {worst[0]}; params checked {len(rows)}")
+        fh.write(f"# {flips} of {total} gates differ from the reference's (largest |preact|/rms {worst_amb:.2e})\n")
+        fh.write("name  pinned:err_vs_fp64  pinned:err_vs_ref32_digest  free:err_vs_fp64_at_own_gates  free:err_vs_ref32_digest\n")
+        for ra, rb in zip(rows_a, rows_b):
+            fh.write(f"{ra[0]} {ra[1]:.3e} {ra[2]:.3e} {rb[1]:.3e} {rb[2]:.3e}\n")
     assert not bad, bad
 
 
@@ -205,17 +232,21 @@ def test_generator_full_size_properties(S, hier):
     G0 = (torch.randn(b, 3, 64, 64, generator=g) / (b * 3 * 64 * 64)).to(d)
     params = [p for p in G.parameters()]
 
-    def run(sl, scale=1.0):
+    from cips3d_amd import ops
+
+    def run(sl, scale=1.0, pin=None, rec=None):
         rs = {k: (v[sl] if k != "u" else v.view(b, n, S)[sl].reshape(-1, S)) for k, v in rand.items()}
         for p in params:
             p.grad = None
-        imgs, _ = G({k: v[sl] for k, v in zs.items()}, img_size=64, fov=12, ray_start=0.88, ray_end=1.12, num_steps=S,
-                    h_stddev=0.3, v_stddev=0.155, hierarchical_sample=hier, sample_dist="gaussian", rand_override=rs)
+        with ops.gate_debug(pin=pin, rec=rec):
+            imgs, _ = G({k: v[sl] for k, v in zs.items()}, img_size=64, fov=12, ray_start=0.88, ray_end=1.12, num_steps=S,
+                        h_stddev=0.3, v_stddev=0.155, hierarchical_sample=hier, sample_dist="gaussian", rand_override=rs)
         imgs.backward(G0[sl] * scale)
         return imgs.detach().clone(), [None if p.grad is None else p.grad.clone() for p in params]
 
     full = slice(0, b)
-    im1, g1 = run(full)
+    gates = []
+    im1, g1 = run(full, rec=gates)
     im2, g2 = run(full)
     assert torch.isfinite(im1).all() and im1.abs().max() <= 1.0
     assert torch.equal(im1, im2), "forward is not deterministic"
@@ -230,7 +261,10 @@ def test_generator_full_size_properties(S, hier):
     acc = [None if x is None else torch.zeros_like(x, dtype=torch.float64) for x in g1]
     for q in range(4):
         sl = slice(8 * q, 8 * q + 8)
-        imq, gq = run(sl)
+        # the quarter batch takes the LeakyReLU gates the full batch took: its mapping MLPs run on other hipBLASLt
+        # kernels (8 rows instead of 32), which moves the styles by ~1e-7 and would flip a few of the 6.7e7 gates per
+        # layer — a discontinuity of the function, not a sharding error
+        imq, gq = run(sl, pin=[p[sl] for p in gates])
         e = max_rel(imq, im1[sl])
         assert e < 2e-5, f"images {8 * q}..{8 * q + 7} depend on the rest of the batch ({e:.2e})"
         for a_, x in zip(acc, gq):
@@ -243,14 +277,12 @@ def test_generator_full_size_properties(S, hier):
             e = rel_err(a_.float(), x)
             rows.append((e, nm))
             worst = max(worst, e)
-    # Gradient tolerance: the mapping MLPs (hipBLASLt picks another kernel for 8 rows than for 32) move the styles by
-    # ~1e-7 and the images by ~1e-5 (asserted above at 2e-5).  At that perturbation about 1e-5 of the 6.7e7 LeakyReLU
-    # gates per layer sit on the other side of zero, each changing one term of a heavily cancelling sum:
-    # measured 5-6e-3 on every parameter alike.  A dropped image, chunk or partial sum would
-    # show up at >= 0.15.
+    # With the gates fixed the gradient is smooth: what is left is fp32 summation order (mapping MLPs on another
+    # hipBLASLt kernel, partial sums over 8 instead of 32 images).  A dropped image, chunk or partial sum would show up
+    # at >= 0.15.
     print(f"   worst parameters: {sorted(rows, reverse=True)[:3]}")
-    print(f"C2 full size S={S} hier={hier}: sum of quarter-batch gradients vs batch gradient, worst rel err {worst:.2e}")
-    assert worst < 2e-2
+    print(f"C2 full size S={S} hier={hier}: sum of quarter-batch gradients vs batch gradient (same gates), worst rel err {worst:.2e}")
+    assert worst < 1e-3
 
 
 @pytest.mark.parametrize("tag", ["g_r8_eval_psi_staged", "g_r8_eval_camera", "g_r8_eval_camera_staged"])
