@@ -109,7 +109,7 @@ SIGNATURES = {
     "cips_modfc_prep_x3_batch": (i32, [C.POINTER(ModfcPrepJob), i32, i32, C.c_float, vp]),
     "cips_modfc_prep_bwd_batch": (i32, [C.POINTER(ModfcBwdJob), i32, i32, vp]),
     "cips_opt_chunk": (i32, []),
-    "cips_opt_step": (i32, [vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp]),
+    "cips_opt_step": (i32, [vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]),
     "cips_torgb_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
     "cips_torgb_bwd_partials": (i32, [i64]),
     "cips_torgb_bwd_w": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),

@@ -5,6 +5,14 @@
 
 #define CIPS_CHECK_LAUNCH() (int)hipGetLastError()
 
+// Launchers cache per-DEVICE facts in function-local statics (dynamic-LDS attribute set, CU count).  One process
+// normally drives one GPU, but nothing enforces it: a cached flag is reset whenever the calling thread's current device
+// is not the one it was set for, so a second GPU gets its own hipFuncSetAttribute / CU count.
+static inline int cips_current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+#define CIPS_PER_DEVICE(flag, zero)                                                      \
+  do { static int cips_dev_ = -1; const int cips_d_ = cips_current_device();             \
+       if (cips_d_ != cips_dev_) { flag = zero; cips_dev_ = cips_d_; } } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

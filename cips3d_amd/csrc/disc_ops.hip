@@ -276,7 +276,7 @@ inline unsigned grid_for(long long total) {
 
 }  // namespace
 
-extern "C" int cips_version(void) { return 1; }
+extern "C" int cips_version(void) { return 2; }
 extern "C" const char* cips_arch(void) { return "gfx950"; }
 
 extern "C" int cips_fused_bias_act(const float* x, const float* bias, const float* refer, float* y,

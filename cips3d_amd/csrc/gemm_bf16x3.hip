@@ -710,6 +710,7 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   }
   // tile choice: 256x128 / 8 waves / 3-stage ring (default, measured fastest); CIPS_X3_TILE=128 selects 128x128 / 4 waves / 4 stages
   static int tile = 0;
+  CIPS_PER_DEVICE(tile, 0);
   if (!tile) {
     const char* e = getenv("CIPS_X3_TILE");
     tile = (e && atoi(e) == 128) ? 128 : 256;
@@ -725,6 +726,7 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
   static int ncu = 0;
+  CIPS_PER_DEVICE(ncu, 0);
   if (!ncu) {   // persistent grid: one workgroup per CU for the 256-row form, two for the 128-row form
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
@@ -776,6 +778,7 @@ extern "C" int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t str
   g.total = (int)total;
   g.stagger_cycles = 0; g.ncu = 0; g.dbg = 0;
   static int ncu = 0;
+  CIPS_PER_DEVICE(ncu, 0);
   if (!ncu) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;

@@ -273,6 +273,7 @@ extern "C" int cips_gemm_bf16x3_km_grouped(const cips_gemm_x3_desc* descs, int n
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
   static int ncu = 0;
+  CIPS_PER_DEVICE(ncu, 0);
   if (!ncu) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
@@ -313,6 +314,7 @@ extern "C" int cips_conv2d_x3_wgrad(const cips_conv_wgrad_desc* c, cips_stream_t
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
   static int ncu = 0;
+  CIPS_PER_DEVICE(ncu, 0);
   if (!ncu) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;

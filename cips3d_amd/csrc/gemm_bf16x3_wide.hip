@@ -439,6 +439,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
 template <bool A, bool Mk, bool R, bool CV = false>
 static void launch_wide(const WArgs& g, int grid, hipStream_t stream) {
   static bool attr = false;
+  CIPS_PER_DEVICE(attr, false);
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16x3_wide_kernel<A, Mk, R, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     attr = true;
@@ -448,6 +449,7 @@ static void launch_wide(const WArgs& g, int grid, hipStream_t stream) {
 
 static int wide_grid(int total) {
   static int ncu = 0;
+  CIPS_PER_DEVICE(ncu, 0);
   if (!ncu) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
@@ -499,6 +501,7 @@ extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t s
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
   static int ncu = 0, gdbg = 0;
+  CIPS_PER_DEVICE(ncu, 0);
   if (!ncu) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;

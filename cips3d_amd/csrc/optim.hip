@@ -21,11 +21,15 @@ constexpr int CHUNK = 65536;
 __global__ __launch_bounds__(256) void opt_sqnorm_kernel(const cips_opt_tensor* __restrict__ T,
                                                          const int* __restrict__ chunk_tensor,
                                                          const long long* __restrict__ chunk_off,
-                                                         double* __restrict__ partial) {
+                                                         double* __restrict__ partial, long long* __restrict__ steps) {
   __shared__ double red[256];
   const int c = blockIdx.x;
   const cips_opt_tensor t = T[chunk_tensor[c]];
   const long long off = chunk_off[c];
+  // device-side Adam step counts (per tensor, like torch.optim.Adam's state): the first chunk of a tensor that has a
+  // gradient advances it here; the update launch reads it.  Nothing about the step count is baked into host-written
+  // data, so a captured hipGraph of the step advances its bias corrections on every replay.
+  if (steps && t.grad && off == 0 && threadIdx.x == 0) steps[chunk_tensor[c]] += 1;
   const long long end = (off + CHUNK < t.n) ? off + CHUNK : t.n;
   float acc = 0.f;
   if (t.grad)
@@ -44,6 +48,7 @@ struct StepArgs {
   const int* chunk_tensor;
   const long long* chunk_off;
   const double* partial;
+  const long long* steps;     // optional device-side per-tensor step counts (already advanced by launch 1)
   float* total_norm;          // optional: the pre-clip norm, for logging
   int nchunks;
   float max_norm;             // <= 0: no clipping
@@ -79,8 +84,10 @@ __global__ __launch_bounds__(256) void opt_step_kernel(StepArgs a) {
   const long long end = (off + CHUNK < t.n) ? off + CHUNK : t.n;
   // bias corrections from THIS tensor's step count (torch.optim.Adam counts steps per parameter: one that had no
   // gradient in some iteration lags behind)
-  const float bc1 = (float)(1.0 - pow((double)a.beta1, (double)t.step));
-  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, (double)t.step));
+  long long step = a.steps ? a.steps[a.chunk_tensor[c]] : t.step;
+  step = step < 1 ? 1 : step;
+  const float bc1 = (float)(1.0 - pow((double)a.beta1, (double)step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, (double)step));
   const float step_size = a.lr / bc1;
   for (long long i = off + threadIdx.x; i < end; i += 256) {
     float p = t.param[i];
@@ -107,12 +114,12 @@ extern "C" int cips_opt_chunk(void) { return CHUNK; }
 extern "C" int cips_opt_step(const cips_opt_tensor* table_dev, const int* chunk_tensor_dev, const long long* chunk_off_dev,
                              int nchunks, double* partial_dev, float* total_norm_dev, float max_norm, float lr,
                              float beta1, float beta2, float eps, float ema_decay, int write_grad,
-                             cips_stream_t stream) {
+                             long long* steps_dev, cips_stream_t stream) {
   if (!table_dev || !chunk_tensor_dev || !chunk_off_dev || !partial_dev || nchunks <= 0) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(nchunks), dim3(256), 0, st, table_dev, chunk_tensor_dev, chunk_off_dev, partial_dev);
+  hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(nchunks), dim3(256), 0, st, table_dev, chunk_tensor_dev, chunk_off_dev, partial_dev, steps_dev);
   StepArgs a;
-  a.T = table_dev; a.chunk_tensor = chunk_tensor_dev; a.chunk_off = chunk_off_dev; a.partial = partial_dev;
+  a.T = table_dev; a.chunk_tensor = chunk_tensor_dev; a.chunk_off = chunk_off_dev; a.partial = partial_dev; a.steps = steps_dev;
   a.total_norm = total_norm_dev; a.nchunks = nchunks; a.max_norm = max_norm;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
   a.ema_decay = ema_decay; a.write_grad = write_grad;

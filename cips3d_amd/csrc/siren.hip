@@ -481,6 +481,7 @@ extern "C" int cips_siren_fwd(const cips_siren_weights* w, const float* points, 
   dim3 grid((P + a.chunk - 1) / a.chunk, B);
   size_t smem = SMEM_FLOATS * sizeof(float);
   static bool attr_set = false;
+  CIPS_PER_DEVICE(attr_set, false);
   if (!attr_set) {
     hipFuncSetAttribute((const void*)siren_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipFuncSetAttribute((const void*)siren_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -512,6 +513,7 @@ extern "C" int cips_siren_bwd_data(const cips_siren_weights* w, const float* poi
   dim3 grid(a.chunks, B);
   size_t smem = SMEM_FLOATS * sizeof(float);
   static bool attr_set = false;
+  CIPS_PER_DEVICE(attr_set, false);
   if (!attr_set) {
     hipFuncSetAttribute((const void*)siren_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipFuncSetAttribute((const void*)siren_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

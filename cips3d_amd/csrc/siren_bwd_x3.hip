@@ -951,6 +951,7 @@ extern "C" int cips_siren_bwd_x3(const cips_siren_weights* w, const float* point
   a.chunks = (P + a.chunk - 1) / a.chunk;
   dim3 grid(a.chunks, B);
   static bool attr_set = false;
+  CIPS_PER_DEVICE(attr_set, false);
   if (!attr_set) {
     hipFuncSetAttribute((const void*)siren_bwd_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     hipFuncSetAttribute((const void*)siren_bwd_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
@@ -973,6 +974,7 @@ extern "C" int cips_siren_fwd_x3(const cips_siren_weights* w, const float* point
   dim3 grid((P + a.chunk - 1) / a.chunk, B);
   const int smem = O_STG;            // weight images + FiLM vectors + the 4 KiB slot reused for the output bias
   static bool attr_set = false;
+  CIPS_PER_DEVICE(attr_set, false);
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)siren_fwd_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute((const void*)siren_fwd_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

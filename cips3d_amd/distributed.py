@@ -24,20 +24,32 @@ class GradAllReducer:
     Contract (that of DDP's static_graph): the set of parameters with a gradient may differ from
     rank to rank, but when it changes it changes on every rank in the same step — it is a function
     of the step's configuration (aux image on/off, frozen NeRF, which loss), not of the data.  Each
-    rank re-plans when ITS pattern changes, and the re-plan is a collective."""
+    rank re-plans when ITS pattern changes, and the re-plan is a collective.  The contract is
+    checked, cheaply: every bucket carries one extra element, a checksum of the plan it was packed
+    with; the reduced value is compared on the host one call later (through an event that has
+    long completed by then), so diverging ranks raise instead of silently mixing gradients.
+
+    Parameters are NOT filtered by `requires_grad` (train.py:335-336, 441-442 toggle it on G and D
+    every step): what takes part is decided per call by which gradients exist."""
 
     def __init__(self, params, bucket_mb=64.0, group=None):
-        self.params = [p for p in params if p.requires_grad]
+        self.params = list(params)
+        if not self.params:
+            raise ValueError("GradAllReducer: empty parameter list")
         self.group = group
         self.limit = int(bucket_mb * 1024 * 1024)
         self._local = None       # this rank's presence pattern the cached plan was built for
+        self._union = None       # the agreed pattern (union over ranks): what `.grad is not None` looks like after a call
         self._buckets = None     # list of lists of parameters (the union over ranks, bucketed)
+        self._sig = 0.0
+        self._pending = None     # (event, pinned host tensor, expected) of the previous call's plan check
 
     def _plan(self, local):
         dev = self.params[0].device
         present = torch.tensor([1.0 if f else 0.0 for f in local], device=dev)
         dist.all_reduce(present, op=dist.ReduceOp.MAX, group=self.group)
-        used = [p for p, f in zip(self.params, present.tolist()) if f > 0]
+        flags = [f > 0 for f in present.tolist()]
+        used = [p for p, f in zip(self.params, flags) if f]
         buckets, cur, size = [], [], 0
         for p in used:
             cur.append(p)
@@ -47,36 +59,66 @@ class GradAllReducer:
                 cur, size = [], 0
         if cur:
             buckets.append(cur)
-        self._local, self._buckets = local, buckets
+        self._local, self._union, self._buckets = local, tuple(flags), buckets
+        # plan checksum: exactly representable in fp32 so that the mean over identical ranks is exact
+        self._sig = float(sum((i + 1) * 7 for i, f in enumerate(flags) if f) % 65521)
+
+    def _check_pending(self, block=False):
+        if self._pending is None:
+            return
+        ev, host, want = self._pending
+        if ev is not None:
+            if not block and not ev.query():
+                return
+            ev.synchronize()
+        self._pending = None
+        if any(abs(float(v) - want) > 1e-3 for v in host.tolist()):
+            raise RuntimeError("GradAllReducer: ranks reduced with different bucket plans — the set of parameters with "
+                               "a gradient changed on some ranks only (see the class contract)")
 
     def __call__(self):
-        if not dist.is_available() or not dist.is_initialized() or not self.params:
+        if not dist.is_available() or not dist.is_initialized():
             return 0
         world = dist.get_world_size(self.group)
         if world == 1:
             return 0
+        self._check_pending()
         local = tuple(p.grad is not None for p in self.params)
-        # a change of the local pattern (another loss, a frozen sub-net) re-plans; see the contract above
-        if local != self._local:
+        # a change of the local pattern (another loss, a frozen sub-net) re-plans; see the contract above.  A caller
+        # that did not reset the gradients to None (zero_grad(set_to_none=False), gradient accumulation) shows the
+        # agreed union pattern on every rank: same plan, no re-plan.
+        if local != self._local and local != self._union:
+            self._check_pending(block=True)
             self._plan(local)
         nbytes = 0
+        sigs = []
         for bucket in self._buckets:
             for p in bucket:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
             grads = [p.grad for p in bucket]
-            flat = torch.cat([g.reshape(-1) for g in grads])
+            sig = torch.full((1,), self._sig, device=grads[0].device, dtype=grads[0].dtype)
+            flat = torch.cat([g.reshape(-1) for g in grads] + [sig])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             flat.div_(world)
-            nbytes += flat.numel() * flat.element_size()
+            nbytes += (flat.numel() - 1) * flat.element_size()
             views, off = [], 0
             for g in grads:
                 n = g.numel()
                 views.append(flat[off:off + n].view_as(g))
                 off += n
             torch._foreach_copy_(grads, views)
-        # parameters that were None here but got the others' mean now carry a grad: the local pattern for the next
-        # call is computed from p.grad again, after the caller's zero_grad / set-to-None, so nothing to fix up
+            sigs.append(flat[off:off + 1])
+        if sigs:
+            got = torch.cat(sigs).float()
+            if got.is_cuda:
+                host = torch.empty(got.shape, dtype=torch.float32).pin_memory()
+                host.copy_(got, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending = (ev, host, self._sig)
+            else:
+                self._pending = (None, got, self._sig)
         return nbytes
 
 

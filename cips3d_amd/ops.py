@@ -31,6 +31,11 @@ def _chk(*tensors):
             continue
         if not t.is_cuda:
             raise RuntimeError("cips3d_amd ops need tensors on the GPU (no CPU fallback)")
+        if t.device.index != torch.cuda.current_device():
+            # launches go to the CURRENT device's current stream (one process per GPU, torch.cuda.set_device(rank),
+            # train.py:48): a tensor of another device would be read through the wrong context
+            raise RuntimeError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                               "call torch.cuda.set_device first")
         if t.dtype != torch.float32 and t.dtype not in (torch.int32, torch.int64, torch.bfloat16):
             raise RuntimeError(f"cips3d_amd ops are fp32 (got {t.dtype})")
         if not t.is_contiguous():
@@ -982,40 +987,55 @@ def inr_head(nblocks, x0, *params):
 # --------------------------------------------------------------------------------------
 # H5 discriminator native ops (same contracts as the reference's pybind ops)
 # --------------------------------------------------------------------------------------
+_FLOATS = (torch.float32, torch.float16, torch.bfloat16, torch.float64)
+
+
+def _native_in(t, what):
+    """The reference's ops dispatch fp16 / fp32 / fp64 (fused_bias_act_kernel.cu:79, upfirdn2d_kernel.cu:177-211); the
+    HIP kernels compute in fp32: other float dtypes make an fp32 round trip (the result is cast back to the INPUT's
+    dtype by the caller), anything else is an error."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must be a CUDA tensor")      # CHECK_CUDA, fused_bias_act.cpp:13
+    if t.dtype not in _FLOATS:
+        raise RuntimeError(f"{what}: unsupported dtype {t.dtype} (floating point expected)")
+    return t.contiguous().float()
+
+
 def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
-    """fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale) -> Tensor
+    """fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale) -> Tensor of input's dtype and shape
     (exp/comm/op/fused_bias_act.cpp:11-21).  Empty tensor = absent."""
     lib = _lib.load()
-    if not input.is_cuda:
-        raise RuntimeError("input must be a CUDA tensor")   # CHECK_CUDA, fused_bias_act.cpp:13
-    x = input.contiguous().float()
-    b = bias.contiguous().float() if (bias is not None and bias.numel()) else None
-    r = refer.contiguous().float() if (refer is not None and refer.numel()) else None
+    x = _native_in(input, "input")
+    b = _native_in(bias, "bias") if (bias is not None and bias.numel()) else None
+    r = _native_in(refer, "refer") if (refer is not None and refer.numel()) else None
+    if r is not None and r.numel() != x.numel():
+        raise RuntimeError("refer must have input's number of elements")
     y = torch.empty_like(x)
     step_b = 1
     for i in range(2, x.dim()):
         step_b *= x.size(i)
     size_b = b.numel() if b is not None else 0
-    check(lib.cips_fused_bias_act(_p(x), _p(b), _p(r), _p(y), x.numel(), size_b, step_b, act, grad, float(alpha),
-                                  float(scale), _stream()), "cips_fused_bias_act")
-    return y
+    with torch.cuda.device(x.device):
+        check(lib.cips_fused_bias_act(_p(x), _p(b), _p(r), _p(y), x.numel(), size_b, step_b, act, grad, float(alpha),
+                                      float(scale), _stream()), "cips_fused_bias_act")
+    return y if input.dtype == torch.float32 else y.to(input.dtype)
 
 
 def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
-    """upfirdn2d_op.upfirdn2d(input[N,H,W,minor], kernel, ...) -> Tensor (exp/comm/op/upfirdn2d.cpp:12-23)."""
+    """upfirdn2d_op.upfirdn2d(input[N,H,W,minor], kernel, ...) -> Tensor of input's dtype
+    (exp/comm/op/upfirdn2d.cpp:12-23)."""
     lib = _lib.load()
-    if not input.is_cuda:
-        raise RuntimeError("input must be a CUDA tensor")
-    x = input.contiguous().float()
-    k = kernel.contiguous().float()
+    x = _native_in(input, "input")
+    k = _native_in(kernel, "kernel")
     major, in_h, in_w, minor = x.shape
     kh, kw = k.shape
     out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
     out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
     out = torch.empty(major, out_h, out_w, minor, device=x.device)
-    check(lib.cips_upfirdn2d(_p(x), _p(k), _p(out), major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y,
-                             pad_x0, pad_x1, pad_y0, pad_y1, _stream()), "cips_upfirdn2d")
-    return out
+    with torch.cuda.device(x.device):
+        check(lib.cips_upfirdn2d(_p(x), _p(k), _p(out), major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y,
+                                 pad_x0, pad_x1, pad_y0, pad_y1, _stream()), "cips_upfirdn2d")
+    return out if input.dtype == torch.float32 else out.to(input.dtype)
 
 
 def im2col(x, kh, kw, stride, pad):

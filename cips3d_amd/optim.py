@@ -41,7 +41,9 @@ class FusedClipAdamEMA:
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.max_norm = float(max_norm) if max_norm else 0.0
         self.ema_decay, self.ema_start_itr = float(ema_decay), int(ema_start_itr)
-        self.steps = [0] * len(self.params)      # per-parameter step counts, like torch.optim.Adam's state
+        # per-parameter step counts (torch.optim.Adam's state) live on the DEVICE and are advanced by the kernel: no
+        # host-written value goes stale between steps or inside a captured hipGraph of the step
+        self._steps_dev = torch.zeros(len(self.params), dtype=torch.int64, device=dev)
         self.device = dev
         total = sum(p.numel() for p in self.params)
         self._m = torch.zeros(total, device=dev)
@@ -64,7 +66,16 @@ class FusedClipAdamEMA:
         self._norm = torch.zeros(1, device=dev)
         self._table_host = (_OptTensor * len(self.params))()
         self._table_dev = torch.empty(C.sizeof(self._table_host), dtype=torch.uint8, device=dev)
-        self._table_pin = torch.empty(C.sizeof(self._table_host), dtype=torch.uint8).pin_memory()
+        # pinned staging ring for the table upload: a slot is rewritten only after the asynchronous copy that read it
+        # has completed (its event), so a host that runs ahead of the stream cannot overwrite a table in flight
+        self._ring = [[torch.empty(C.sizeof(self._table_host), dtype=torch.uint8).pin_memory(), None] for _ in range(4)]
+        self._ring_pos = 0
+        self._uploaded = None        # bytes of the table the device currently holds
+
+    @property
+    def steps(self):
+        """per-parameter Adam step counts (host copy; synchronises)"""
+        return [int(v) for v in self._steps_dev.tolist()]
 
     def zero_grad(self):
         for p in self.params:
@@ -84,23 +95,32 @@ class FusedClipAdamEMA:
             t.exp_avg, t.exp_avg_sq = self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
             t.ema = self.ema[i].data_ptr() if do_ema else None
             t.n = p.numel()
-            if g is not None:
-                self.steps[i] += 1
-            t.step = max(self.steps[i], 1)
-        C.memmove(self._table_pin.data_ptr(), C.addressof(self._table_host), C.sizeof(self._table_host))
-        self._table_dev.copy_(self._table_pin, non_blocking=True)
+            t.step = 0                       # unused: the step counts are device-side (steps_dev)
+        raw = bytes(self._table_host)
+        if raw != self._uploaded:            # pointers change when autograd reallocates gradients; often they do not
+            slot = self._ring[self._ring_pos]
+            self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+            if slot[1] is not None:
+                slot[1].synchronize()        # the copy that last read this slot (4 uploads ago) — long done
+            C.memmove(slot[0].data_ptr(), C.addressof(self._table_host), C.sizeof(self._table_host))
+            self._table_dev.copy_(slot[0], non_blocking=True)
+            if not torch.cuda.is_current_stream_capturing():
+                slot[1] = torch.cuda.Event()
+                slot[1].record()
+            self._uploaded = raw
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         check(lib.cips_opt_step(C.c_void_p(self._table_dev.data_ptr()), C.c_void_p(self._chunk_tensor.data_ptr()),
                                 C.c_void_p(self._chunk_off.data_ptr()), self.nchunks,
                                 C.c_void_p(self._partial.data_ptr()), C.c_void_p(self._norm.data_ptr()),
                                 self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
-                                self.ema_decay, 1, st), "cips_opt_step")
+                                self.ema_decay, 1, C.c_void_p(self._steps_dev.data_ptr()), st), "cips_opt_step")
         return self._norm
 
     def state_dict(self):
         """torch.optim.Adam-compatible state (per-parameter step / exp_avg / exp_avg_sq)."""
-        state = {i: dict(step=torch.tensor(float(self.steps[i])), exp_avg=self.exp_avg[i].clone(),
-                         exp_avg_sq=self.exp_avg_sq[i].clone()) for i in range(len(self.params)) if self.steps[i] > 0}
+        steps = self.steps
+        state = {i: dict(step=torch.tensor(float(steps[i])), exp_avg=self.exp_avg[i].clone(),
+                         exp_avg_sq=self.exp_avg_sq[i].clone()) for i in range(len(self.params)) if steps[i] > 0}
         group = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=0, amsgrad=False,
                      params=list(range(len(self.params))))
         return dict(state=state, param_groups=[group])
@@ -108,6 +128,6 @@ class FusedClipAdamEMA:
     def load_state_dict(self, sd):
         for i, st in sd["state"].items():
             self.exp_avg[int(i)].copy_(st["exp_avg"]); self.exp_avg_sq[int(i)].copy_(st["exp_avg_sq"])
-            self.steps[int(i)] = int(float(st["step"]))
+            self._steps_dev[int(i)] = int(float(st["step"]))
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps = float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"])

@@ -377,7 +377,10 @@ int cips_col2im(const float* col, float* dx, int B, int C, int H, int W,
  * The tensors are walked in chunks of cips_opt_chunk() elements: chunk_tensor_dev[c] = tensor index,
  * chunk_off_dev[c] = first element; partial_dev: nchunks doubles of scratch; total_norm_dev (optional): pre-clip norm.
  * max_norm <= 0 disables clipping; `step` = this tensor's 1-based Adam step count (torch counts per parameter);
- * write_grad != 0 stores the clipped gradient back. */
+ * write_grad != 0 stores the clipped gradient back.
+ * steps_dev (optional, one long long per tensor): device-side step counts — the call advances the count of every
+ * tensor that has a gradient and uses it instead of the table's `step`, so neither the table nor a captured hipGraph of
+ * the call goes stale from one step to the next. */
 typedef struct cips_opt_tensor {
   float* param; const float* grad; float* exp_avg; float* exp_avg_sq; float* ema; long long n; long long step;
 } cips_opt_tensor;
@@ -385,7 +388,7 @@ int cips_opt_chunk(void);
 int cips_opt_step(const cips_opt_tensor* table_dev, const int* chunk_tensor_dev, const long long* chunk_off_dev,
                   int nchunks, double* partial_dev, float* total_norm_dev, float max_norm, float lr,
                   float beta1, float beta2, float eps, float ema_decay, int write_grad,
-                  cips_stream_t stream);
+                  long long* steps_dev, cips_stream_t stream);
 
 #ifdef __cplusplus
 }

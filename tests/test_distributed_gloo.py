@@ -45,7 +45,26 @@ def _worker(rank, world, port, q):
                 params[2].grad = torch.full((3,), 6.0)
         red()
         steady.append([None if p.grad is None else p.grad.clone().numpy() for p in params])
-    q.put((rank, out, nbytes, steady))
+    # (a) a caller that does not reset gradients to None (zero_grad(set_to_none=False)): after step 2 every rank holds a
+    #     grad for the agreed union; the next call must reuse the plan (no re-plan collective on some ranks only)
+    for p in params:
+        if p.grad is not None:
+            p.grad.fill_(float(rank))
+    red()
+    leftover = [None if p.grad is None else float(p.grad.reshape(-1)[0]) for p in params]
+    # (b) a reducer built while the parameters are frozen (train.py:335-336 toggles requires_grad every step) still
+    #     reduces what has a gradient at call time
+    for p in params:
+        p.requires_grad_(False)
+    red2 = GradAllReducer(params, bucket_mb=0.5)
+    for p in params:
+        p.requires_grad_(True)
+        p.grad = torch.full_like(p, float(rank + 3))
+    red2()
+    red2._check_pending(block=True)
+    red._check_pending(block=True)
+    frozen_built = [float(p.grad.reshape(-1)[0]) for p in params]
+    q.put((rank, out, nbytes, steady, leftover, frozen_built))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,8 +79,8 @@ def _run_world(world):
     res = {}
     try:
         for _ in range(world):
-            r, out, nbytes, steady = q.get(timeout=180)
-            res[r] = (out, nbytes, steady)
+            r, out, nbytes, steady, leftover, frozen_built = q.get(timeout=180)
+            res[r] = (out, nbytes, steady, leftover, frozen_built)
         for p in procs:
             p.join(timeout=60)
             if p.exitcode != 0:
@@ -89,7 +108,8 @@ def test_allreduce_grads_world2_gloo():
     g1 = [torch.randn(300000, generator=g) for g in gens]
     g2 = torch.randn(3, generator=gens[0])
     for r in range(world):
-        out, nbytes, steady = res[r]
+        out, nbytes, steady, leftover, frozen_built = res[r]
+        assert leftover == [0.5, 0.5, 0.5, 0.5] and frozen_built == [3.5, 3.5, 3.5, 3.5]
         out = [None if o is None else torch.from_numpy(o) for o in out]
         steady = [[None if o is None else torch.from_numpy(o) for o in st] for st in steady]
         assert torch.allclose(out[0], (g0[0] + g0[1]) / 2, atol=1e-6)

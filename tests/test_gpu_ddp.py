@@ -1,0 +1,148 @@
+"""GPU: the drop-in generator and discriminator under torch.nn.parallel.DistributedDataParallel exactly as the
+reference's training script wraps them (exp/cips3d/scripts/train.py:41-49 setup_ddp, :235-236
+DDP(..., find_unused_parameters=True, broadcast_buffers=False)), through one D step (two D forwards, R1
+double-backward, train.py:383-440) and one G step through the frozen D (:441-466).  Two ranks share cuda:0 and
+exchange gradients over gloo (the driver's boxes have one GPU; RCCL needs one device per rank).  After each backward
+the gradients on every rank must equal the mean of the two ranks' single-process gradients — for every parameter DDP
+leaves a gradient on, including those used on no rank (None)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+IMG, B, S = 16, 2, 4
+G_KW = dict(fov=12, ray_start=0.88, ray_end=1.12, num_steps=S, h_stddev=0.3, v_stddev=0.155, hierarchical_sample=True,
+            psi=1., sample_dist="gaussian")
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _requires_grad(m, flag):
+    for p in m.parameters():
+        p.requires_grad_(flag)
+
+
+def _build(dev):
+    from conftest import G_CFG, D_CFG
+    from cips3d_amd import GeneratorNerfINR, Discriminator_MultiScale_Aux
+    torch.manual_seed(1234)                             # same initial weights on every rank (build_model + seed)
+    G = GeneratorNerfINR(**G_CFG, device=dev).to(dev); G.device = dev
+    D = Discriminator_MultiScale_Aux(**D_CFG).to(dev)
+    return G, D
+
+
+def _steps(G_call, D_call, G, D, data_rank, dev):
+    """the D step and the G step of train.py for the data of `data_rank` -> (D grads, G grads) as lists of CPU tensors"""
+    torch.manual_seed(777 + data_rank)                  # latents, cameras, jitter and the "real" images of this rank
+    real = torch.rand(B, 3, IMG, IMG, device=dev) * 2 - 1
+    # ---- TRAIN DISCRIMINATOR (train.py:334-440) ----
+    _requires_grad(G, False); _requires_grad(D, True)
+    with torch.no_grad():
+        gen, _ = G_call(G.get_zs(B), img_size=IMG, nerf_noise=0.1, return_aux_img=True, forward_points=None,
+                        grad_points=None, **G_KW)
+    real2 = torch.cat([real, real], dim=0).requires_grad_()
+    r_preds, _, _ = D_call(real2, alpha=0.8, use_aux_disc=True)
+    grad_real, = torch.autograd.grad(outputs=r_preds.sum(), inputs=real2, create_graph=True)
+    pen = 0.5 * 10.0 * grad_real.flatten(start_dim=1).square().sum(dim=1, keepdim=True) + 0. * r_preds
+    g_preds, _, _ = D_call(gen, alpha=0.8, use_aux_disc=True)
+    d_loss = (F.softplus(g_preds) + F.softplus(-r_preds) + pen).mean()
+    for p in D.parameters():
+        p.grad = None
+    d_loss.backward()
+    d_grads = [None if p.grad is None else p.grad.detach().cpu().clone() for p in D.parameters()]
+    # ---- TRAIN GENERATOR (train.py:441-466) ----
+    _requires_grad(G, True); _requires_grad(D, False)
+    imgs, _ = G_call(G.get_zs(B), img_size=IMG, nerf_noise=0.1, return_aux_img=True, grad_points=None,
+                     forward_points=None, **G_KW)
+    preds, _, _ = D_call(imgs.to(torch.float32), alpha=0.8, use_aux_disc=True)
+    g_loss = F.softplus(-preds).mean()
+    for p in G.parameters():
+        p.grad = None
+    g_loss.backward()
+    g_grads = [None if p.grad is None else p.grad.detach().cpu().clone() for p in G.parameters()]
+    torch.cuda.synchronize()
+    return d_grads, g_grads
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # setup_ddp (train.py:41-49) with gloo
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    G, D = _build(dev)
+    G_ddp = DDP(G, device_ids=[0], find_unused_parameters=True, broadcast_buffers=False)
+    D_ddp = DDP(D, device_ids=[0], find_unused_parameters=True, broadcast_buffers=False)
+    G_ddp.module.set_device(dev)
+    d_grads, g_grads = _steps(G_ddp, D_ddp, G, D, rank, dev)
+    q.put((rank, [None if t is None else t.numpy() for t in d_grads], [None if t is None else t.numpy() for t in g_grads]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_wrapped_generator_and_discriminator_train_steps():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, _free_port_shared(), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r, dg, gg = q.get(timeout=600)
+            res[r] = (dg, gg)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    # single-process gradients for each rank's data, then their mean
+    dev = torch.device("cuda", 0)
+    G, D = _build(dev)
+    singles = [_steps(G, D, G, D, r, dev) for r in range(world)]
+
+    def mean(ts):
+        if all(t is None for t in ts):
+            return None
+        return sum(torch.zeros_like(next(x for x in ts if x is not None)) if t is None else t for t in ts) / len(ts)
+
+    for which, params in ((0, list(D.named_parameters())), (1, list(G.named_parameters()))):
+        worst, used = 0.0, 0
+        for i, (name, _) in enumerate(params):
+            want = mean([singles[r][which][i] for r in range(world)])
+            for r in range(world):
+                got = res[r][which][i]
+                if want is None:
+                    assert got is None or float(abs(got).max()) == 0.0, (name, "unused parameter got a gradient")
+                    continue
+                assert got is not None, name
+                got = torch.from_numpy(got)
+                e = float((got.double() - want.double()).norm() / want.double().norm().clamp_min(1e-30))
+                worst = max(worst, e)
+                assert e < 1e-5, (name, r, e)
+            used += want is not None
+        print(f"{'D' if which == 0 else 'G'} under DDP: {used} of {len(params)} parameters carry a gradient; worst "
+              f"difference from the mean of the single-process gradients {worst:.2e}")
+
+
+_PORT = []
+
+
+def _free_port_shared():
+    if not _PORT:
+        _PORT.append(_free_port())
+    return _PORT[0]

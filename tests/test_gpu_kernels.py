@@ -672,3 +672,26 @@ def test_torgb_x3_forward_and_weight_gradient(M, K):
     assert rel_err(db, drgb.double().sum(0)) < 2e-6
     dw2, db2 = ops.torgb_bwd_w_x3(xP, drgb.to(d))
     assert torch.equal(dw, dw2) and torch.equal(db, db2)          # fixed combine order
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float64, torch.float32])
+def test_native_ops_keep_the_input_dtype(dtype):
+    """The reference's two native ops dispatch fp16 / fp32 / fp64 (fused_bias_act_kernel.cu:79,
+    upfirdn2d_kernel.cu:177-211) and return the input's dtype; here other float dtypes make an fp32 round trip and
+    come back in their own dtype (through the shipped pybind stand-ins, cips3d_amd.compat); integers raise."""
+    from cips3d_amd import compat
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 6, 6, generator=g); b = torch.randn(5, generator=g)
+    y = compat.fused.fused_bias_act(x.to(d, dtype), b.to(d, dtype), torch.empty(0, device=d, dtype=dtype), 3, 0, 0.2, 2 ** 0.5)
+    assert y.dtype == dtype and y.shape == x.shape
+    yr = orc.fused_bias_act(x.to(dtype).float(), b.to(dtype).float(), torch.empty(0), 3, 0, 0.2, 2 ** 0.5)
+    tol = {torch.float16: 2e-3, torch.bfloat16: 2e-2, torch.float64: 1e-6, torch.float32: 1e-6}[dtype]
+    assert max_rel(y.float(), yr) < tol
+    k = torch.tensor([1., 3., 3., 1.]); k = k[None] * k[:, None]; k = k / k.sum()
+    xi = torch.randn(3, 9, 9, 1, generator=g)
+    o = compat.upfirdn2d_op.upfirdn2d(xi.to(d, dtype), k.to(d, dtype), 1, 1, 2, 2, 1, 1, 1, 1)
+    orf = orc.upfirdn2d(xi.to(dtype).float().view(1, 3, 9, 9), k.to(dtype).float(), up=1, down=2, pad=(1, 1))
+    assert o.dtype == dtype and max_rel(o.float().view(3, o.shape[1], o.shape[2]), orf[0]) < tol
+    with pytest.raises(RuntimeError):
+        compat.fused.fused_bias_act(torch.zeros(2, 2, device=d, dtype=torch.int32), torch.empty(0, device=d), torch.empty(0, device=d), 3, 0, 0.2, 1.0)

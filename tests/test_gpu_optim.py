@@ -75,3 +75,77 @@ def test_fused_optimizer_on_generator_parameters():
     assert changed > 100
     assert all(torch.isfinite(p).all() for p in G.parameters())
     assert any(not torch.equal(a, b) for a, b in zip(G_ema.parameters(), before))
+
+
+def test_fused_step_queued_without_host_sync():
+    """Six steps enqueued back to back with NO synchronisation between them and freshly allocated gradient tensors
+    every step (what zero_grad(set_to_none=True) + backward does): the parameter table is re-uploaded every step
+    while earlier steps are still queued.  A long kernel in front keeps the stream behind the host, so a staging
+    buffer that were reused before its copy ran would hand an earlier step the next step's gradient pointers."""
+    from cips3d_amd.optim import FusedClipAdamEMA
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 33), (200000,), (5,), (512, 512)]
+    p_ref = [torch.nn.Parameter(torch.randn(*s, generator=g).to(d)) for s in shapes]
+    p_fus = [torch.nn.Parameter(p.detach().clone()) for p in p_ref]
+    opt = torch.optim.Adam([{"params": p_ref}], lr=1e-3, betas=(0.5, 0.99), weight_decay=0)
+    fus = FusedClipAdamEMA(p_fus, lr=1e-3, betas=(0.5, 0.99), max_norm=None)
+    all_grads = [[torch.randn(*s, generator=g).to(d) * (1 + it) for s in shapes] for it in range(6)]
+    for it in range(6):
+        for a, gr in zip(p_ref, all_grads[it]):
+            a.grad = gr.clone()
+        opt.step()
+    torch.cuda.synchronize()
+    big = torch.randn(8192, 8192, device=d)
+    keep = []
+    for _ in range(6):
+        big = big @ big * 1e-4                     # ~1 ms each: the stream falls behind the host
+    for it in range(6):
+        for b, gr in zip(p_fus, all_grads[it]):
+            b.grad = gr.clone() + 0                # a fresh allocation per step
+            keep.append(b.grad)
+        fus.step()
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(p_ref, p_fus)):
+        assert torch.allclose(a, b, rtol=5e-6, atol=1e-7), (k, float((a - b).abs().max()))
+    assert fus.steps == [6, 6, 6, 6]
+
+
+def test_fused_step_replayed_as_hipgraph_advances_bias_correction():
+    """The step captured once in a hipGraph and replayed: the Adam step counts live on the device and advance on every
+    replay (with host-side counts the bias corrections would stay at the captured step)."""
+    from cips3d_amd.optim import FusedClipAdamEMA
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(10)
+    shapes = [(300, 7), (70000,)]
+    p_ref = [torch.nn.Parameter(torch.randn(*s, generator=g).to(d)) for s in shapes]
+    p_fus = [torch.nn.Parameter(p.detach().clone()) for p in p_ref]
+    for p in p_fus:
+        p.grad = torch.zeros_like(p)              # static gradient buffers, as a captured training step has them
+    opt = torch.optim.Adam([{"params": p_ref}], lr=1e-2, betas=(0.9, 0.999), weight_decay=0)
+    fus = FusedClipAdamEMA(p_fus, lr=1e-2, betas=(0.9, 0.999), max_norm=None)
+    grads = [[torch.randn(*s, generator=g).to(d) for s in shapes] for _ in range(4)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fus.step()                                # warm-up outside the graph (step 1 with zero gradients)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for p in p_ref:
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fus.step()
+    for p in p_ref:                               # the capture itself does not execute
+        pass
+    for it in range(4):
+        for a, b, gr in zip(p_ref, p_fus, grads[it]):
+            a.grad = gr.clone()
+            b.grad.copy_(gr)
+        opt.step()
+        graph.replay()
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(p_ref, p_fus)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (k, float((a - b).abs().max()))
+    assert fus.steps == [5, 5]

@@ -1,0 +1,202 @@
+"""GPU: parity at BASELINE.json's REAL configurations, not toy sizes — the HIP path
+against the CPU oracle run on the GPU box's host cores with identical weights, latents and random draws:
+
+  C2  r64, 24 SIREN evaluations per ray, batch 32: S=24 flat and S=12+12 hierarchical, every image of the batch
+      (oracle under no_grad, image by image);
+  C1  r32, S=12 hierarchical, batch 4, aux image: forward AND every parameter gradient;
+  C3  r128 geometry, S=12+12, an image pair: forward;
+  C4  r256, S=24+24 (E=48), GeneratorNerfINR_freeze_NeRF, an image pair: forward and the INR-side gradients (the
+      per-GPU batch of the 8-GPU stages: the weight-gradient GEMMs split the pixel range, ops.py InrHeadX3Function);
+  D   Discriminator_MultiScale_Aux at 64^2 and 256^2, main + aux branch, fade-in alpha < 1: logits, R1 input gradient
+      (double-backward graph) and every parameter gradient of the full d_loss — the 256-/128-channel layers
+      (convs.64/128/256, the aux branch's 256-wide stack) and every conv dispatch branch (implicit GEMM, folded small
+      planes, streaming RGB convs) with the real channel tables (discriminator.py:441-451, 621-631).
+
+Gradients are compared for the same LeakyReLU gates (recorded from the oracle's run and pinned into the HIP path, see
+test_gpu_generator.py); bars: images / logits 1e-3 (north_star), gradients 5e-4."""
+import pytest
+import torch
+
+from conftest import seeded_generator, max_rel, pack_bitplane, D_CFG
+from oracle import cips3d_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+GRAD_TOL = 5e-4
+KW = dict(fov=12, ray_start=0.88, ray_end=1.12, h_stddev=0.3, v_stddev=0.155)
+
+
+def _draws(g, b, img, S, hier):
+    n = img * img
+    E = 2 * S if hier else S
+    zs = {"z_nerf": torch.randn(b, 256, generator=g), "z_inr": torch.randn(b, 512, generator=g)}
+    rand = dict(jitter=torch.rand(b, n, S, 1, generator=g), theta=torch.randn(b, 1, generator=g),
+                phi=torch.randn(b, 1, generator=g), noise_c=torch.randn(b, n, S, 1, generator=g),
+                u=torch.rand(b * n, S, generator=g), noise_f=torch.randn(b, n, E, 1, generator=g))
+    return zs, rand
+
+
+def _slice(zs, rand, i, b, n, S):
+    z1 = {k: v[i:i + 1] for k, v in zs.items()}
+    r1 = {k: (v[i:i + 1] if k != "u" else v.view(b, n, S)[i].reshape(n, S)) for k, v in rand.items()}
+    return z1, r1
+
+
+def _product_forward(G, zs, rand, d, img, S, hier, aux=False, pin=None, nerf_noise=0.0):
+    from cips3d_amd import ops
+    with ops.gate_debug(pin=pin):
+        imgs, _ = G({k: v.to(d) for k, v in zs.items()}, img_size=img, num_steps=S, hierarchical_sample=hier,
+                    sample_dist="gaussian", nerf_noise=nerf_noise, return_aux_img=aux, grad_points=None,
+                    forward_points=None, rand_override={k: v.to(d) for k, v in rand.items()}, **KW)
+    return imgs
+
+
+@pytest.mark.parametrize("S,hier", [(24, False), (12, True)])
+def test_c2_full_batch_forward_vs_oracle(S, hier):
+    """BASELINE configs[1]: r64, 24 evaluations per ray, batch 32 — all 32 images against the oracle."""
+    d = torch.device("cuda:0")
+    b, img = 32, 64
+    n = img * img
+    g = torch.Generator().manual_seed(2024 + S)
+    zs, rand = _draws(g, b, img, S, hier)
+    Gc = seeded_generator(1234)
+    sd = dict(Gc.named_parameters())
+    Gd = seeded_generator(1234, device=d)
+    with torch.no_grad():
+        imgs = _product_forward(Gd, zs, rand, d, img, S, hier, nerf_noise=0.3).cpu()
+        worst = 0.0
+        for i in range(b):
+            z1, r1 = _slice(zs, rand, i, b, n, S)
+            ref = orc.generator_forward(sd, z1, r1, img, KW["fov"], KW["ray_start"], KW["ray_end"], S, KW["h_stddev"],
+                                        KW["v_stddev"], hier, nerf_noise=0.3)["imgs"]
+            e = max_rel(imgs[i:i + 1], ref)
+            worst = max(worst, e)
+            assert e < TOL, (i, e)
+    print(f"C2 b=32 r64 S={S} hier={hier} (nerf_noise 0.3): worst image max_rel vs oracle {worst:.3e}")
+
+
+def _grad_compare(named_params, ref_grads, what):
+    worst = ("", 0.0)
+    n_used = 0
+    for name, p in named_params:
+        r = ref_grads.get(name)
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        n_used += 1
+        e = float((p.grad.detach().cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-300))
+        if e > worst[1]:
+            worst = (name, e)
+    print(f"{what}: {n_used} parameter gradients, worst rel err {worst[1]:.3e} at {worst[0]}")
+    assert worst[1] < GRAD_TOL, worst
+
+
+def test_c1_forward_backward_vs_oracle():
+    """BASELINE configs[0]: r32, 12 samples per ray (hierarchical, E=24), batch 4, aux image on (ffhq_exp.yaml:169)."""
+    d = torch.device("cuda:0")
+    b, img, S = 4, 32, 12
+    g = torch.Generator().manual_seed(31)
+    zs, rand = _draws(g, b, img, S, True)
+    G0 = torch.randn(2 * b, 3, img, img, generator=g) / (2 * b * 3 * img * img)
+    Gc = seeded_generator(1234)
+    tape = orc.GateTape()
+    with orc.gate_tape(tape):
+        ref = orc.generator_forward(dict(Gc.named_parameters()), zs, rand, img, KW["fov"], KW["ray_start"], KW["ray_end"],
+                                    S, KW["h_stddev"], KW["v_stddev"], True, nerf_noise=0.2, return_aux_img=True)
+    (ref["imgs"] * G0).sum().backward()
+    ref_grads = {k: p.grad for k, p in Gc.named_parameters() if p.grad is not None}
+    Gd = seeded_generator(1234, device=d)
+    imgs = _product_forward(Gd, zs, rand, d, img, S, True, aux=True, pin=[pack_bitplane(t) for t in tape.rec], nerf_noise=0.2)
+    e = max_rel(imgs, ref["imgs"])
+    print(f"C1 b=4 r32 S=12+12 aux: imgs max_rel {e:.3e}")
+    assert imgs.shape == (2 * b, 3, img, img) and e < TOL
+    (imgs * G0.to(d)).sum().backward()
+    torch.cuda.synchronize()
+    _grad_compare(list(Gd.named_parameters()), ref_grads, "C1 gradients (oracle's gates pinned)")
+
+
+def test_c3_r128_pair_forward_vs_oracle():
+    """C3 geometry: r128, 24 evaluations per ray (S=12+12), an image pair."""
+    d = torch.device("cuda:0")
+    b, img, S = 2, 128, 12
+    g = torch.Generator().manual_seed(128)
+    zs, rand = _draws(g, b, img, S, True)
+    Gc = seeded_generator(1234)
+    Gd = seeded_generator(1234, device=d)
+    with torch.no_grad():
+        ref = orc.generator_forward(dict(Gc.named_parameters()), zs, rand, img, KW["fov"], KW["ray_start"], KW["ray_end"], S,
+                                    KW["h_stddev"], KW["v_stddev"], True)["imgs"]
+        imgs = _product_forward(Gd, zs, rand, d, img, S, True)
+    e = max_rel(imgs, ref)
+    print(f"C3 geometry b=2 r128 S=12+12: imgs max_rel {e:.3e}")
+    assert e < TOL
+
+
+def test_c4_r256_e48_frozen_nerf_forward_backward_vs_oracle():
+    """C4: r256, num_steps 24 + hierarchical (E=48), GeneratorNerfINR_freeze_NeRF (ffhq_exp.yaml:192-210), an image
+    pair: forward and the gradients of everything that trains in that stage (INR head, mapping_inr)."""
+    import psutil
+    d = torch.device("cuda:0")
+    # the oracle's autograd state is ~6 GB of host memory per 256^2 image
+    b, img, S = (2 if psutil.virtual_memory().available > 64 * 2 ** 30 else 1), 256, 24
+    g = torch.Generator().manual_seed(256)
+    zs, rand = _draws(g, b, img, S, True)
+    G0 = torch.randn(b, 3, img, img, generator=g) / (b * 3 * img * img)
+    Gc = seeded_generator(1234, freeze=True)
+    tape = orc.GateTape()
+    with orc.gate_tape(tape):
+        ref = orc.generator_forward(dict(Gc.named_parameters()), zs, rand, img, KW["fov"], KW["ray_start"], KW["ray_end"], S,
+                                    KW["h_stddev"], KW["v_stddev"], True, freeze_nerf=True)
+    (ref["imgs"] * G0).sum().backward()
+    ref_grads = {k: p.grad for k, p in Gc.named_parameters() if p.grad is not None}
+    assert not any(k.startswith(("siren", "mapping_network_nerf", "aux_to_rbg")) for k in ref_grads)
+    ref_imgs = ref["imgs"].detach()
+    pins = [pack_bitplane(t) for t in tape.rec]
+    del ref, tape
+    Gd = seeded_generator(1234, freeze=True, device=d)
+    imgs = _product_forward(Gd, zs, rand, d, img, S, True, pin=pins)
+    e = max_rel(imgs, ref_imgs)
+    print(f"C4 b=2 r256 S=24+24 frozen NeRF: imgs max_rel {e:.3e}")
+    assert e < TOL
+    (imgs * G0.to(d)).sum().backward()
+    torch.cuda.synchronize()
+    _grad_compare(list(Gd.named_parameters()), ref_grads, "C4 gradients (oracle's gates pinned)")
+
+
+@pytest.mark.parametrize("size,b,alpha", [(64, 2, 0.6), (256, 1, 0.75)])
+def test_discriminator_real_sizes_vs_oracle(size, b, alpha):
+    """Discriminator_MultiScale_Aux with the shipped channel tables at 64^2 and 256^2, main + aux branch, fade-in:
+    logits, R1 input gradient and all parameter gradients of the d_loss of train.py:385-409 against the oracle."""
+    from cips3d_amd import discriminator as dmod
+    from cips3d_amd.discriminator import Discriminator_MultiScale_Aux
+    d = torch.device("cuda:0")
+    torch.manual_seed(4321)
+    D = Discriminator_MultiScale_Aux(**D_CFG)
+    g = torch.Generator().manual_seed(size)
+    x0 = torch.rand(2 * b, 3, size, size, generator=g) * 2 - 1
+    sd = dict(D.state_dict())
+    sd.update(dict(D.named_parameters()))
+    x = x0.clone().requires_grad_(True)
+    tape = orc.GateTape()
+    with orc.gate_tape(tape):
+        out = orc.discriminator_forward(sd, x, alpha=alpha, use_aux_disc=True)
+    gr, = torch.autograd.grad(out.sum(), x, create_graph=True)
+    loss = torch.nn.functional.softplus(-out).mean() + 0.5 * 10. * gr.flatten(1).pow(2).sum(1).mean()
+    loss.backward()
+    ref_grads = {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None}
+    ref_out, ref_gr, ref_loss = out.detach(), gr.detach(), float(loss)
+    D.zero_grad(set_to_none=True)
+    Dd = D.to(d)
+    xd = x0.to(d).requires_grad_(True)
+    with dmod.gate_debug(pin=tape.rec):
+        o = Dd(xd, alpha=alpha, use_aux_disc=True)[0]
+    gd, = torch.autograd.grad(o.sum(), xd, create_graph=True)
+    ld = torch.nn.functional.softplus(-o).mean() + 0.5 * 10. * gd.flatten(1).pow(2).sum(1).mean()
+    ld.backward()
+    torch.cuda.synchronize()
+    e, eg = max_rel(o, ref_out), max_rel(gd, ref_gr)
+    print(f"D {size}x{size} b={b} main+aux alpha={alpha}: logits max_rel {e:.3e}, R1 input-gradient max_rel {eg:.3e}, "
+          f"loss {float(ld):.6f} vs {ref_loss:.6f}")
+    assert e < TOL and eg < GRAD_TOL and abs(float(ld) - ref_loss) < TOL * max(1.0, abs(ref_loss))
+    _grad_compare(list(Dd.named_parameters()), ref_grads, f"D {size}x{size} gradients (oracle's gates pinned)")
