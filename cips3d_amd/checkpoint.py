@@ -1,0 +1,74 @@
+"""On-disk checkpoint layout of the reference's training script.
+
+exp/cips3d/scripts/train.py:249-256 collects
+
+    model_dict = {'generator': G, 'G_ema': G_ema, 'discriminator': D, 'state_dict': {cur_fid, best_fid, worst_fid, step}}
+
+and hands it to tl2's `torch_utils.save_models(save_dir, model_dict)` (train.py:72) / `load_models(save_dir, model_dict,
+strict=False, rank=rank)` (:262, :272); gen_images.py:102 and eval_fid.py load one network from its file with
+`Checkpointer(G_ema).load_state_dict_from_file(network_pkl)`.  tl2 is an unpinned PyPI package that is not vendored in
+the reference; the layout it produces — one `torch.save`d `state_dict()` per entry, `<save_dir>/<name>.pth`, plain dicts
+saved as they are — is what the released checkpoints (`G_ema.pth`, README.md:96-100) look like and what these functions
+read and write, so a checkpoint directory written by the reference loads into the MI355X classes and vice versa (the
+172 / 160 state_dict keys and shapes are identical, tests/test_compat_cpu.py)."""
+import os
+
+import torch
+
+
+def _unwrap(obj):
+    return obj.module if isinstance(obj, torch.nn.parallel.DistributedDataParallel) else obj
+
+
+def save_models(save_dir, model_dict, info_msg=None):
+    """<save_dir>/<name>.pth for every entry: modules / optimisers / EMA helpers -> their state_dict(), plain dicts
+    (the 'state_dict' entry: step, FID bookkeeping) as they are.  Tensors are moved to the CPU first."""
+    os.makedirs(save_dir, exist_ok=True)
+    for name, obj in model_dict.items():
+        obj = _unwrap(obj)
+        sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
+        if isinstance(sd, dict):
+            sd = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in sd.items()}
+        torch.save(sd, os.path.join(save_dir, f"{name}.pth"))
+    if info_msg is not None:
+        with open(os.path.join(save_dir, "0info.txt"), "w") as f:
+            f.write(f"{info_msg}\n")
+
+
+def load_models(save_dir, model_dict, strict=True, rank=0, verbose=False):
+    """Inverse of save_models: load <save_dir>/<name>.pth into every entry in place.  Missing files are skipped when
+    strict is False (train.py loads with strict=False so that e.g. a generator-only directory fine-tunes)."""
+    for name, obj in model_dict.items():
+        path = os.path.join(save_dir, f"{name}.pth")
+        if not os.path.exists(path):
+            if strict:
+                raise FileNotFoundError(path)
+            continue
+        obj = _unwrap(obj)
+        loaded = torch.load(path, map_location="cpu", weights_only=False)
+        if isinstance(obj, torch.nn.Module):
+            res = obj.load_state_dict(loaded, strict=strict)
+            if verbose and rank == 0:
+                print(f"{name}: {res}")
+        elif hasattr(obj, "load_state_dict"):
+            obj.load_state_dict(loaded)
+        elif isinstance(obj, dict):
+            obj.clear()
+            obj.update(loaded)
+        else:
+            raise TypeError(f"cannot load into {type(obj)}")
+
+
+class Checkpointer:
+    """`Checkpointer(G_ema).load_state_dict_from_file(network_pkl, rank=rank)` (gen_images.py:102)."""
+
+    def __init__(self, model):
+        self.model = _unwrap(model)
+
+    def load_state_dict_from_file(self, path, rank=0, strict=True):
+        sd = torch.load(path, map_location="cpu", weights_only=False)
+        return self.model.load_state_dict(sd, strict=strict)
+
+    def save_state_dict_to_file(self, path):
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, path)

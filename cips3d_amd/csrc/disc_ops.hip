@@ -276,6 +276,38 @@ inline unsigned grid_for(long long total) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------
+// FID path (exp/cips3d/scripts/gen_images.py:56-60): torchvision.utils.save_image(img, normalize=True,
+// value_range=(lo, hi)) turns the generator's float image into the uint8 pixels that are JPEG-encoded and fed to the
+// Inception network: clamp to [lo, hi], (x - lo) * (1 / max(hi - lo, 1e-5)) (ATen's CUDA div-by-scalar is a multiply by
+// the reciprocal), then mul(255).add_(0.5).clamp_(0, 255).to(uint8) in HWC order (torchvision/utils.py: make_grid
+// norm_ip, save_image).  One thread per pixel; separate roundings for the multiply and the add (no fma contraction) so
+// that identical float inputs give identical bytes.
+__global__ __launch_bounds__(256) void image_to_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ out,
+                                                          long long npix, int HW, int C, float lo, float hi, float inv) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / HW, p = i - b * HW;
+    for (int c = 0; c < C; ++c) {
+      float v = x[(b * C + c) * HW + p];
+      v = fminf(fmaxf(v, lo), hi);
+      v = __fmul_rn(__fsub_rn(v, lo), inv);
+      v = __fadd_rn(__fmul_rn(v, 255.f), 0.5f);
+      v = fminf(fmaxf(v, 0.f), 255.f);
+      out[i * C + c] = (unsigned char)v;
+    }
+  }
+}
+
+extern "C" int cips_image_to_u8(const float* x, unsigned char* out, int B, int C, int H, int W, float lo, float hi,
+                                cips_stream_t stream) {
+  if (!x || !out || B <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+  const long long npix = (long long)B * H * W;
+  const float d = fmaxf(hi - lo, 1e-5f);
+  const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+  hipLaunchKernelGGL(image_to_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, npix, H * W, C, lo, hi, 1.f / d);
+  return CIPS_CHECK_LAUNCH();
+}
+
 extern "C" int cips_version(void) { return 2; }
 extern "C" const char* cips_arch(void) { return "gfx950"; }
 

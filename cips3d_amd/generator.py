@@ -439,7 +439,7 @@ class GeneratorNerfINR(nn.Module):
         pass
 
     def staged_forward(self, *args, **kwargs):
-        raise NotImplementedError
+        raise NotImplementedError        # as in the reference (generator.py:1819-1820: the same two lines)
 
     # ---- the hot path ----
     def _nerf_styles(self, style_dict):

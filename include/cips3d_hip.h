@@ -350,6 +350,13 @@ int cips_upfirdn2d(const float* input, const float* kernel, float* out,
                    int up_x, int up_y, int down_x, int down_y,
                    int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream);
 
+/* FID path: float image (B, C <= 4, H, W) -> uint8 pixels (B, H, W, C) exactly as torchvision.utils.save_image(img,
+ * normalize=True, value_range=(lo, hi)) quantises them before JPEG encoding (exp/cips3d/scripts/gen_images.py:56-60;
+ * torchvision/utils.py make_grid norm_ip + save_image): clamp to [lo, hi], (x - lo) * (1 / max(hi - lo, 1e-5)),
+ * * 255, + 0.5, clamp to [0, 255], truncate.  Bit-exact on identical float inputs. */
+int cips_image_to_u8(const float* x, unsigned char* out, int B, int C, int H, int W, float lo, float hi,
+                     cips_stream_t stream);
+
 /* 1x1 convolution with C <= 4 input channels (EqualConv2d of the RGB input layers, discriminator.py:457-459):
  * y (B, O, HW) = w (O, C) . x (B, C, HW); HW % 4 == 0.  Streaming kernel, no GEMM. */
 int cips_conv1x1_smallk(const float* x, const float* w, float* y, int B, int C, int O, int HW, cips_stream_t stream);

@@ -87,3 +87,63 @@ def test_registry_builds_the_drop_in_models_from_the_reference_yaml():
     assert list(D.state_dict().keys()) == list(Dr.state_dict().keys())
     assert all(a.shape == b.shape for a, b in zip(G.state_dict().values(), Gr.state_dict().values()))
     assert all(a.shape == b.shape for a, b in zip(D.state_dict().values(), Dr.state_dict().values()))
+
+
+@needs_ref
+def test_checkpoint_directory_round_trips_with_the_reference_classes(tmp_path):
+    """tl2-layout checkpoint directory ({generator, G_ema, discriminator, state_dict}.pth; train.py:249-256): a directory
+    written from the REFERENCE's modules loads into the drop-in classes (strict) and a directory written from the
+    drop-in classes loads into the reference's modules (strict), values bit for bit; `Checkpointer(...)
+    .load_state_dict_from_file(G_ema.pth)` (gen_images.py:102) reads the single-network file."""
+    import copy
+    import yaml
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    from oracle import ref_shim
+    ref_shim.install()
+    from tl2.proj.fvcore import build_model
+    from exp.cips3d.models import generator as ref_gen, discriminator as ref_disc    # noqa: F401
+    from cips3d_amd import GeneratorNerfINR, Discriminator_MultiScale_Aux
+    from cips3d_amd.checkpoint import save_models, load_models, Checkpointer
+    from conftest import G_CFG, D_CFG
+    cfg = yaml.safe_load(open(os.path.join(REF, "exp/cips3d/configs/ffhq_exp.yaml")))
+    torch.manual_seed(5)
+    Gr = build_model(cfg["G_cfg_3D2D"], device="cpu")
+    Dr = build_model(cfg["D_cfg"], kwargs_priority=True, diffaug=False)
+    Gr_ema = copy.deepcopy(Gr)
+    with torch.no_grad():
+        for p in Gr_ema.parameters():
+            p.mul_(0.5)
+    state = {"cur_fid": 12.5, "best_fid": 11.0, "worst_fid": 300.0, "step": 4321}
+    d1 = str(tmp_path / "from_reference")
+    save_models(d1, {"generator": Gr, "G_ema": Gr_ema, "discriminator": Dr, "state_dict": state}, info_msg="step: 4321")
+    assert sorted(os.listdir(d1)) == ["0info.txt", "G_ema.pth", "discriminator.pth", "generator.pth", "state_dict.pth"]
+    torch.manual_seed(99)                                   # different initial weights: everything must come from disk
+    G = GeneratorNerfINR(**G_CFG, device="cpu"); G_ema = copy.deepcopy(G); D = Discriminator_MultiScale_Aux(**D_CFG)
+    st = {}
+    load_models(d1, {"generator": G, "G_ema": G_ema, "discriminator": D, "state_dict": st}, strict=True)
+    assert st == state
+    for a, b in ((G, Gr), (G_ema, Gr_ema), (D, Dr)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa) == list(sb) and all(torch.equal(sa[k], sb[k]) for k in sa)
+    # the other direction, and the single-file loader of gen_images.py:102
+    d2 = str(tmp_path / "from_mi355x")
+    with torch.no_grad():
+        for p in G_ema.parameters():
+            p.add_(1.0)
+    save_models(d2, {"generator": G, "G_ema": G_ema, "discriminator": D, "state_dict": st})
+    torch.manual_seed(7)
+    Gr2 = build_model(cfg["G_cfg_3D2D"], device="cpu")
+    Checkpointer(Gr2).load_state_dict_from_file(os.path.join(d2, "G_ema.pth"))
+    assert all(torch.equal(v, G_ema.state_dict()[k]) for k, v in Gr2.state_dict().items())
+    # freeze variant: load_nerf_ema (generator.py:1957-1961) copies the NeRF side of G_ema
+    from cips3d_amd import GeneratorNerfINR_freeze_NeRF
+    Gf = GeneratorNerfINR_freeze_NeRF(**G_CFG, device="cpu")
+    load_models(d2, {"generator": Gf}, strict=True)
+    Gf.load_nerf_ema(G_ema)
+    assert torch.equal(Gf.siren.network[0].linear.weight, G_ema.siren.network[0].linear.weight)
+    # a missing file: skipped with strict=False (train.py:262 loads with strict=False), an error with strict=True
+    os.remove(os.path.join(d2, "discriminator.pth"))
+    load_models(d2, {"discriminator": D}, strict=False)
+    with pytest.raises(FileNotFoundError):
+        load_models(d2, {"discriminator": D}, strict=True)
