@@ -22,6 +22,16 @@ class SirenWeights(C.Structure):
                  "g0", "p0", "g1", "p1", "gc", "pc")] + [("box_scale", f32), ("trig_mode", i32)]
 
 
+class RayParams(C.Structure):
+    _fields_ = [("xg", vp), ("yg", vp), ("zg", vp), ("cam2world", vp), ("jitter", vp), ("zc", f32), ("H", i32), ("W", i32),
+                ("S", i32)]
+
+
+class GlinJob(C.Structure):
+    _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("y", vp), ("dy", vp), ("dw", vp), ("db", vp), ("in_dim", i32),
+                ("out_dim", i32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("A", vp), ("B", vp), ("C", vp),
@@ -86,6 +96,8 @@ SIGNATURES = {
     "cips_siren_bwd_x3_sred": (i32, []),
     "cips_siren_bwd_x3_prof": (i32, [vp]),
     "cips_siren_bwd_x3": (i32, [C.POINTER(SirenWeights), vp, vp, vp, vp, vp, i32, i32, vp]),
+    "cips_siren_bwd_x3_rays": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, vp, vp, vp, i32, vp]),
+    "cips_march_fwd_x3": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, f32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "cips_siren_bwd_data": (i32, [C.POINTER(SirenWeights)] + [vp] * 14 + [i32, i32, vp]),
     "cips_resample_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_composite_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
@@ -110,6 +122,10 @@ SIGNATURES = {
     "cips_modfc_prep_bwd_batch": (i32, [C.POINTER(ModfcBwdJob), i32, i32, vp]),
     "cips_opt_chunk": (i32, []),
     "cips_opt_step": (i32, [vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]),
+    "cips_grouped_linear_max_jobs": (i32, []),
+    "cips_grouped_linear_fwd": (i32, [C.POINTER(GlinJob), i32, i32, vp]),
+    "cips_grouped_linear_scratch": (i64, [C.POINTER(GlinJob), i32, i32]),
+    "cips_grouped_linear_bwd": (i32, [C.POINTER(GlinJob), i32, i32, vp, vp, i64, vp]),
     "cips_torgb_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
     "cips_torgb_bwd_partials": (i32, [i64]),
     "cips_torgb_bwd_w": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),

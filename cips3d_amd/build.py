@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libcips3d_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "gemm_bf16x3_wide.hip", "gemm_bf16x3_km_wide.hip", "siren.hip", "siren_bwd_x3.hip", "render.hip", "modfc.hip", "disc_ops.hip", "optim.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "gemm_bf16x3_wide.hip", "gemm_bf16x3_km_wide.hip", "siren.hip", "siren_bwd_x3.hip", "render.hip", "modfc.hip", "disc_ops.hip", "optim.hip", "small_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -25,7 +25,8 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
     objdir = os.path.join(HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "cips3d_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "siren_fwd_chain.inc"),
+               os.path.join(HERE, "..", "include", "cips3d_hip.h")]
     objs = []
     procs = []
     for src in SOURCES:

@@ -298,6 +298,50 @@ __device__ __forceinline__ f32x16 x2f(f32x16 acc, const Frag& a, const Frag& b) 
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// In-kernel ray set-up (what rays_kernel of render.hip materialises; exp/comm/comm_utils.py:365-438, 584-679): the
+// sample point of (image b, ray, sample s) from the three linspace grids, the camera matrix and the jitter draw — 4 B
+// per point read instead of 12 B, and no (B, n, S, 3) tensor in HBM.  Same expressions, in the same order, as
+// rays_kernel.
+struct RayGen {
+  const float *xg, *yg, *zg;   // torch.linspace grids (W), (H), (S)
+  const float* c2w;            // (B, 4, 4)
+  const float* jitter;         // (B, n, S) uniforms or NULL
+  float zc;
+  int W, n, S;
+};
+struct RayDir { float dx, dy, dz; };
+__device__ __forceinline__ RayDir ray_dir(const RayGen& g, int ray) {
+  const int row = ray / g.W, col = ray - row * g.W;
+  const float x = g.xg[col], y = g.yg[row];
+  const float nrm = sqrtf(x * x + y * y + g.zc * g.zc);
+  RayDir d = {x / nrm, y / nrm, g.zc / nrm};
+  return d;
+}
+// camera-space sample at depth grid value z0 with jitter draw u (raw uniform; ignored when has_jit is false) -> world
+// point and the jittered depth
+__device__ __forceinline__ void ray_point(const RayGen& g, const float* M, const RayDir& d, float z0, float u, bool has_jit,
+                                          float& wx, float& wy, float& wz, float& zout) {
+  float z = z0;
+  float px = d.dx * z, py = d.dy * z, pz = d.dz * z;
+  if (has_jit) {
+    const float off = (u - 0.5f) * (g.zg[1] - g.zg[0]);
+    z = z + off;
+    px = px + off * d.dx; py = py + off * d.dy; pz = pz + off * d.dz;
+  }
+  wx = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3];
+  wy = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7];
+  wz = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11];
+  zout = z;
+}
+// point-major index p = ray * S + s of image b -> world point
+__device__ __forceinline__ void gen_point(const RayGen& g, int b, int p, float& wx, float& wy, float& wz) {
+  const int ray = p / g.S, s = p - ray * g.S;
+  const RayDir d = ray_dir(g, ray);
+  const float u = g.jitter ? g.jitter[(long long)b * g.n * g.S + p] : 0.f;
+  float z;
+  ray_point(g, g.c2w + (long long)b * 16, d, g.zg[s], u, g.jitter != nullptr, wx, wy, wz, z);
+}
+
 struct BwdX3Args {
   cips_siren_weights w;
   const float* points;
@@ -308,6 +352,7 @@ struct BwdX3Args {
   int B, P, chunk, chunks;
   unsigned long long* prof;
   int dbg;        // timing attribution only (env CIPS_X3_DBG): bit0/1/2 skip the dWf / dWc / dW1 phases
+  RayGen rg;      // points == NULL: the points are generated from the ray parameters (point index = ray * S + s)
 };
 constexpr int GP_G1 = 0, GP_GC = H * H, GP_GF0 = GP_GC + HC * H, GP_GF1 = GP_GF0 + CF * HC, GPART = GP_GF1 + CF * HC;
 constexpr int SRED = 4 * 32 * 8 + 8;   // per wave a 32x8 tile of column sums, then 4 per-wave sums of dsigma (+ pad)
@@ -391,7 +436,8 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_x3_kernel(BwdX3Args a) {
     const int p = cstart + wave * 32 + (lane0 & 31);
     const bool valid = p < cend;
     const long long gp = (long long)b * a.P + (valid ? p : cend - 1);
-    px = a.points[gp * 3 + 0]; py = a.points[gp * 3 + 1]; pz = a.points[gp * 3 + 2];
+    if (a.points) { px = a.points[gp * 3 + 0]; py = a.points[gp * 3 + 1]; pz = a.points[gp * 3 + 2]; }
+    else gen_point(a.rg, b, valid ? p : cend - 1, px, py, pz);
     dsg = valid ? a.dsigma[gp] : 0.f;
   }
 
@@ -688,7 +734,8 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_x3_kernel(BwdX3Args a) {
       const int p = pbase + 128 + prow;
       const bool valid = p < cend;
       const long long gp = (long long)b * a.P + (valid ? p : cend - 1);
-      px = a.points[gp * 3 + 0]; py = a.points[gp * 3 + 1]; pz = a.points[gp * 3 + 2];
+      if (a.points) { px = a.points[gp * 3 + 0]; py = a.points[gp * 3 + 1]; pz = a.points[gp * 3 + 2]; }
+      else gen_point(a.rg, b, valid ? p : cend - 1, px, py, pz);
       dsg = valid ? a.dsigma[gp] : 0.f;
     }
 
@@ -813,85 +860,7 @@ __global__ __launch_bounds__(512) void siren_fwd_x3_kernel(FwdX3Args a) {
     const long long gp = (long long)b * a.P + (valid ? p : cend - 1);
     const float px = a.points[gp * 3 + 0], py = a.points[gp * 3 + 1], pz = a.points[gp * 3 + 2];
 
-    f32x16 acc[4];
-    zero_acc(acc);
-    {
-      Act<4> h1p;
-      float4 pn[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 16 * e);
-#pragma unroll
-      for (int grp = 0; grp < 16; ++grp) {
-        float4 pk[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = pn[e];
-        if (grp + 1 < 16) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 128 * (grp + 1) + 16 * e);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float sn[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sn[e] = film_sin<HW>(fmaf(pk[e].x, px, fmaf(pk[e].y, py, fmaf(pk[e].z, pz, pk[e].w))));
-        const int q = grp >> 2, g = grp & 3;
-        split2(sn[0], sn[1], h1p.hi[q][2 * g], h1p.lo[q][2 * g]);
-        split2(sn[2], sn[3], h1p.hi[q][2 * g + 1], h1p.lo[q][2 * g + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      layer_fwd<4, 4, H, O_W1H, O_W1L - O_W1H>(LA, h1p, acc);
-    }
-    Act<4> h2p;
-    float sig = 0.f;
-    {
-      float4 gn = lds_ld4(LA.v16 + (O_G1 - O_L0)), cn = lds_ld4(LA.v16 + (O_C1 - O_L0)), wn = lds_ld4(LA.v16 + (O_WS - O_L0));
-#pragma unroll
-      for (int grp = 0; grp < 16; ++grp) {
-        const float4 g4 = gn, c4 = cn, w4 = wn;
-        if (grp + 1 < 16) {
-          gn = lds_ld4(LA.v16 + (O_G1 - O_L0) + 32 * (grp + 1)); cn = lds_ld4(LA.v16 + (O_C1 - O_L0) + 32 * (grp + 1));
-          wn = lds_ld4(LA.v16 + (O_WS - O_L0) + 32 * (grp + 1));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const int q = grp >> 2, g = grp & 3;
-        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
-        float sn[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          sn[e] = film_sin<HW>(fmaf(gg[e], acc[q][4 * g + e], cc[e]));
-          sig = fmaf(ww[e], sn[e], sig);
-        }
-        split2(sn[0], sn[1], h2p.hi[q][2 * g], h2p.lo[q][2 * g]);
-        split2(sn[2], sn[3], h2p.hi[q][2 * g + 1], h2p.lo[q][2 * g + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    sig += __shfl_xor(sig, 32);
-    sig += bs;
-
-    f32x16 accc[2];
-    zero_acc(accc);
-    layer_fwd<2, 4, HC, O_WCH, O_WCL - O_WCH>(LA, h2p, accc);
-    Act<2> hcp;
-    {
-      float4 gn = lds_ld4(LA.v16 + (O_GC - O_L0)), cn = lds_ld4(LA.v16 + (O_CC - O_L0));
-#pragma unroll
-      for (int grp = 0; grp < 8; ++grp) {
-        const float4 g4 = gn, c4 = cn;
-        if (grp + 1 < 8) { gn = lds_ld4(LA.v16 + (O_GC - O_L0) + 32 * (grp + 1)); cn = lds_ld4(LA.v16 + (O_CC - O_L0) + 32 * (grp + 1)); }
-        __builtin_amdgcn_sched_barrier(0);
-        const int q = grp >> 2, g = grp & 3;
-        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
-        float sn[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sn[e] = film_sin<HW>(fmaf(gg[e], accc[q][4 * g + e], cc[e]));
-        split2(sn[0], sn[1], hcp.hi[q][2 * g], hcp.lo[q][2 * g]);
-        split2(sn[2], sn[3], hcp.hi[q][2 * g + 1], hcp.lo[q][2 * g + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    f32x16 accf[1];
-    zero_acc(accf);
-    layer_fwd<1, 2, CF, O_WFH, O_WFL - O_WFH>(LA, hcp, accf);
+#include "siren_fwd_chain.inc"
     if (valid) {
       float* fo = a.feat + gp * CF + 4 * hf;
       const float* bfv = reinterpret_cast<const float*>(smem + O_AUX);
@@ -907,6 +876,138 @@ __global__ __launch_bounds__(512) void siren_fwd_x3_kernel(FwdX3Args a) {
       if (hf == 0) a.sigma[gp] = sig;
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused ray-march, non-hierarchical sampling (the headline configuration: num_steps samples per ray, no resampling):
+// ray set-up + FiLM-SIREN + alpha-composite (exp/comm/comm_utils.py:365-438, 584-679; exp/cips3d/models/
+// generator.py:260-317; exp/pigan/pigan_utils.py:212-273) in ONE kernel that walks the samples along the ray.
+// A wave owns 32 rays (lane & 31 = ray; the two lane halves hold 16 of the 32 feature channels each) and steps
+// s = 0..S-1: generate the sample point, run the register-chain MLP of siren_point_x3 (weights resident in LDS), and
+// fold the sample front-to-back into the ray's running transmittance / feature / depth accumulators — z is ascending by
+// construction (|jitter offset| <= half a bin), so the merge of the hierarchical path is the identity here and the
+// composite needs no cross-lane traffic at all.  HBM per ray: 4 B per sample of jitter (+ 4 B of noise when
+// nerf_noise > 0) in, 128 B feature + 4 B depth out = 4 S + 132 B; the (B, n, S, 3) points and the
+// (B, P, 32) per-sample features never exist in HBM unless the caller asks for them (feat / sigma / z outputs: the
+// training forward keeps them for the backward).  Transmittance runs in double like ATen's CPU cumprod.
+struct MarchArgs {
+  cips_siren_weights w;
+  RayGen rg;
+  const float* noise;        // (B, n, S) standard normals or NULL
+  float noise_std;
+  int clamp_mode, flags;     // flags: bit0 last_back, bit1 white_back
+  float *fea, *depth;        // (B, n, 32), (B, n)
+  float *weights;            // (B, n, S) or NULL
+  float *feat, *sigma, *zout;   // per-sample outputs (B, P, 32), (B, P), (B, P) or NULL
+  int B, rays_per_wg;
+};
+
+template <bool HW>
+__global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) uchar smem[];
+  const int b = blockIdx.y;
+  stage_weights_x3(smem, a.w, b);
+  if (threadIdx.x < CF) reinterpret_cast<float*>(smem + O_AUX)[threadIdx.x] = a.w.bf[threadIdx.x];
+  __syncthreads();
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uchar*)smem);
+  const float bs = a.w.bs[0];
+  const RayGen& g = a.rg;
+  const int S = g.S, n = g.n;
+  const int cstart = blockIdx.x * a.rays_per_wg;
+  const int cend = min(cstart + a.rays_per_wg, n);
+  const float* M = g.c2w + (long long)b * 16;
+  const float* bfv = reinterpret_cast<const float*>(smem + O_AUX);
+  for (int rbase = cstart + wave * 32; rbase < cend; rbase += 8 * 32) {
+    const int l31s = lane0 & 31, hfs = lane0 >> 5;
+    const int ray_raw = rbase + l31s;
+    const bool valid = ray_raw < cend;
+    const int ray = valid ? ray_raw : cend - 1;
+    const long long rs = ((long long)b * n + ray) * S;        // first sample of this ray in the (B, n, S) tensors
+    const RayDir d = ray_dir(g, ray);
+    const bool has_jit = g.jitter != nullptr;
+    float bias[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = bfv[(r & 3) + 8 * (r >> 2) + 4 * hfs];
+    float F[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) F[r] = 0.f;
+    float flast[16];
+    double T = 1.0;
+    float depth = 0.f, wsum = 0.f, wlast = 0.f, zlast = 0.f;
+    // sample s: world point + depth; the depth of sample s+1 gives delta_s
+    float wx, wy, wz, zs;
+    ray_point(g, M, d, g.zg[0], has_jit ? g.jitter[rs] : 0.f, has_jit, wx, wy, wz, zs);
+    float u_next = (has_jit && S > 1) ? g.jitter[rs + 1] : 0.f;
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      const int hf = lane >> 5;
+      const LaneAddr LA = lane_addr(lane, sbase);
+      // next sample's point now (its jitter was requested one step ago), the one after that requested now
+      float nx = 0.f, ny = 0.f, nz = 0.f, zn = 0.f;
+      if (s + 1 < S) ray_point(g, M, d, g.zg[s + 1], u_next, has_jit, nx, ny, nz, zn);
+      if (has_jit && s + 2 < S) u_next = g.jitter[rs + s + 2];
+      const float nse = a.noise ? a.noise[rs + s] : 0.f;
+
+      const float px = wx, py = wy, pz = wz;
+#include "siren_fwd_chain.inc"
+      float f[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) f[r] = accf[0][r] + bias[r];
+      // ---- composite (pigan_utils.py:239-258): alpha = 1 - exp(-delta * clamp(sigma + noise)), w = alpha * T ----
+      const float delta = (s + 1 < S) ? (zn - zs) : 1e10f;
+      const float sg = a.noise ? sig + nse * a.noise_std : sig;
+      const float dens = (a.clamp_mode == 1) ? ((sg > 20.f) ? sg : log1pf(expf(sg))) : fmaxf(sg, 0.f);
+      const float alpha = 1.f - expf(-delta * dens);
+      const float w = alpha * (float)T;
+      T *= (double)(1.f - alpha + 1e-10f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) F[r] = fmaf(w, f[r], F[r]);
+      depth = fmaf(w, zs, depth);
+      wsum += w;
+      if (s == S - 1) {
+        wlast = w; zlast = zs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) flast[r] = f[r];
+      }
+      if (valid) {
+        if (a.feat) {
+          float* fo = a.feat + (rs + s) * CF + 4 * hf;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4*>(fo + 8 * gq) = make_float4(f[4 * gq], f[4 * gq + 1], f[4 * gq + 2], f[4 * gq + 3]);
+        }
+        if (hf == 0) {
+          if (a.sigma) a.sigma[rs + s] = sig;
+          if (a.zout) a.zout[rs + s] = zs;
+          if (a.weights && !(s == S - 1 && (a.flags & 1))) a.weights[rs + s] = w;
+        }
+      }
+      wx = nx; wy = ny; wz = nz; zs = zn;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (a.flags & 1) {           // last_back: weights[:, :, -1] += 1 - weights_sum (pigan_utils.py:261-263)
+      const float extra = 1.f - wsum;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) F[r] = fmaf(extra, flast[r], F[r]);
+      depth = fmaf(extra, zlast, depth);
+      if (a.weights && valid && hfs == 0) a.weights[rs + S - 1] = wlast + extra;
+    }
+    if (a.flags & 2) {           // white_back: rgb + 1 - weights_sum (:266-268)
+      const float extra = 1.f - wsum;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) F[r] += extra;
+    }
+    if (valid) {
+      float* o = a.fea + ((long long)b * n + ray) * CF + 4 * hfs;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<float4*>(o + 8 * gq) = make_float4(F[4 * gq], F[4 * gq + 1], F[4 * gq + 2], F[4 * gq + 3]);
+      if (hfs == 0 && a.depth) a.depth[(long long)b * n + ray] = depth;
+    }
   }
 }
 
@@ -930,13 +1031,39 @@ extern "C" int cips_siren_bwd_x3_prof(unsigned long long* host_out) {   // tunin
 }
 extern "C" int cips_siren_bwd_x3_sred(void) { return SRED; }
 
+static int fill_raygen(RayGen& g, const cips_ray_params* r) {
+  if (!r || !r->xg || !r->yg || !r->zg || !r->cam2world || r->W <= 0 || r->H <= 0 || r->S <= 1) return (int)hipErrorInvalidValue;
+  g.xg = r->xg; g.yg = r->yg; g.zg = r->zg; g.c2w = r->cam2world; g.jitter = r->jitter; g.zc = r->zc;
+  g.W = r->W; g.n = r->W * r->H; g.S = r->S;
+  return 0;
+}
+
+static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points, const cips_ray_params* rays,
+                               const float* dfeat, const float* dsigma, float* sred, float* gpart, int B, int P,
+                               cips_stream_t stream);
+
 extern "C" int cips_siren_bwd_x3(const cips_siren_weights* w, const float* points, const float* dfeat,
                                  const float* dsigma, float* sred, float* gpart, int B, int P,
                                  cips_stream_t stream) {
-  if (!w || !points || !dfeat || !dsigma || !sred || !gpart || B <= 0 || P <= 0) return (int)hipErrorInvalidValue;
+  if (!points) return (int)hipErrorInvalidValue;
+  return siren_bwd_x3_launch(w, points, nullptr, dfeat, dsigma, sred, gpart, B, P, stream);
+}
+
+extern "C" int cips_siren_bwd_x3_rays(const cips_siren_weights* w, const cips_ray_params* rays, const float* dfeat,
+                                      const float* dsigma, float* sred, float* gpart, int B, cips_stream_t stream) {
+  if (!rays) return (int)hipErrorInvalidValue;
+  return siren_bwd_x3_launch(w, nullptr, rays, dfeat, dsigma, sred, gpart, B, rays->W * rays->H * rays->S, stream);
+}
+
+static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points, const cips_ray_params* rays,
+                               const float* dfeat, const float* dsigma, float* sred, float* gpart, int B, int P,
+                               cips_stream_t stream) {
+  if (!w || !dfeat || !dsigma || !sred || !gpart || B <= 0 || P <= 0) return (int)hipErrorInvalidValue;
   BwdX3Args a;
   a.w = *w; a.points = points; a.dfeat = dfeat; a.dsigma = dsigma; a.sred = sred; a.gpart = gpart;
   a.B = B; a.P = P;
+  a.rg = RayGen{};
+  if (!points) { const int rc = fill_raygen(a.rg, rays); if (rc) return rc; }
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("CIPS_X3_DBG"); dbg = e ? atoi(e) : 0; }
   a.dbg = dbg;
@@ -984,5 +1111,34 @@ extern "C" int cips_siren_fwd_x3(const cips_siren_weights* w, const float* point
     hipLaunchKernelGGL(siren_fwd_x3_kernel<true>, grid, dim3(512), smem, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(siren_fwd_x3_kernel<false>, grid, dim3(512), smem, (hipStream_t)stream, a);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_params* rays, const float* noise,
+                                 float noise_std, int clamp_mode, int flags, float* fea, float* depth, float* weights,
+                                 float* feat, float* sigma, float* z, int B, cips_stream_t stream) {
+  if (!w || !fea || B <= 0) return (int)hipErrorInvalidValue;
+  MarchArgs a;
+  a.w = *w;
+  const int rc = fill_raygen(a.rg, rays);
+  if (rc) return rc;
+  a.noise = noise; a.noise_std = noise_std; a.clamp_mode = clamp_mode; a.flags = flags;
+  a.fea = fea; a.depth = depth; a.weights = weights; a.feat = feat; a.sigma = sigma; a.zout = z; a.B = B;
+  // a workgroup's 8 waves take 32 rays each: 256-ray chunks keep all of them busy; halve only for small images
+  a.rays_per_wg = 256;
+  const int n = a.rg.n;
+  dim3 grid((n + a.rays_per_wg - 1) / a.rays_per_wg, B);
+  const int smem = O_STG;
+  static bool attr_set = false;
+  CIPS_PER_DEVICE(attr_set, false);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  if (w->trig_mode == 1)
+    hipLaunchKernelGGL(siren_march_x3_kernel<true>, grid, dim3(512), smem, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(siren_march_x3_kernel<false>, grid, dim3(512), smem, (hipStream_t)stream, a);
   return CIPS_CHECK_LAUNCH();
 }

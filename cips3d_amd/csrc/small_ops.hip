@@ -1,0 +1,241 @@
+// small_ops.hip — the O(batch) linear layers around the hot path as a handful of grouped launches for gfx950.
+//
+// Every per-image vector the kernels consume is a Linear of a style vector: the 18 SinStyleMod.modulation layers of the
+// CIPS head (exp/comm/models/mod_conv_fc.py:433-436, :474: s = modulation(style), 512 -> 512 / 32) and the gain_fc /
+// bias_fc pairs of the three FiLM layers (exp/comm/models/film_layer.py:59-63, :88-93, 128 -> 128 / 64).  As torch ops
+// they are 24 forward GEMMs of 32 rows (hipBLASLt, ~11 us each, launch-bound) and 48 backward GEMMs plus bias
+// reductions per step — 0.9 ms of a 20 ms step for 0.2 GFLOP.  Here: one launch forward, three backward, over a table of
+// jobs that share the batch size; weight-read bound (18 MB), deterministic (fixed summation order, no atomics).
+#include "common.h"
+#include "../../include/cips3d_hip.h"
+
+namespace {
+
+constexpr int GL_MAX = 32;     // jobs per launch
+constexpr int GL_ROWS = 32;    // batch rows per register tile
+
+struct GLJobs {
+  const float* x[GL_MAX]; const float* w[GL_MAX]; const float* bias[GL_MAX]; float* y[GL_MAX];
+  const float* dy[GL_MAX]; float* dw[GL_MAX]; float* db[GL_MAX];
+  int in_dim[GL_MAX], out_dim[GL_MAX];
+  int tile0[GL_MAX + 1];       // first workgroup tile of each job (prefix sums)
+  int njobs;
+};
+
+__device__ __forceinline__ int find_job(const GLJobs& J, int tile) {
+  int j = 0;
+  while (j + 1 < J.njobs && tile >= J.tile0[j + 1]) ++j;
+  return j;
+}
+
+// y[b][o] = sum_i x[b][i] w[o][i] + bias[o].  One wave per 4 outputs: the lanes stride over i with 16-byte loads of the
+// weight row (coalesced) and of the x rows (LDS), 32 batch rows in registers, then a transpose-reduce over the lanes.
+__global__ __launch_bounds__(256) void glin_fwd_kernel(GLJobs J, int B, float out_scale_unused) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];       // [GL_ROWS][in_dim]
+  const int job = find_job(J, blockIdx.x);
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  const int o0 = (blockIdx.x - J.tile0[job]) * 16;                  // 16 outputs per workgroup (4 waves x 4)
+  const float* __restrict__ x = J.x[job];
+  const float* __restrict__ w = J.w[job];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b0 = 0; b0 < B; b0 += GL_ROWS) {
+    const int nb = min(GL_ROWS, B - b0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < GL_ROWS * in_dim / 4; i += 256) {
+      const int r = i / (in_dim / 4), c = i - r * (in_dim / 4);
+      reinterpret_cast<float4*>(xs)[i] = r < nb ? reinterpret_cast<const float4*>(x + (long long)(b0 + r) * in_dim)[c]
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    for (int oo = 0; oo < 4; ++oo) {
+      const int o = o0 + wave * 4 + oo;
+      if (o >= out_dim) break;
+      float acc[GL_ROWS];
+#pragma unroll
+      for (int r = 0; r < GL_ROWS; ++r) acc[r] = 0.f;
+      for (int i4 = lane; i4 < in_dim / 4; i4 += 64) {
+        const float4 wv = reinterpret_cast<const float4*>(w + (long long)o * in_dim)[i4];
+#pragma unroll
+        for (int r = 0; r < GL_ROWS; ++r) {
+          const float4 xv = reinterpret_cast<const float4*>(xs + r * in_dim)[i4];
+          acc[r] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[r]))));
+        }
+      }
+      // transpose-reduce: after the step with mask m a lane keeps the rows whose bit matches its own lane bit
+      float v16[16], v8[8], v4[4], v2[2], v1;
+      {
+        const bool up = lane & 32;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const float send = up ? acc[k] : acc[k + 16], keep = up ? acc[k + 16] : acc[k];
+          v16[k] = keep + __shfl_xor(send, 32);
+        }
+      }
+      {
+        const bool up = lane & 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float send = up ? v16[k] : v16[k + 8], keep = up ? v16[k + 8] : v16[k];
+          v8[k] = keep + __shfl_xor(send, 16);
+        }
+      }
+      {
+        const bool up = lane & 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float send = up ? v8[k] : v8[k + 4], keep = up ? v8[k + 4] : v8[k];
+          v4[k] = keep + __shfl_xor(send, 8);
+        }
+      }
+      {
+        const bool up = lane & 4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float send = up ? v4[k] : v4[k + 2], keep = up ? v4[k + 2] : v4[k];
+          v2[k] = keep + __shfl_xor(send, 4);
+        }
+      }
+      {
+        const bool up = lane & 2;
+        const float send = up ? v2[0] : v2[1], keep = up ? v2[1] : v2[0];
+        v1 = keep + __shfl_xor(send, 2);
+      }
+      v1 += __shfl_xor(v1, 1);
+      // the lane now holds row r = 16*b5 + 8*b4 + 4*b3 + 2*b2 + b1 (its lane bits 5..1)
+      const int r = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+      if ((lane & 1) == 0 && r < nb)
+        J.y[job][(long long)(b0 + r) * out_dim + o] = v1 + (J.bias[job] ? J.bias[job][o] : 0.f);
+    }
+  }
+}
+
+// dw[o][i] = sum_b dy[b][o] x[b][i];  db[o] = sum_b dy[b][o].  Thread = one i (16-byte column group), the x column in
+// registers, dy[b][o] uniform per workgroup row -> scalar operand; 16 outputs per workgroup.
+__global__ __launch_bounds__(128) void glin_bwd_w_kernel(GLJobs J, int B) {
+  const int job = find_job(J, blockIdx.x);
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  const int o0 = (blockIdx.x - J.tile0[job]) * 16;
+  const float* __restrict__ x = J.x[job];
+  const float* __restrict__ dy = J.dy[job];
+  const int i4 = threadIdx.x;                                       // in_dim / 4 <= 128
+  const bool on = i4 < in_dim / 4;
+  for (int oo = 0; oo < 16; ++oo) {
+    const int o = o0 + oo;
+    if (o >= out_dim) break;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float g = dy[(long long)b * out_dim + o];
+      sb += g;
+      if (on) {
+        const float4 xv = reinterpret_cast<const float4*>(x + (long long)b * in_dim)[i4];
+        acc.x = fmaf(g, xv.x, acc.x); acc.y = fmaf(g, xv.y, acc.y); acc.z = fmaf(g, xv.z, acc.z); acc.w = fmaf(g, xv.w, acc.w);
+      }
+    }
+    if (on) reinterpret_cast<float4*>(J.dw[job] + (long long)o * in_dim)[i4] = acc;
+    if (threadIdx.x == 0 && J.db[job]) J.db[job][o] = sb;
+  }
+}
+
+// dx partials: part[chunk][b][i] = sum over the chunk's (job, o) pairs of dy[b][o] w[o][i]; chunk = 64 outputs of one
+// job; thread = 4 consecutive i, 32 batch rows in registers.  All jobs of a launch share x (same in_dim).
+__global__ __launch_bounds__(128) void glin_bwd_x_kernel(GLJobs J, int B, int in_dim, float* __restrict__ part) {
+  const int job = find_job(J, blockIdx.x);
+  const int out_dim = J.out_dim[job];
+  const int o0 = (blockIdx.x - J.tile0[job]) * 64;
+  const float* __restrict__ w = J.w[job];
+  const float* __restrict__ dy = J.dy[job];
+  const int i4 = threadIdx.x;
+  if (i4 >= in_dim / 4) return;
+  for (int b0 = 0; b0 < B; b0 += GL_ROWS) {
+    const int nb = min(GL_ROWS, B - b0);
+    float4 acc[GL_ROWS];
+#pragma unroll
+    for (int r = 0; r < GL_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int oend = min(o0 + 64, out_dim);
+    for (int o = o0; o < oend; ++o) {
+      const float4 wv = reinterpret_cast<const float4*>(w + (long long)o * in_dim)[i4];
+#pragma unroll
+      for (int r = 0; r < GL_ROWS; ++r) {
+        const float g = (r < nb) ? dy[(long long)(b0 + r) * out_dim + o] : 0.f;
+        acc[r].x = fmaf(g, wv.x, acc[r].x); acc[r].y = fmaf(g, wv.y, acc[r].y);
+        acc[r].z = fmaf(g, wv.z, acc[r].z); acc[r].w = fmaf(g, wv.w, acc[r].w);
+      }
+    }
+    for (int r = 0; r < nb; ++r)
+      reinterpret_cast<float4*>(part + ((long long)blockIdx.x * B + b0 + r) * in_dim)[i4] = acc[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void glin_sum_kernel(const float* __restrict__ part, float* __restrict__ dx, int nchunks, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += part[(long long)c * n + i];
+  dx[i] = s;
+}
+
+int fill(GLJobs& J, const cips_glin_job* jobs, int njobs, int outs_per_tile) {
+  if (!jobs || njobs <= 0 || njobs > GL_MAX) return (int)hipErrorInvalidValue;
+  J.njobs = njobs;
+  int t = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const cips_glin_job& q = jobs[j];
+    if (!q.x || !q.w || q.in_dim <= 0 || q.out_dim <= 0 || (q.in_dim & 3) || q.in_dim > 512) return (int)hipErrorInvalidValue;
+    J.x[j] = q.x; J.w[j] = q.w; J.bias[j] = q.bias; J.y[j] = q.y; J.dy[j] = q.dy; J.dw[j] = q.dw; J.db[j] = q.db;
+    J.in_dim[j] = q.in_dim; J.out_dim[j] = q.out_dim;
+    J.tile0[j] = t;
+    t += (q.out_dim + outs_per_tile - 1) / outs_per_tile;
+  }
+  J.tile0[njobs] = t;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int cips_grouped_linear_max_jobs(void) { return GL_MAX; }
+
+extern "C" int cips_grouped_linear_fwd(const cips_glin_job* jobs, int njobs, int B, cips_stream_t stream) {
+  GLJobs J;
+  int rc = fill(J, jobs, njobs, 16);
+  if (rc) return rc;
+  if (B <= 0) return (int)hipErrorInvalidValue;
+  int max_in = 0;
+  for (int j = 0; j < njobs; ++j) { if (!jobs[j].y) return (int)hipErrorInvalidValue; max_in = jobs[j].in_dim > max_in ? jobs[j].in_dim : max_in; }
+  const size_t smem = (size_t)GL_ROWS * max_in * sizeof(float);
+  static bool attr_set = false;
+  CIPS_PER_DEVICE(attr_set, false);
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)glin_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GL_ROWS * 512 * 4); attr_set = true; }
+  hipLaunchKernelGGL(glin_fwd_kernel, dim3(J.tile0[njobs]), dim3(256), smem, (hipStream_t)stream, J, B, 1.f);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_grouped_linear_bwd(const cips_glin_job* jobs, int njobs, int B, float* dx, float* scratch,
+                                       long long scratch_floats, cips_stream_t stream) {
+  GLJobs J;
+  int rc = fill(J, jobs, njobs, 16);
+  if (rc) return rc;
+  if (B <= 0) return (int)hipErrorInvalidValue;
+  for (int j = 0; j < njobs; ++j) if (!jobs[j].dy || !jobs[j].dw) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(glin_bwd_w_kernel, dim3(J.tile0[njobs]), dim3(128), 0, (hipStream_t)stream, J, B);
+  if (dx) {
+    const int in_dim = jobs[0].in_dim;
+    for (int j = 1; j < njobs; ++j) if (jobs[j].in_dim != in_dim || jobs[j].x != jobs[0].x) return (int)hipErrorInvalidValue;
+    GLJobs K;
+    rc = fill(K, jobs, njobs, 64);
+    if (rc) return rc;
+    const int nchunks = K.tile0[njobs];
+    if (!scratch || scratch_floats < (long long)nchunks * B * in_dim) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(glin_bwd_x_kernel, dim3(nchunks), dim3(128), 0, (hipStream_t)stream, K, B, in_dim, scratch);
+    const long long n = (long long)B * in_dim;
+    hipLaunchKernelGGL(glin_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch, dx, nchunks, n);
+  }
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" long long cips_grouped_linear_scratch(const cips_glin_job* jobs, int njobs, int B) {
+  if (!jobs || njobs <= 0) return 0;
+  long long chunks = 0;
+  for (int j = 0; j < njobs; ++j) chunks += (jobs[j].out_dim + 63) / 64;
+  return chunks * B * jobs[0].in_dim;
+}

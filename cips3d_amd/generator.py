@@ -179,6 +179,20 @@ class NeRFNetwork(nn.Module):
             self.color_layer_sine.linear.weight, self.color_layer_sine.linear.bias,
             self.color_layer_linear[0].weight, self.color_layer_linear[0].bias)
 
+    def march(self, style_dict, geom, xg, yg, zg, cam2world, jitter, noise):
+        """fused rays + SIREN + composite for non-hierarchical sampling -> pixels_fea (b,n,32), depth (b,n)"""
+        p = self.name_prefix
+        g0, p0 = self.network[0].film(style_dict[f'{p}_w0'])
+        g1, p1 = self.network[1].film(style_dict[f'{p}_w1'])
+        gc, pc = self.color_layer_sine.film(style_dict[f'{p}_rgb'])
+        return ops.RayMarchFunction.apply(
+            geom, xg, yg, zg, cam2world, jitter, noise, g0, p0, g1, p1, gc, pc,
+            self.network[0].linear.weight, self.network[0].linear.bias,
+            self.network[1].linear.weight, self.network[1].linear.bias,
+            self.final_layer.weight, self.final_layer.bias,
+            self.color_layer_sine.linear.weight, self.color_layer_sine.linear.bias,
+            self.color_layer_linear[0].weight, self.color_layer_linear[0].bias)
+
     def forward(self, input, style_dict, ray_directions=None, **kwargs):
         feat, sigma = self.evaluate(input, style_dict)
         return torch.cat([feat, sigma.unsqueeze(-1)], dim=-1)
@@ -551,7 +565,11 @@ class GeneratorNerfINR(nn.Module):
             yg = torch.linspace(1, -1, H, device=device)
             zg = torch.linspace(ray_start, ray_end, S, device=device)
             zc = float((-torch.ones(1) / np.tan((2 * math.pi * fov / 360) / 2)).item())
-            points, z_vals, dirs = ops.rays_fwd(xg, yg, zg, zc, cam2world, jitter.reshape(b, n, S), b, H, W, S)
+            # non-hierarchical sampling of whole images: rays + SIREN + composite fused in one kernel that walks the
+            # samples along each ray (ops.RayMarchFunction); no (b,n,S,3) points, no per-sample features in HBM
+            fused = (not hierarchical_sample) and (not part) and ops.march_available()
+            if not fused:
+                points, z_vals, dirs = ops.rays_fwd(xg, yg, zg, zc, cam2world, jitter.reshape(b, n, S), b, H, W, S)
             ray_origins = cam2world[:, :3, 3].contiguous()       # every ray starts at the camera
 
         nerf_styles = self._nerf_styles(style_dict)
@@ -586,7 +604,18 @@ class GeneratorNerfINR(nn.Module):
                 pixels_fea = pixels_fea.detach()
             return self.inr_net(pixels_fea, style_dict), aux
 
-        if not part:
+        if fused:
+            ctx_nerf = torch.enable_grad() if nerf_grad else torch.no_grad()
+            with ctx_nerf:
+                geom = (b, H, W, S, zc, float(nerf_noise), clamp, flags)
+                pixels_fea, _depth = self.siren.march(nerf_styles, geom, xg, yg, zg, cam2world, jitter.reshape(b, n, S),
+                                                      noise_f.reshape(b, n, S) if nerf_noise != 0 else None)
+                aux_img = torch.tanh(_ToRGBFunction.apply(pixels_fea, self.aux_to_rbg[0].weight,
+                                                          self.aux_to_rbg[0].bias)) if return_aux_img else None
+            if not nerf_grad:
+                pixels_fea = pixels_fea.detach()
+            inr_img = self.inr_net(pixels_fea, style_dict)
+        elif not part:
             inr_img, aux_img = pipeline(points, z_vals, dirs, n, noise_c, u, noise_f, nerf_grad)
         else:
             # ---- part_grad_forward (generator.py:1536-1657) ----

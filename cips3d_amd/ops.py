@@ -167,23 +167,36 @@ class SirenFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeat, dsigma):
-        lib = _lib.load()
         points = ctx.saved_tensors[0]
         t = dict(zip(_SIREN_NAMES, ctx.saved_tensors[1:]))
         B, P, _ = points.shape
         dev = points.device
         dfeat = _c(dfeat) if dfeat is not None else torch.zeros(B, P, 32, device=dev)
         dsigma = _c(dsigma) if dsigma is not None else torch.zeros(B, P, device=dev)
-        sw = _siren_struct(t)
-        if SIREN_BWD_MODE == "x3":
+        return (None,) + _siren_backward(t, dfeat, dsigma, B, P, points=points)
+
+
+def _siren_backward(t, dfeat, dsigma, B, P, points=None, rays=None):
+    """SIREN backward for upstream gradients dfeat (B,P,32), dsigma (B,P): -> (dg0, dp0, dg1, dp1, dgc, dpc, dw0, db0, dw1,
+    db1, dws, dbs, dwc, dbc, dwf, dbf).  The sample points are either given (B,P,3) or regenerated in-kernel from
+    `rays` (a RayParams struct; fused bf16x3 form only)."""
+    lib = _lib.load()
+    dev = dfeat.device
+    sw = _siren_struct(t)
+    if True:
+        if SIREN_BWD_MODE == "x3" or points is None:
             # fused kernel: recompute + data gradients + weight-gradient contractions, nothing staged in HBM
             chunks = lib.cips_siren_bwd_x3_chunks(B, P)
             gw = lib.cips_siren_bwd_x3_gpart()
             sw_ = lib.cips_siren_bwd_x3_sred()
             sred = torch.empty(B * chunks, sw_, device=dev)
             gpart = torch.empty(B * chunks, gw, device=dev)
-            check(lib.cips_siren_bwd_x3(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(sred), _p(gpart), B, P,
-                                        _stream()), "cips_siren_bwd_x3")
+            if points is not None:
+                check(lib.cips_siren_bwd_x3(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(sred), _p(gpart), B, P,
+                                            _stream()), "cips_siren_bwd_x3")
+            else:
+                check(lib.cips_siren_bwd_x3_rays(C.byref(sw), C.byref(rays), _p(dfeat), _p(dsigma), _p(sred), _p(gpart), B,
+                                                 _stream()), "cips_siren_bwd_x3_rays")
             SR = sred.view(B, chunks, sw_).sum(1)
             T = SR[:, :1024].view(B, 4, 32, 8)                     # [wave][row][column sums], see cips3d_hip.h
             R = torch.zeros(B, 868, device=dev)                    # same row format as the staged data pass
@@ -243,7 +256,7 @@ class SirenFunction(torch.autograd.Function):
         dws = R[:, 704:832].sum(0, keepdim=True)
         dbf = R[:, 832:864].sum(0)
         dbs = R[:, 864].sum().view(1)
-        return (None, dg0, dp0, dg1, dp1, dgc, dpc, dw0, db0, dw1, db1, dws, dbs, dwc, dbc, dwf, dbf)
+        return (dg0, dp0, dg1, dp1, dgc, dpc, dw0, db0, dw1, db1, dws, dbs, dwc, dbc, dwf, dbf)
 
 
 # --------------------------------------------------------------------------------------
@@ -318,6 +331,83 @@ class CompositeFunction(torch.autograd.Function):
                                      noise_std, _p(order), _p(dfea), _p(dfeat_c), _p(dsig_c), _p(dfeat_f),
                                      _p(dsig_f), R, S, clamp_mode, flags, _stream()), "cips_composite_bwd")
         return dfeat_c, dsig_c, None, dfeat_f, dsig_f, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------
+# Fused ray-march (non-hierarchical sampling): rays + SIREN + composite in one kernel
+# --------------------------------------------------------------------------------------
+import os as _os0
+MARCH_FUSED = _os0.environ.get("CIPS_MARCH_FUSED", "1") != "0"
+
+
+def march_available():
+    """the fused march runs on the split-bf16 register chain (forward) and regenerates points in the fused backward"""
+    return MARCH_FUSED and SIREN_FWD_MODE == "x3" and SIREN_BWD_MODE == "x3"
+
+
+def _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S):
+    from ._lib import RayParams
+    r = RayParams()
+    r.xg, r.yg, r.zg, r.cam2world, r.jitter = _p(xg), _p(yg), _p(zg), _p(cam2world), _p(jitter)
+    r.zc, r.H, r.W, r.S = float(zc), H, W, S
+    return r
+
+
+class RayMarchFunction(torch.autograd.Function):
+    """pixels_fea (B,n,32), depth (B,n) = composite(SIREN(points(rays, jitter))) for hierarchical_sample=False: the
+    chain get_initial_rays_trig / perturb_points / transform_sampled_points (comm_utils.py:365-438, 584-679) ->
+    NeRFNetwork (generator.py:260-317) -> fancy_integration (pigan_utils.py:212-273) as ONE kernel that walks the
+    samples along each ray (cips_march_fwd_x3).  Under no_grad nothing per-sample reaches HBM (4 S + 132 B per ray);
+    a training forward also writes feat / sigma / z for the backward, which is cips_composite_bwd followed by the fused
+    SIREN backward with the points regenerated in-kernel (cips_siren_bwd_x3_rays)."""
+
+    @staticmethod
+    def forward(ctx, geom, xg, yg, zg, cam2world, jitter, noise, g0, p0, g1, p1, gc, pc, w0, b0, w1, b1, ws, bs, wc, bc,
+                wf, bf):
+        lib = _lib.load()
+        B, H, W, S, zc, noise_std, clamp_mode, flags = geom
+        t = dict(w0=w0, b0=b0, w1=w1, b1=b1, ws=ws, bs=bs, wc=wc, bc=bc, wf=wf, bf=bf,
+                 g0=g0, p0=p0, g1=g1, p1=p1, gc=gc, pc=pc)
+        t = {k: _c(v.detach()) for k, v in t.items()}
+        xg, yg, zg, cam2world = _c(xg), _c(yg), _c(zg), _c(cam2world)
+        jitter = _c(jitter) if jitter is not None else None
+        noise = _c(noise) if (noise is not None and noise_std != 0.0) else None
+        _chk(xg, yg, zg, cam2world, jitter, noise, *t.values())
+        dev = cam2world.device
+        n = H * W
+        train = any(ctx.needs_input_grad)
+        fea = torch.empty(B, n, 32, device=dev)
+        depth = torch.empty(B, n, device=dev)
+        feat = torch.empty(B, n * S, 32, device=dev) if train else None
+        sigma = torch.empty(B, n * S, device=dev) if train else None
+        z = torch.empty(B, n * S, device=dev) if train else None
+        sw = _siren_struct(t)
+        rp = _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S)
+        check(lib.cips_march_fwd_x3(C.byref(sw), C.byref(rp), _p(noise), float(noise_std), clamp_mode, flags, _p(fea),
+                                    _p(depth), None, _p(feat), _p(sigma), _p(z), B, _stream()), "cips_march_fwd_x3")
+        if train:
+            ctx.save_for_backward(xg, yg, zg, cam2world, jitter, noise, feat, sigma, z, *[t[k] for k in _SIREN_NAMES])
+        ctx.geom = geom
+        ctx.mark_non_differentiable(depth)
+        return fea, depth
+
+    @staticmethod
+    def backward(ctx, dfea, _ddepth):
+        lib = _lib.load()
+        xg, yg, zg, cam2world, jitter, noise, feat, sigma, z = ctx.saved_tensors[:9]
+        t = dict(zip(_SIREN_NAMES, ctx.saved_tensors[9:]))
+        B, H, W, S, zc, noise_std, clamp_mode, flags = ctx.geom
+        n = H * W
+        R = B * n
+        dfea = _c(dfea)
+        dfeat = torch.empty_like(feat)
+        dsig = torch.empty_like(sigma)
+        check(lib.cips_composite_bwd(_p(feat), _p(sigma), _p(z), None, None, None, _p(noise), float(noise_std), None,
+                                     _p(dfea), _p(dfeat), _p(dsig), None, None, R, S, clamp_mode, flags, _stream()),
+              "cips_composite_bwd")
+        rp = _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S)
+        grads = _siren_backward(t, dfeat, dsig, B, n * S, rays=rp)
+        return (None,) * 7 + grads
 
 
 # --------------------------------------------------------------------------------------

@@ -123,6 +123,34 @@ int cips_siren_bwd_x3_prof(unsigned long long* host_out);
 int cips_siren_bwd_x3(const cips_siren_weights* w, const float* points, const float* dfeat,
                       const float* dsigma, float* sred, float* gpart, int B, int P, cips_stream_t stream);
 
+/* Ray parameters for in-kernel point generation (what cips_rays_fwd materialises): the sample point of
+ * (image b, ray r, sample s) is recomputed from the linspace grids, the camera matrix and the jitter draw, 4 B per
+ * point read instead of 12 B and no (B, n, S, 3) tensor in HBM.  Point index p = r * S + s. */
+typedef struct cips_ray_params {
+  const float* xg; const float* yg; const float* zg;   /* torch.linspace grids (W), (H), (S) */
+  const float* cam2world;                                /* (B,4,4) */
+  const float* jitter;                                   /* (B,n,S) uniforms in [0,1) or NULL */
+  float zc;                                              /* -1/tan(fov/2) */
+  int H, W, S;
+} cips_ray_params;
+
+/* cips_siren_bwd_x3 with the points generated in-kernel from `rays` (P = H*W*S points per image). */
+int cips_siren_bwd_x3_rays(const cips_siren_weights* w, const cips_ray_params* rays, const float* dfeat,
+                           const float* dsigma, float* sred, float* gpart, int B, cips_stream_t stream);
+
+/* Fused ray-march for NON-hierarchical sampling: ray set-up + FiLM-SIREN + alpha-composite in one kernel that walks
+ * the samples along the ray (a wave owns 32 rays, one lane pair per ray; the running transmittance / feature / depth
+ * accumulators live in registers).  Replaces, for hierarchical_sample=False,
+ *   exp/comm/comm_utils.py:365-438, 584-679 (rays), exp/cips3d/models/generator.py:260-317 (SIREN),
+ *   exp/pigan/pigan_utils.py:212-273 (fancy_integration; the merge of generator.py:1733-1752 is the identity).
+ * noise (B,n,S) standard normals or NULL; clamp_mode 0 relu / 1 softplus; flags bit0 last_back, bit1 white_back.
+ * out: fea (B,n,32), depth (B,n) [may be NULL]; optional: weights (B,n,S), and — for a training forward whose backward
+ * needs them — the per-sample feat (B,P,32), sigma (B,P), z (B,P).  With those NULL the kernel moves 4*S + 132 B per ray
+ * (SURVEY.md §8d-iii). */
+int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_params* rays, const float* noise, float noise_std,
+                      int clamp_mode, int flags, float* fea, float* depth, float* weights, float* feat, float* sigma,
+                      float* z, int B, cips_stream_t stream);
+
 /* ------------------------------------------------------------------ */
 /* H3  hierarchical resampling + merge + alpha-composite               */
 /* ------------------------------------------------------------------ */
@@ -160,7 +188,7 @@ int cips_composite_fwd(const float* feat_c, const float* sig_c, const float* z_c
 /* Backward of the above w.r.t. feat/sigma of both sample sets (z has no grad:
  * fine z is detach()ed, generator_nerf_inr.py:575-579; coarse z is an input).
  * dfea (R,32) upstream.  Re-reads the forward inputs (no saved activations
- * besides `order`). */
+ * besides `order`; order == NULL with no fine set means the identity). */
 int cips_composite_bwd(const float* feat_c, const float* sig_c, const float* z_c,
                        const float* feat_f, const float* sig_f, const float* z_f,
                        const float* noise, float noise_std, const int* order,
@@ -309,6 +337,24 @@ typedef struct cips_modfc_bwd_job {
 int cips_modfc_max_jobs(void);
 int cips_modfc_prep_x3_batch(const cips_modfc_prep_job* jobs, int njobs, int B, float eps, cips_stream_t stream);
 int cips_modfc_prep_bwd_batch(const cips_modfc_bwd_job* jobs, int njobs, int B, cips_stream_t stream);
+
+/* Grouped small Linear layers: every per-image vector of the hot path is a Linear of a style vector — the 18
+ * SinStyleMod.modulation layers of the CIPS head (exp/comm/models/mod_conv_fc.py:433-436, 474) and the gain_fc / bias_fc
+ * pairs of the FiLM layers (exp/comm/models/film_layer.py:59-63, 88-93).  One launch for all of them:
+ *   forward   y_j (B,out_j) = x_j (B,in_j) w_j^T (out_j,in_j) + bias_j            (bias may be NULL)
+ *   backward  dw_j = dy_j^T x_j, db_j = sum_b dy_j (db may be NULL), and — when dx != NULL, for jobs that all share one
+ *             x — dx (B,in) = sum_j dy_j w_j (partials in `scratch`, cips_grouped_linear_scratch() floats, summed in
+ *             a fixed order).  in_j % 4 == 0, in_j <= 512, njobs <= cips_grouped_linear_max_jobs(). */
+typedef struct cips_glin_job {
+  const float* x; const float* w; const float* bias; float* y;      /* forward */
+  const float* dy; float* dw; float* db;                             /* backward */
+  int in_dim, out_dim;
+} cips_glin_job;
+int cips_grouped_linear_max_jobs(void);
+int cips_grouped_linear_fwd(const cips_glin_job* jobs, int njobs, int B, cips_stream_t stream);
+long long cips_grouped_linear_scratch(const cips_glin_job* jobs, int njobs, int B);
+int cips_grouped_linear_bwd(const cips_glin_job* jobs, int njobs, int B, float* dx, float* scratch,
+                            long long scratch_floats, cips_stream_t stream);
 
 /* ToRGB (generator.py:983-1006): rgb (M,3) (+)= x (M,K) @ w^T (3,K) + bias.
  * accumulate != 0: rgb += ...  */

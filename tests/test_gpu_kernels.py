@@ -191,6 +191,82 @@ def test_rays_match_oracle():
     assert max_rel(dirs, r["dirs"]) < 1e-5
 
 
+@pytest.mark.parametrize("img,S,b,noise_std,clamp,flags", [(8, 4, 2, 0.0, "relu", 0), (16, 24, 2, 0.3, "relu", 0),
+                                                           (10, 5, 3, 0.2, "softplus", 3), (24, 12, 1, 0.0, "relu", 1)])
+def test_fused_march_forward_backward(img, S, b, noise_std, clamp, flags):
+    """The fused ray-march (rays + SIREN + composite in one kernel, non-hierarchical sampling; cips_march_fwd_x3 and
+    its backward cips_composite_bwd + cips_siren_bwd_x3_rays) against the oracle's rays -> siren -> integrate chain:
+    per-sample outputs (feat, sigma, z, weights), pixel features and depth, and every SIREN parameter / style gradient;
+    images whose ray count is not a multiple of the 32-ray wave granule, noise, softplus, last_back / white_back."""
+    import ctypes as C
+    from cips3d_amd import ops, _lib
+    from cips3d_amd._lib import check
+    d = dev()
+    n = img * img
+    G = seeded_generator(11)
+    g = torch.Generator().manual_seed(100 + img + S)
+    style = torch.randn(b, 128, generator=g)
+    jitter = torch.rand(b, n, S, 1, generator=g)
+    theta, phi = torch.randn(b, 1, generator=g), torch.randn(b, 1, generator=g)
+    noise = torch.randn(b, n, S, 1, generator=g)
+    up = torch.randn(b, n, 32, generator=g)
+    sd = dict(G.named_parameters())
+    r = orc.rays(b, img, 12, 0.88, 1.12, S, jitter, theta, phi, 0.3, 0.155)
+    st_r = style.clone().requires_grad_(True)
+    out = orc.siren(sd, r["points"].reshape(b, n * S, 3), st_r).reshape(b, n, S, 33)
+    fea, depth, w = orc.integrate(out, r["z"], noise, noise_std, clamp_mode=clamp, last_back=bool(flags & 1),
+                                  white_back=bool(flags & 2))
+    (fea * up).sum().backward()
+    ref = {k: p.grad.clone() for k, p in G.siren.named_parameters()}
+    ref_style = st_r.grad.clone()
+    G.zero_grad()
+    # ---- HIP: direct call with every optional output ----
+    Gd = G.to(d)
+    lib = _lib.load()
+    xg = torch.linspace(-1, 1, img, device=d); yg = torch.linspace(1, -1, img, device=d); zg = torch.linspace(0.88, 1.12, S, device=d)
+    zc = float((-torch.ones(1) / torch.tan(torch.tensor((2 * math.pi * 12 / 360) / 2))).item())
+    c2w = r["cam2world"].to(d).contiguous()
+    std = style.to(d).requires_grad_(True)
+    sdict = {"nerf_w0": std, "nerf_w1": std, "nerf_rgb": std}
+    t = {}
+    net = Gd.siren
+    t["g0"], t["p0"] = net.network[0].film(std); t["g1"], t["p1"] = net.network[1].film(std); t["gc"], t["pc"] = net.color_layer_sine.film(std)
+    t.update(w0=net.network[0].linear.weight, b0=net.network[0].linear.bias, w1=net.network[1].linear.weight, b1=net.network[1].linear.bias,
+             ws=net.final_layer.weight, bs=net.final_layer.bias, wc=net.color_layer_sine.linear.weight, bc=net.color_layer_sine.linear.bias,
+             wf=net.color_layer_linear[0].weight, bf=net.color_layer_linear[0].bias)
+    tt = {k: v.detach().contiguous() for k, v in t.items()}
+    sw = ops._siren_struct(tt)
+    jd = jitter.to(d).reshape(b, n, S).contiguous(); nd = noise.to(d).reshape(b, n, S).contiguous()
+    rp = ops._ray_params(xg, yg, zg, zc, c2w, jd, img, img, S)
+    o_fea = torch.empty(b, n, 32, device=d); o_depth = torch.empty(b, n, device=d); o_w = torch.full((b, n, S), float("nan"), device=d)
+    o_feat = torch.empty(b, n * S, 32, device=d); o_sig = torch.empty(b, n * S, device=d); o_z = torch.empty(b, n * S, device=d)
+    P = lambda x: C.c_void_p(x.data_ptr())
+    check(lib.cips_march_fwd_x3(C.byref(sw), C.byref(rp), P(nd) if noise_std else None, float(noise_std), ops._CLAMP[clamp], flags,
+                                P(o_fea), P(o_depth), P(o_w), P(o_feat), P(o_sig), P(o_z), b, ops._stream()), "march")
+    torch.cuda.synchronize()
+    assert torch.equal(o_z.cpu().view(b, n, S), r["z"].view(b, n, S)) or max_rel(o_z.view(b, n, S), r["z"].view(b, n, S)) < 1e-6
+    e = [max_rel(o_feat.view(b, n, S, 32), out[..., :32]), max_rel(o_sig.view(b, n, S), out[..., 32]),
+         max_rel(o_w, w.view(b, n, S)), max_rel(o_fea, fea), max_rel(o_depth, depth.view(b, n))]
+    print(f"march {img}x{img} S={S} b={b} noise {noise_std} {clamp} flags {flags}: feat {e[0]:.2e} sigma {e[1]:.2e} weights {e[2]:.2e} "
+          f"fea {e[3]:.2e} depth {e[4]:.2e}")
+    assert max(e) < 2e-4
+    # ---- HIP: the autograd function (forward that keeps nothing per sample under no_grad; training forward + backward) ----
+    geom = (b, img, img, S, zc, float(noise_std), ops._CLAMP[clamp], flags)
+    with torch.no_grad():
+        f0, d0 = net.march(sdict, geom, xg, yg, zg, c2w, jd, nd)
+    assert torch.equal(f0, o_fea) and torch.equal(d0, o_depth)
+    f1, d1 = net.march(sdict, geom, xg, yg, zg, c2w, jd, nd)
+    assert torch.equal(f1, o_fea)
+    (f1 * up.to(d)).sum().backward()
+    torch.cuda.synchronize()
+    worst = rel_err(std.grad, ref_style)
+    for k, p in net.named_parameters():
+        worst = max(worst, rel_err(p.grad, ref[k]))
+        assert rel_err(p.grad, ref[k]) < TOL, k
+    print(f"march backward: worst gradient rel err {worst:.3e}")
+    assert worst < TOL
+
+
 @pytest.mark.parametrize("noise_std,clamp", [(0.0, "relu"), (0.4, "relu"), (0.2, "softplus")])
 def test_resample_matches_oracle_bookkeeping(noise_std, clamp):
     from cips3d_amd import ops
