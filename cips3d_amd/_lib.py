@@ -22,6 +22,11 @@ class SirenWeights(C.Structure):
                  "g0", "p0", "g1", "p1", "gc", "pc")] + [("box_scale", f32), ("trig_mode", i32)]
 
 
+class SirenGrads(C.Structure):
+    _fields_ = [(n, vp) for n in ("dg0", "dp0", "dg1", "dp1", "dgc", "dpc", "dw0", "db0", "dw1", "db1", "dws", "dbs", "dwc",
+                                  "dbc", "dwf", "dbf")]
+
+
 class RayParams(C.Structure):
     _fields_ = [("xg", vp), ("yg", vp), ("zg", vp), ("cam2world", vp), ("jitter", vp), ("zc", f32), ("H", i32), ("W", i32),
                 ("S", i32)]
@@ -97,6 +102,7 @@ SIGNATURES = {
     "cips_siren_bwd_x3_prof": (i32, [vp]),
     "cips_siren_bwd_x3": (i32, [C.POINTER(SirenWeights), vp, vp, vp, vp, vp, i32, i32, vp]),
     "cips_siren_bwd_x3_rays": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, vp, vp, vp, i32, vp]),
+    "cips_siren_bwd_x3_finalize": (i32, [C.POINTER(SirenWeights), vp, vp, i32, i32, C.POINTER(SirenGrads), vp]),
     "cips_march_fwd_x3": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, f32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "cips_siren_bwd_data": (i32, [C.POINTER(SirenWeights)] + [vp] * 14 + [i32, i32, vp]),
     "cips_resample_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

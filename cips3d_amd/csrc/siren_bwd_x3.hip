@@ -1011,6 +1011,116 @@ __global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Finalisation of the fused backward: the per-workgroup partials (sred, gpart) -> the 16 gradient tensors autograd
+// expects (FiLM gains / phases per image, weights and biases summed over the batch), in one launch instead of ~40 tiny
+// torch reductions / broadcasts.  Chain rule of film_layer.py:88-107 (arg = gain * (W x + b) + phase):
+//   d phase = sum_p d arg;  d gain = sum_j G[f][j] W[f][j] + b[f] d phase  (G = d arg^T h_in);  dW = sum_b gain_b G_b;
+//   db = sum_b gain_b d phase_b.  Layer 0's input is box_scale * point.  Fixed summation order: chunks, then images.
+// One workgroup of 128 threads per output row: [0,128) rows of dW1 (+ layer 0 and the sigma head of feature f),
+// [128,192) rows of dWc, [192,224) rows of dWf (+ its bias), 224: the sigma bias.
+struct FinArgs {
+  cips_siren_weights w;
+  const float* sred; const float* gpart;
+  cips_siren_grads o;
+  int B, chunks;
+};
+
+__global__ __launch_bounds__(128) void siren_bwd_finalize_kernel(FinArgs a) {
+  __shared__ float cols[8];
+  __shared__ float red[128];
+  const int task = blockIdx.x, j = threadIdx.x;
+  const int B = a.B, C = a.chunks;
+  auto colsum = [&](int b, int f, int col) {       // sum over chunks of column `col` of feature row f (SRED layout)
+    float s = 0.f;
+    const float* p = a.sred + (long long)b * C * SRED + (f >> 5) * 256 + (f & 31) * 8 + col;
+    for (int c = 0; c < C; ++c) s += p[(long long)c * SRED];
+    return s;
+  };
+  auto block_sum = [&](float v) {
+    red[j] = v;
+    __syncthreads();
+    for (int s_ = 64; s_ > 0; s_ >>= 1) {
+      if (j < s_) red[j] += red[j + s_];
+      __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+  if (task < 192) {
+    const bool l1 = task < 128;
+    const int f = l1 ? task : task - 128;
+    const int goff = l1 ? GP_G1 : GP_GC;
+    const float* Wrow = (l1 ? a.w.w1 : a.w.wc) + f * H;
+    const float* gain = l1 ? a.w.g1 : a.w.gc;
+    const int gdim = l1 ? H : HC;
+    const float bias = l1 ? a.w.b1[f] : a.w.bc[f];
+    const float wj = Wrow[j];
+    float acc_w = 0.f, acc_b = 0.f, acc_ws = 0.f, acc_b0 = 0.f, acc_w0[3] = {0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+      float v = 0.f;
+      const float* gp = a.gpart + (long long)b * C * GPART + goff + f * H + j;
+      for (int c = 0; c < C; ++c) v += gp[(long long)c * GPART];
+      const float gn = gain[b * gdim + f];
+      acc_w = fmaf(gn, v, acc_w);
+      if (j < 8) cols[j] = colsum(b, f, j);
+      const float dot = block_sum(v * wj);           // (its barriers also publish cols)
+      if (j == 0) {
+        const float dph = l1 ? cols[4] : cols[6];
+        (l1 ? a.o.dp1 : a.o.dpc)[b * gdim + f] = dph;
+        (l1 ? a.o.dg1 : a.o.dgc)[b * gdim + f] = fmaf(bias, dph, dot);
+        acc_b = fmaf(gn, dph, acc_b);
+        if (l1) {
+          // layer 0 and the sigma head ride along with feature f
+          const float dp0 = cols[0], g0 = a.w.g0[b * H + f];
+          float s0[3], dg0 = a.w.b0[f] * dp0;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { s0[c] = cols[1 + c] * a.w.box_scale; dg0 = fmaf(s0[c], a.w.w0[f * 3 + c], dg0); acc_w0[c] = fmaf(g0, s0[c], acc_w0[c]); }
+          a.o.dp0[b * H + f] = dp0;
+          a.o.dg0[b * H + f] = dg0;
+          acc_b0 = fmaf(g0, dp0, acc_b0);
+          acc_ws += cols[5];
+        }
+      }
+      __syncthreads();
+    }
+    (l1 ? a.o.dw1 : a.o.dwc)[f * H + j] = acc_w;
+    if (j == 0) {
+      (l1 ? a.o.db1 : a.o.dbc)[f] = acc_b;
+      if (l1) {
+        a.o.db0[f] = acc_b0; a.o.dws[f] = acc_ws;
+        a.o.dw0[f * 3 + 0] = acc_w0[0]; a.o.dw0[f * 3 + 1] = acc_w0[1]; a.o.dw0[f * 3 + 2] = acc_w0[2];
+      }
+    }
+  } else if (task < 224) {
+    const int ch = task - 192;
+    if (j < HC) {
+      float v = 0.f;
+      for (int b = 0; b < B; ++b) {
+        float vb = 0.f;
+        const float* gp = a.gpart + (long long)b * C * GPART + ch * HC + j;
+        for (int c = 0; c < C; ++c) vb += gp[(long long)c * GPART + GP_GF0] + gp[(long long)c * GPART + GP_GF1];
+        v += vb;
+      }
+      a.o.dwf[ch * HC + j] = v;
+    }
+    if (j == 0) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += colsum(b, ch, 7) + colsum(b, 64 + ch, 7);     // waves 0 and 2 hold the two halves
+      a.o.dbf[ch] = s;
+    }
+  } else if (j == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c) {
+        const float* p = a.sred + ((long long)b * C + c) * SRED + 1024;
+        s += (p[0] + p[1]) + (p[2] + p[3]);
+      }
+    a.o.dbs[0] = s;
+  }
+}
+
 }  // namespace
 
 // 4096-point chunks when that still fills the chip (>= 3 workgroups per CU on 256 CUs), else 2048 / 1024 / 512
@@ -1140,5 +1250,16 @@ extern "C" int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_par
     hipLaunchKernelGGL(siren_march_x3_kernel<true>, grid, dim3(512), smem, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(siren_march_x3_kernel<false>, grid, dim3(512), smem, (hipStream_t)stream, a);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_siren_bwd_x3_finalize(const cips_siren_weights* w, const float* sred, const float* gpart, int B,
+                                          int chunks, const cips_siren_grads* out, cips_stream_t stream) {
+  if (!w || !sred || !gpart || !out || B <= 0 || chunks <= 0) return (int)hipErrorInvalidValue;
+  const float* const* po = reinterpret_cast<const float* const*>(out);
+  for (int i = 0; i < 16; ++i) if (!po[i]) return (int)hipErrorInvalidValue;
+  FinArgs a;
+  a.w = *w; a.sred = sred; a.gpart = gpart; a.o = *out; a.B = B; a.chunks = chunks;
+  hipLaunchKernelGGL(siren_bwd_finalize_kernel, dim3(225), dim3(128), 0, (hipStream_t)stream, a);
   return CIPS_CHECK_LAUNCH();
 }

@@ -130,6 +130,12 @@ class FiLMLayer(nn.Module):
         return self.gain_fc(style) * 15 + 30, self.bias_fc(style)
 
 
+def _film_all(layers, styles):
+    """FiLM vectors of several layers in one grouped launch: -> [(gain, bias), ...]"""
+    ys = ops.grouped_linear([(st, m) for lay, st in zip(layers, styles) for m in (lay.gain_fc, lay.bias_fc)])
+    return [(ys[2 * i] * 15 + 30, ys[2 * i + 1]) for i in range(len(layers))]
+
+
 class NeRFNetwork(nn.Module):
     """generator.py:151-340.  forward() keeps the reference op boundary ((b,P,3) -> (b,P,33));
     the generator uses `evaluate()` which returns feat / sigma separately (no 33-wide cat)."""
@@ -168,9 +174,8 @@ class NeRFNetwork(nn.Module):
     def evaluate(self, points, style_dict):
         """points (b,P,3) -> feat (b,P,32), sigma (b,P) via the fused HIP kernel."""
         p = self.name_prefix
-        g0, p0 = self.network[0].film(style_dict[f'{p}_w0'])
-        g1, p1 = self.network[1].film(style_dict[f'{p}_w1'])
-        gc, pc = self.color_layer_sine.film(style_dict[f'{p}_rgb'])
+        (g0, p0), (g1, p1), (gc, pc) = _film_all([self.network[0], self.network[1], self.color_layer_sine],
+                                                 [style_dict[f'{p}_w0'], style_dict[f'{p}_w1'], style_dict[f'{p}_rgb']])
         return ops.SirenFunction.apply(
             points, g0, p0, g1, p1, gc, pc,
             self.network[0].linear.weight, self.network[0].linear.bias,
@@ -182,9 +187,8 @@ class NeRFNetwork(nn.Module):
     def march(self, style_dict, geom, xg, yg, zg, cam2world, jitter, noise):
         """fused rays + SIREN + composite for non-hierarchical sampling -> pixels_fea (b,n,32), depth (b,n)"""
         p = self.name_prefix
-        g0, p0 = self.network[0].film(style_dict[f'{p}_w0'])
-        g1, p1 = self.network[1].film(style_dict[f'{p}_w1'])
-        gc, pc = self.color_layer_sine.film(style_dict[f'{p}_rgb'])
+        (g0, p0), (g1, p1), (gc, pc) = _film_all([self.network[0], self.network[1], self.color_layer_sine],
+                                                 [style_dict[f'{p}_w0'], style_dict[f'{p}_w1'], style_dict[f'{p}_rgb']])
         return ops.RayMarchFunction.apply(
             geom, xg, yg, zg, cam2world, jitter, noise, g0, p0, g1, p1, gc, pc,
             self.network[0].linear.weight, self.network[0].linear.bias,
@@ -276,11 +280,12 @@ class CIPSNet(nn.Module):
             if name == img_size:
                 break
         params = []
-        for name in names:
+        # s = SinStyleMod.modulation(style) of all 18 layers (mod_conv_fc.py:474) in one grouped launch
+        mods = ops.grouped_linear([(style_dict[f'{self.network[name].name_prefix}_{j}'], m.modulation)
+                                   for name in names for j, m in enumerate((self.network[name].mod1, self.network[name].mod2))])
+        for k, name in enumerate(names):
             blk = self.network[name]
-            s1 = blk.mod1.modulation(style_dict[f'{blk.name_prefix}_0'])
-            s2 = blk.mod2.modulation(style_dict[f'{blk.name_prefix}_1'])
-            params += [blk.mod1.weight[0], s1, blk.mod2.weight[0], s2]
+            params += [blk.mod1.weight[0], mods[2 * k], blk.mod2.weight[0], mods[2 * k + 1]]
         for idx, name in enumerate(names):
             if idx >= 3:
                 params += [self.to_rgbs[name].linear.weight, self.to_rgbs[name].linear.bias]

@@ -137,6 +137,7 @@ def _split_k(P, target=8):
 
 SIREN_FWD_MODE = __import__("os").environ.get("CIPS_SIREN_FWD", "x3")   # "x3": split-bf16 chain (default, ~1e-5 rel.); "f32": exact fp32 MFMA
 SIREN_BWD_MODE = __import__("os").environ.get("CIPS_SIREN_BWD", "x3")   # "x3": fused bf16x3 backward; "staged": data pass + GEMMs
+SIREN_BWD_FINALIZE = __import__("os").environ.get("CIPS_SIREN_BWD_FINALIZE", "1") != "0"   # partials -> gradients in one launch
 
 
 class SirenFunction(torch.autograd.Function):
@@ -197,6 +198,20 @@ def _siren_backward(t, dfeat, dsigma, B, P, points=None, rays=None):
             else:
                 check(lib.cips_siren_bwd_x3_rays(C.byref(sw), C.byref(rays), _p(dfeat), _p(dsigma), _p(sred), _p(gpart), B,
                                                  _stream()), "cips_siren_bwd_x3_rays")
+            if SIREN_BWD_FINALIZE:
+                # the 16 gradient tensors from the partials in one launch (was ~40 tiny torch reductions)
+                from ._lib import SirenGrads
+                shapes = dict(dg0=(B, 128), dp0=(B, 128), dg1=(B, 128), dp1=(B, 128), dgc=(B, 64), dpc=(B, 64), dw0=(128, 3),
+                              db0=(128,), dw1=(128, 128), db1=(128,), dws=(1, 128), dbs=(1,), dwc=(64, 128), dbc=(64,),
+                              dwf=(32, 64), dbf=(32,))
+                outs = {k: torch.empty(*v, device=dev) for k, v in shapes.items()}
+                sg = SirenGrads()
+                for k, v in outs.items():
+                    setattr(sg, k, _p(v))
+                check(lib.cips_siren_bwd_x3_finalize(C.byref(sw), _p(sred), _p(gpart), B, chunks, C.byref(sg), _stream()),
+                      "cips_siren_bwd_x3_finalize")
+                return tuple(outs[k] for k in ("dg0", "dp0", "dg1", "dp1", "dgc", "dpc", "dw0", "db0", "dw1", "db1", "dws",
+                                               "dbs", "dwc", "dbc", "dwf", "dbf"))
             SR = sred.view(B, chunks, sw_).sum(1)
             T = SR[:, :1024].view(B, 4, 32, 8)                     # [wave][row][column sums], see cips3d_hip.h
             R = torch.zeros(B, 868, device=dev)                    # same row format as the staged data pass
@@ -331,6 +346,100 @@ class CompositeFunction(torch.autograd.Function):
                                      noise_std, _p(order), _p(dfea), _p(dfeat_c), _p(dsig_c), _p(dfeat_f),
                                      _p(dsig_f), R, S, clamp_mode, flags, _stream()), "cips_composite_bwd")
         return dfeat_c, dsig_c, None, dfeat_f, dsig_f, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------
+# Grouped small Linear layers (style -> per-image vectors), one launch for all of them
+# --------------------------------------------------------------------------------------
+GROUPED_LINEAR = __import__("os").environ.get("CIPS_GROUPED_LINEAR", "1") != "0"
+
+
+class GroupedLinearFunction(torch.autograd.Function):
+    """ys = [x @ W_j^T + b_j for j] for Linear layers that share their input x (B, in): the SinStyleMod.modulation
+    layers of the CIPS head (mod_conv_fc.py:433-436, 474) or the gain_fc / bias_fc of the FiLM layers
+    (film_layer.py:59-63, 88-93).  forward(x, W_0, b_0, W_1, b_1, ...) -> tuple of (B, out_j)."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        lib = _lib.load()
+        from ._lib import GlinJob
+        x = _c(x.detach())
+        ws = [_c(w.detach()) for w in wb[0::2]]
+        bs = [_c(b.detach()) if b is not None else None for b in wb[1::2]]
+        _chk(x, *ws, *[b for b in bs if b is not None])
+        B, in_dim = x.shape
+        n = len(ws)
+        if n > lib.cips_grouped_linear_max_jobs() or in_dim % 4 or in_dim > 512:
+            raise RuntimeError("grouped linear: at most 32 jobs, in_dim a multiple of 4 and <= 512")
+        jobs = (GlinJob * n)()
+        ys = []
+        for j, (w, b) in zip(jobs, zip(ws, bs)):
+            y = torch.empty(B, w.shape[0], device=x.device)
+            j.x, j.w, j.bias, j.y = _p(x), _p(w), _p(b), _p(y)
+            j.in_dim, j.out_dim = in_dim, w.shape[0]
+            ys.append(y)
+        check(lib.cips_grouped_linear_fwd(jobs, n, B, _stream()), "cips_grouped_linear_fwd")
+        ctx.save_for_backward(x, *ws)
+        ctx.has_bias = [b is not None for b in bs]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        from ._lib import GlinJob
+        x, *ws = ctx.saved_tensors
+        B, in_dim = x.shape
+        n = len(ws)
+        jobs = (GlinJob * n)()
+        dws, dbs, keep = [], [], []
+        for j, w, dy, hb in zip(jobs, ws, dys, ctx.has_bias):
+            dy = _c(dy) if dy is not None else torch.zeros(B, w.shape[0], device=x.device)
+            keep.append(dy)
+            dw = torch.empty_like(w)
+            db = torch.empty(w.shape[0], device=x.device) if hb else None
+            j.x, j.w, j.dy, j.dw, j.db = _p(x), _p(w), _p(dy), _p(dw), _p(db)
+            j.in_dim, j.out_dim = in_dim, w.shape[0]
+            dws.append(dw); dbs.append(db)
+        dx = scratch = None
+        nscr = 0
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            nscr = lib.cips_grouped_linear_scratch(jobs, n, B)
+            scratch = torch.empty(nscr, device=x.device)
+        check(lib.cips_grouped_linear_bwd(jobs, n, B, _p(dx), _p(scratch), nscr, _stream()), "cips_grouped_linear_bwd")
+        out = [dx]
+        for dw, db in zip(dws, dbs):
+            out += [dw, db]
+        return tuple(out)
+
+
+def grouped_linear(pairs):
+    """pairs: list of (x (B,in), nn.Linear) -> list of Linear(x).  Layers whose inputs are the SAME tensor go into one
+    grouped launch (the reference's style dicts alias one tensor per mapping network, multi_head_mapping.py:147-153);
+    anything else (truncated / mixed styles) falls back to one launch per distinct input."""
+    out = [None] * len(pairs)
+    if not GROUPED_LINEAR:
+        return [lin(x) for x, lin in pairs]
+    groups = {}
+    for idx, (x, lin) in enumerate(pairs):
+        groups.setdefault(id(x), []).append(idx)
+    mx = 32
+    for idxs in groups.values():
+        x = pairs[idxs[0]][0]
+        if x.dim() != 2 or x.shape[1] % 4 or x.shape[1] > 512 or not x.is_cuda:
+            for i in idxs:
+                out[i] = pairs[i][1](pairs[i][0])
+            continue
+        for c0 in range(0, len(idxs), mx):
+            chunk = idxs[c0:c0 + mx]
+            args = []
+            for i in chunk:
+                lin = pairs[i][1]
+                args += [lin.weight, lin.bias]
+            ys = GroupedLinearFunction.apply(x, *args)
+            for i, y in zip(chunk, ys):
+                out[i] = y
+    return out
 
 
 # --------------------------------------------------------------------------------------

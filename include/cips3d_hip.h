@@ -123,6 +123,16 @@ int cips_siren_bwd_x3_prof(unsigned long long* host_out);
 int cips_siren_bwd_x3(const cips_siren_weights* w, const float* points, const float* dfeat,
                       const float* dsigma, float* sred, float* gpart, int B, int P, cips_stream_t stream);
 
+/* The 16 gradient tensors of the SIREN from the fused backward's per-workgroup partials, in one launch (chain rule of
+ * exp/comm/models/film_layer.py:88-107): per-image FiLM gradients dg* / dp* (B,128 | B,64) and the batch-summed weight /
+ * bias gradients in the parameters' own shapes. */
+typedef struct cips_siren_grads {
+  float *dg0, *dp0, *dg1, *dp1, *dgc, *dpc;          /* (B,128) x4, (B,64) x2 */
+  float *dw0, *db0, *dw1, *db1, *dws, *dbs, *dwc, *dbc, *dwf, *dbf;   /* (128,3) (128) (128,128) (128) (1,128) (1) (64,128) (64) (32,64) (32) */
+} cips_siren_grads;
+int cips_siren_bwd_x3_finalize(const cips_siren_weights* w, const float* sred, const float* gpart, int B, int chunks,
+                               const cips_siren_grads* out, cips_stream_t stream);
+
 /* Ray parameters for in-kernel point generation (what cips_rays_fwd materialises): the sample point of
  * (image b, ray r, sample s) is recomputed from the linspace grids, the camera matrix and the jitter draw, 4 B per
  * point read instead of 12 B and no (B, n, S, 3) tensor in HBM.  Point index p = r * S + s. */
