@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--num-steps", type=int, default=None, help="coarse samples per ray")
     ap.add_argument("--hier", action="store_true", help="hierarchical sampling (S coarse + S fine)")
+    ap.add_argument("--freeze", action="store_true", help="GeneratorNerfINR_freeze_NeRF (the r256 stages: gradients for the INR head only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
@@ -216,7 +217,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    from cips3d_amd.generator import GeneratorNerfINR
+    from cips3d_amd.generator import GeneratorNerfINR, GeneratorNerfINR_freeze_NeRF
     from cips3d_amd.distributed import GradAllReducer
     from cips3d_amd import ops
     if a.inr_mode:
@@ -225,7 +226,7 @@ def main():
 
     S = a.num_steps if a.num_steps is not None else (12 if a.hier else 24)
     torch.manual_seed(1234)                       # identical initial weights on every rank
-    G = GeneratorNerfINR(**G_CFG, device=dev).to(dev)
+    G = (GeneratorNerfINR_freeze_NeRF if a.freeze else GeneratorNerfINR)(**G_CFG, device=dev).to(dev)
     G.device = dev
     torch.manual_seed(1234 + rank)                # per-rank latents / cameras (train.py:221)
     b, img = a.batch, a.img_size
@@ -318,7 +319,7 @@ def main():
         "dtype": "f32" if mode == "f32" else "f32 (dense layers as 3-pass split-bf16 MFMA with fp32 accumulate, ~1e-5 rel.; everything else fp32)",
         "data": "synthetic",
         "config": {"workload": f"FFHQ r{img}, {E} SIREN evals/ray (num_steps {S}, hierarchical {a.hier}), "
-                               f"batch {b}/GPU, G fwd+bwd, all 9 CIPS blocks",
+                               f"batch {b}/GPU, G fwd+bwd, all 9 CIPS blocks" + (", NeRF frozen" if a.freeze else ""),
                    "global_batch": world * b, "parallelism": f"dp{world}", "rccl_ranks": world if backend == "nccl" else 0,
                    "inr_gemm_mode": mode,
                    "launch": "hipGraph replay" if use_graph[0] else "eager"},

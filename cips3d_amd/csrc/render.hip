@@ -69,6 +69,7 @@ __device__ __forceinline__ float clamp_density_grad(float x, int mode) {
 // ------------------------------------------------------------------------------------
 struct ResampleArgs {
   const float *sigma, *z, *noise, *u, *origins, *dirs;
+  const float* cdf_in;      // optional (R, S-1): use this cdf instead of the one computed here (bookkeeping contract test)
   float noise_std;
   float *fine_z, *fine_pts, *weights_out, *cdf_out;
   long long* inds_out;
@@ -119,6 +120,8 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
       cdf[k + 1] = (float)acc;
     }
     for (int j = 0; j < S - 1; ++j) bins[j] = 0.5f * (zs[j] + zs[j + 1]);
+    if (a.cdf_in)
+      for (int j = 0; j < S - 1; ++j) cdf[j] = a.cdf_in[ray * (S - 1) + j];
   }
   __syncthreads();
   const int b = (int)(ray / a.n);
@@ -380,9 +383,10 @@ extern "C" int cips_rays_fwd(const float* xg, const float* yg, const float* zg, 
 extern "C" int cips_resample_fwd(const float* sigma, const float* z, const float* noise, float noise_std,
                                  const float* u, const float* origins, const float* dirs, float* fine_z,
                                  float* fine_pts, float* weights_out, float* cdf_out, long long* inds_out,
-                                 int B, int n, int S, int clamp_mode, cips_stream_t stream) {
+                                 int B, int n, int S, int clamp_mode, const float* cdf_in, cips_stream_t stream) {
   if (B <= 0 || n <= 0 || S < 3) return (int)hipErrorInvalidValue;
   ResampleArgs a;
+  a.cdf_in = cdf_in;
   a.sigma = sigma; a.z = z; a.noise = noise; a.noise_std = noise_std; a.u = u; a.origins = origins;
   a.dirs = dirs; a.fine_z = fine_z; a.fine_pts = fine_pts; a.weights_out = weights_out;
   a.cdf_out = cdf_out; a.inds_out = inds_out; a.B = B; a.n = n; a.S = S; a.clamp_mode = clamp_mode;

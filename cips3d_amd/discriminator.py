@@ -266,26 +266,73 @@ def _nhwc(t):
     return p
 
 
-def _w_planes(w):
-    """(O, C, kh, kw) -> Planes (O, kh*kw*C): contraction index (tap, channel)"""
+# Operand planes of a convolution WEIGHT are a function of the parameter alone, but every conv call of a step needs
+# them: three discriminator forwards, the backward and the R1 double-backward re-derive the same planes (412
+# split_planes launches per GAN step).  They are cached per nn.Parameter and invalidated by the tensor's version
+# counter (bumped by every in-place update: torch.optim, load_state_dict, and cips3d_amd.optim.FusedClipAdamEMA, which
+# writes through raw pointers and therefore bumps it explicitly).  Transient weights (the double-backward's `ggw`) are
+# never cached.  CIPS_D_WCACHE=0 disables the cache.
+_WCACHE_ON = _os.environ.get("CIPS_D_WCACHE", "1") != "0"
+
+
+def _cached(w, scale, kind, build):
+    """build(w_eff) -> operand for `kind`, memoised on (parameter, version, scale)"""
+    if not (_WCACHE_ON and isinstance(w, nn.Parameter)):
+        return build(w if scale == 1.0 else w * scale)
+    ent = w.__dict__.setdefault("_cips_planes", {})        # lives and dies with the Parameter object
+    key = (kind, float(scale))
+    hit = ent.get(key)
+    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+        return hit[2]
+    with torch.no_grad():
+        val = build(w.detach() if scale == 1.0 else w.detach() * scale)
+    ent[key] = (w._version, w.data_ptr(), val)
+    return val
+
+
+def _w_planes_raw(w):
     O, C, kh, kw = w.shape
     P, _ = ops.split_planes(w.permute(0, 2, 3, 1).reshape(1, O, kh * kw * C).contiguous(), want_p=True, want_t=False)
     return P
 
 
-def _conv_fwd(x, w, stride, pad):
+def _w_planes(w, scale=1.0):
+    """(O, C, kh, kw) -> Planes (O, kh*kw*C) of w * scale: contraction index (tap, channel)"""
+    return _cached(w, scale, "fwd", _w_planes_raw)
+
+
+def _w_planes_flipT(w, scale=1.0):
+    """planes of the data-gradient filter bank: flipped taps, channel roles swapped, (C, kh*kw*O)"""
+    return _cached(w, scale, "flipT", lambda we: _w_planes_raw(we.flip(2, 3).transpose(0, 1)))
+
+
+def _w_rows(w, scale, want_t):
+    """(O, K) matrix of w * scale as planes (1, O, K) (want_t False) or transposed (1, K, O)"""
+    def build(we):
+        O = we.shape[0]
+        P, T = ops.split_planes(we.reshape(1, O, -1).contiguous(), want_p=not want_t, want_t=want_t)
+        return T if want_t else P
+    return _cached(w, scale, "rowsT" if want_t else "rows", build)
+
+
+def _scaled(w, scale):
+    return w if scale == 1.0 else w * scale
+
+
+def _conv_fwd(x, w, stride, pad, scale=1.0):
+    """y = conv(x, w * scale); `w` may be the nn.Parameter itself (its operand planes are cached, see _cached)"""
     B, C, H, W = x.shape
     O, _, kh, kw = w.shape
     x = x.contiguous()
     Ho_, Wo_ = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     if _RGB_STREAM and kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
-        return ops.conv1x1_smallk(x, w.reshape(O, C).contiguous())      # RGB input convs: streaming, no GEMM
+        return ops.conv1x1_smallk(x, _scaled(w, scale).reshape(O, C).contiguous())      # RGB input convs: streaming, no GEMM
     if _implicit_ok(C, Ho_ * Wo_, O):
-        return ops.conv2d_x3(_w_planes(w), _nhwc(x), B, C, H, W, O, kh, kw, stride, pad)
+        return ops.conv2d_x3(_w_planes(w, scale), _nhwc(x), B, C, H, W, O, kh, kw, stride, pad)
     if _fold_ok(C * kh * kw, Ho_ * Wo_, B, O):
         K, N = C * kh * kw, Ho_ * Wo_
         colP, _, _ = _folded_col_planes(x, kh, kw, stride, pad)
-        _, wT = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=False, want_t=True)   # (1, K, O)
+        wT = _w_rows(w, scale, True)                                                           # (1, K, O)
         nch = _split_count(((O + 255) // 256) * ((B * N + 127) // 128), K)
         kc = K // nch
         y2 = torch.empty(nch, O, B * N, device=x.device)
@@ -295,7 +342,7 @@ def _conv_fwd(x, w, stride, pad):
     if _x3_ok(C * kh * kw, Ho_ * Wo_, O):
         K, N = C * kh * kw, Ho_ * Wo_
         colP, _, _ = ops.im2col_x3(x, kh, kw, stride, pad)               # planes (B, K, N): k-major B operand
-        _, wT = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=False, want_t=True)   # (1, K, O): k-major A operand
+        wT = _w_rows(w, scale, True)                                     # (1, K, O): k-major A operand
         y = torch.empty(B, O, Ho_, Wo_, device=x.device)
         ops.gemm_x3_km(wT, colP, O, N, K, O, N, B, 0, K * N, y)          # y[b] (O,N) = W (O,K) @ col[b] (K,N)
         return y
@@ -303,7 +350,7 @@ def _conv_fwd(x, w, stride, pad):
     K, N = C * kh * kw, Ho * Wo
     if N % 4:
         raise NotImplementedError("conv output plane must have a multiple of 4 pixels")
-    wm = w.reshape(O, K)
+    wm = _scaled(w, scale).reshape(O, K)
     Kp = _pad4(K)
     if Kp != K:   # RGB input (C_in = 3, 1x1): pad the contraction dim to the GEMM's 16-byte vector granule
         wm = F.pad(wm, (0, Kp - K))
@@ -314,30 +361,29 @@ def _conv_fwd(x, w, stride, pad):
     return y
 
 
-def _conv_bwd_data(dy, w, in_shape, stride, pad):
+def _conv_bwd_data(dy, w, in_shape, stride, pad, scale=1.0):
     B, C, H, W = in_shape
     O, _, kh, kw = w.shape
     dy = dy.contiguous()
     Ho, Wo = dy.shape[2], dy.shape[3]
     K, N = C * kh * kw, Ho * Wo
     if _RGB_STREAM and kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
-        return ops.conv1x1_smallk_bwd_data(dy, w.reshape(O, C).contiguous(), C)
+        return ops.conv1x1_smallk_bwd_data(dy, _scaled(w, scale).reshape(O, C).contiguous(), C)
     if stride == 1 and _implicit_ok(O, H * W, C) and Ho + kh - 1 - 2 * pad == H and kh - 1 - pad >= 0:
         # dx = conv(dy, flipped weights with the channel roles swapped), padding kh-1-pad
-        wf = w.flip(2, 3).transpose(0, 1)                                   # (C, O, kh, kw)
-        return ops.conv2d_x3(_w_planes(wf), _nhwc(dy), B, O, Ho, Wo, C, kh, kw, 1, kh - 1 - pad)
+        return ops.conv2d_x3(_w_planes_flipT(w, scale), _nhwc(dy), B, O, Ho, Wo, C, kh, kw, 1, kh - 1 - pad)
     if _fold_ok(K, N, B, O):
-        wP, _ = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=True, want_t=False)    # (1, O, K)
+        wP = _w_rows(w, scale, False)                                                            # (1, O, K)
         dcol2 = torch.empty(K, B * N, device=dy.device)
         ops.gemm_x3_km(wP, _folded_rows_planes(dy), K, B * N, O, K, B * N, 1, 0, 0, dcol2)       # dcol (K, B*N) = W^T dy
         return ops.col2im(dcol2.view(K, B, N).permute(1, 0, 2).contiguous(), B, C, H, W, kh, kw, stride, pad)
     if _x3_ok(K, N, O):
-        wP, _ = ops.split_planes(w.reshape(1, O, K).contiguous(), want_p=True, want_t=False)    # (1, O, K): contraction index o = rows
+        wP = _w_rows(w, scale, False)                                    # (1, O, K): contraction index o = rows
         dyP, _ = ops.split_planes(dy.view(B, O, N), want_p=True, want_t=False)
         dcol = torch.empty(B, K, N, device=dy.device)
         ops.gemm_x3_km(wP, dyP, K, N, O, K, N, B, 0, O * N, dcol)        # dcol[b] (K,N) = W^T (K,O) @ dy[b] (O,N)
         return ops.col2im(dcol, B, C, H, W, kh, kw, stride, pad)
-    wm = w.reshape(O, K)
+    wm = _scaled(w, scale).reshape(O, K)
     Kp = _pad4(K)
     if Kp != K:
         wm = F.pad(wm, (0, Kp - K))
@@ -379,47 +425,58 @@ def _conv_bwd_weight(dy, x, w_shape, stride, pad):
 
 
 class Conv2dFunction(Function):
+    """y = conv(x, w * scale).  `scale` is EqualConv2d's constant 1/sqrt(C k^2) (discriminator.py:33, 44): keeping it
+    out of the tensor lets the parameter itself arrive here, so that its operand planes can be cached (_cached)."""
+
     @staticmethod
-    def forward(ctx, x, w, stride, pad):
+    def forward(ctx, x, w, stride, pad, scale=1.0):
         ctx.save_for_backward(x, w)
-        ctx.stride, ctx.pad = stride, pad
+        ctx.stride, ctx.pad, ctx.scale = stride, pad, scale
+        ctx.w_obj = w if isinstance(w, nn.Parameter) else None       # the Parameter object: the cache key
         with _share_planes():
-            y = _conv_fwd(x, w, stride, pad)
+            y = _conv_fwd(x, w, stride, pad, scale)
             ctx.xP = _shared.get((x.data_ptr(), tuple(x.shape))) if ctx.needs_input_grad[1] else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
+        w = ctx.w_obj if ctx.w_obj is not None else w
         dx = dw = None
         dy = dy.contiguous()
         with _share_planes((x, ctx.xP)):
             if ctx.needs_input_grad[0]:
-                dx = Conv2dBwdDataFunction.apply(dy, w, x.shape, ctx.stride, ctx.pad)
+                dx = Conv2dBwdDataFunction.apply(dy, w, x.shape, ctx.stride, ctx.pad, ctx.scale)
             if ctx.needs_input_grad[1]:
                 dw = Conv2dBwdWeightFunction.apply(dy, x, w.shape, ctx.stride, ctx.pad)
+                if ctx.scale != 1.0:
+                    dw = dw * ctx.scale
         ctx.xP = None
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class Conv2dBwdDataFunction(Function):
     @staticmethod
-    def forward(ctx, dy, w, in_shape, stride, pad):
+    def forward(ctx, dy, w, in_shape, stride, pad, scale=1.0):
         ctx.save_for_backward(dy, w)
-        ctx.in_shape, ctx.stride, ctx.pad = in_shape, stride, pad
-        return _conv_bwd_data(dy, w, in_shape, stride, pad)
+        ctx.in_shape, ctx.stride, ctx.pad, ctx.scale = in_shape, stride, pad, scale
+        ctx.w_obj = w if isinstance(w, nn.Parameter) else None
+        return _conv_bwd_data(dy, w, in_shape, stride, pad, scale)
 
     @staticmethod
     def backward(ctx, ggx):
         dy, w = ctx.saved_tensors
+        w = ctx.w_obj if ctx.w_obj is not None else w
         g_dy = g_w = None
         ggx = ggx.contiguous()
         with _share_planes():
             if ctx.needs_input_grad[0]:
-                g_dy = Conv2dFunction.apply(ggx, w, ctx.stride, ctx.pad)
+                g_dy = Conv2dFunction.apply(ggx, w, ctx.stride, ctx.pad, ctx.scale)
             if ctx.needs_input_grad[1]:
                 g_w = Conv2dBwdWeightFunction.apply(dy, ggx, w.shape, ctx.stride, ctx.pad)
-        return g_dy, g_w, None, None, None
+                if ctx.scale != 1.0:
+                    g_w = g_w * ctx.scale
+        return g_dy, g_w, None, None, None, None
 
 
 class Conv2dBwdWeightFunction(Function):
@@ -440,8 +497,9 @@ class Conv2dBwdWeightFunction(Function):
         return g_dy, g_x, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, padding=0):
-    y = Conv2dFunction.apply(x, w, stride, padding)
+def conv2d(x, w, bias=None, stride=1, padding=0, scale=1.0):
+    """conv2d(x, w * scale) + bias; pass the raw nn.Parameter and its constant scale to get the plane cache"""
+    y = Conv2dFunction.apply(x, w, stride, padding, scale)
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
     return y
@@ -461,7 +519,7 @@ class EqualConv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
     def forward(self, input):
-        return conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
+        return conv2d(input, self.weight, bias=self.bias, stride=self.stride, padding=self.padding, scale=self.scale)
 
 
 def make_kernel(k):

@@ -277,7 +277,7 @@ def _siren_backward(t, dfeat, dsigma, B, P, points=None, rays=None):
 # --------------------------------------------------------------------------------------
 # H3 resample / composite
 # --------------------------------------------------------------------------------------
-def resample_fwd(sigma, z, noise, noise_std, u, origins, dirs, B, n, S, clamp_mode=0, debug=False):
+def resample_fwd(sigma, z, noise, noise_std, u, origins, dirs, B, n, S, clamp_mode=0, debug=False, cdf_in=None):
     """sigma/z/noise/u (B*n,S) -> fine_z (B*n,S), fine_pts (B*n,S,3) [+ weights, cdf, inds]."""
     lib = _lib.load()
     dev = sigma.device
@@ -293,7 +293,7 @@ def resample_fwd(sigma, z, noise, noise_std, u, origins, dirs, B, n, S, clamp_mo
         inds = torch.empty(R, S, device=dev, dtype=torch.int64)
     check(lib.cips_resample_fwd(_p(sigma), _p(z), _p(noise), float(noise_std), _p(u), _p(origins), _p(dirs),
                                 _p(fine_z), _p(fine_pts), _p(w), _p(cdf), _p(inds), B, n, S, clamp_mode,
-                                _stream()), "cips_resample_fwd")
+                                _p(_c(cdf_in)) if cdf_in is not None else None, _stream()), "cips_resample_fwd")
     if debug:
         return fine_z, fine_pts, w, cdf, inds
     return fine_z, fine_pts

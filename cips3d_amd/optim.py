@@ -114,6 +114,13 @@ class FusedClipAdamEMA:
                                 C.c_void_p(self._partial.data_ptr()), C.c_void_p(self._norm.data_ptr()),
                                 self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
                                 self.ema_decay, 1, C.c_void_p(self._steps_dev.data_ptr()), st), "cips_opt_step")
+        # the kernel wrote the parameters (and the EMA copies) through raw pointers: tell autograd, so that anything
+        # derived from a parameter and memoised on its version (the discriminator's weight planes) is rebuilt
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)
+        if do_ema:
+            for e in self.ema:
+                torch.autograd.graph.increment_version(e)
         return self._norm
 
     def state_dict(self):

@@ -173,12 +173,15 @@ int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_params* rays, 
  * u (R,S) uniforms, origins (B,3), dirs (R,3) with R = B*n rays.
  * out: fine_z (R,S), fine_pts (R,S,3); optional debug outs (may be NULL):
  * weights (R,S), cdf (R,S-1), inds (R,S) int64 (searchsorted result).
- * clamp_mode: 0 = relu, 1 = softplus. */
+ * clamp_mode: 0 = relu, 1 = softplus.
+ * cdf_in (optional, (R,S-1)): take the cdf from the caller instead of computing it — the "bit-exact integer bookkeeping
+ * on identical float inputs" contract: with the reference's cdf and u the indices must equal
+ * torch.searchsorted's exactly. */
 int cips_resample_fwd(const float* sigma, const float* z, const float* noise, float noise_std,
                       const float* u, const float* origins, const float* dirs,
                       float* fine_z, float* fine_pts,
                       float* weights_out, float* cdf_out, long long* inds_out,
-                      int B, int n, int S, int clamp_mode, cips_stream_t stream);
+                      int B, int n, int S, int clamp_mode, const float* cdf_in, cips_stream_t stream);
 
 /* Merge (coarse + fine, ascending z) and alpha-composite.
  * replaces exp/cips3d/models/generator.py:1733-1752 (cat/sort/gather) and

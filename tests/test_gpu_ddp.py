@@ -101,7 +101,7 @@ def test_ddp_wrapped_generator_and_discriminator_train_steps():
     res = {}
     try:
         for _ in range(world):
-            r, dg, gg = q.get(timeout=600)
+            r, dg, gg = q.get(timeout=180)
             res[r] = (dg, gg)
         for p in procs:
             p.join(timeout=120)

@@ -284,8 +284,18 @@ def test_resample_matches_oracle_bookkeeping(noise_std, clamp):
         u.to(d), orig[:, 0].contiguous().to(d), dirs.view(b * n, 3).to(d), b, n, S, ops._CLAMP[clamp], debug=True)
     assert max_rel(w_d, book["weights"].view(b * n, S)) < 1e-5
     assert max_rel(cdf_d, book["cdf"]) < 1e-5
+    # (1) the bookkeeping contract: on IDENTICAL float inputs — the oracle's cdf and u — the integer
+    #     indices are bit-exact, and with them below / above, hence the gathered bins and the samples
+    cdf_o = book["cdf"].to(d)
+    fz_x, fp_x, _, cdf_x, inds_x = ops.resample_fwd(
+        coarse[..., 32].reshape(b * n, S).to(d), z.view(b * n, S).to(d), noise.view(b * n, S).to(d), noise_std,
+        u.to(d), orig[:, 0].contiguous().to(d), dirs.view(b * n, 3).to(d), b, n, S, ops._CLAMP[clamp], debug=True, cdf_in=cdf_o)
+    assert torch.equal(cdf_x.cpu(), book["cdf"])
+    assert torch.equal(inds_x.cpu(), book["inds"]), "searchsorted indices differ on identical float inputs"
+    assert max_rel(fz_x.cpu(), fz.view(b * n, S)) < 1e-6
+    # (2) end to end (the kernel's own weights -> cdf, ulp-level differences in exp / scan order): mismatch rate reported
     mism = (inds_d.cpu() != book["inds"]).float().mean().item()
-    print(f"searchsorted index mismatch rate (own cdf) = {mism:.2e}")
+    print(f"searchsorted indices: 0 mismatches on the oracle's cdf; end-to-end (own cdf) mismatch rate = {mism:.2e}")
     assert mism < 1e-3
     good = (inds_d.cpu() == book["inds"])
     assert max_rel(fz_d.cpu()[good], fz.view(b * n, S)[good]) < 1e-4
@@ -797,6 +807,8 @@ def test_grouped_linear_forward_backward(B, in_dim, outs):
     ref = [torch.nn.functional.linear(xr, l.weight.double(), None if l.bias is None else l.bias.double()) for l in lins]
     used = [j for j in range(len(outs)) if not (len(outs) > 2 and j == len(outs) - 1)]      # the last output stays unused
     sum((ref[j] * ups[j].double()).sum() for j in used).backward()
+    for l in lins:
+        l.zero_grad(set_to_none=True)       # the fp64 reference above left gradients on the parameters
     xd = x.to(d).requires_grad_(True)
     lins_d = [l.to(d) for l in lins]
     ys = ops.grouped_linear([(xd, l) for l in lins_d])
@@ -805,8 +817,6 @@ def test_grouped_linear_forward_backward(B, in_dim, outs):
     sum((ys[j] * ups[j].to(d)).sum() for j in used).backward()
     torch.cuda.synchronize()
     assert rel_err(xd.grad, xr.grad) < 1e-6
-    for j, l in enumerate(lins_d):
-        wref = torch.autograd.grad((ref[j] * ups[j].double()).sum(), xr, allow_unused=True) if False else None
     xr2 = x.double()
     for j, l in enumerate(lins_d):
         if j in used:
@@ -814,4 +824,4 @@ def test_grouped_linear_forward_backward(B, in_dim, outs):
             if l.bias is not None:
                 assert rel_err(l.bias.grad, ups[j].double().sum(0)) < 1e-6, j
         else:
-            assert float(l.weight.grad.abs().max()) == 0.0
+            assert l.weight.grad is None or float(l.weight.grad.abs().max()) == 0.0
