@@ -28,8 +28,8 @@ class SirenGrads(C.Structure):
 
 
 class RayParams(C.Structure):
-    _fields_ = [("xg", vp), ("yg", vp), ("zg", vp), ("cam2world", vp), ("jitter", vp), ("zc", f32), ("H", i32), ("W", i32),
-                ("S", i32)]
+    _fields_ = [("xg", vp), ("yg", vp), ("zg", vp), ("cam2world", vp), ("jitter", vp), ("zvals", vp), ("zc", f32), ("H", i32),
+                ("W", i32), ("S", i32)]
 
 
 class GlinJob(C.Structure):
@@ -101,11 +101,12 @@ SIGNATURES = {
     "cips_siren_bwd_x3_sred": (i32, []),
     "cips_siren_bwd_x3_prof": (i32, [vp]),
     "cips_siren_bwd_x3": (i32, [C.POINTER(SirenWeights), vp, vp, vp, vp, vp, i32, i32, vp]),
+    "cips_siren_fwd_x3_rays": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, vp, vp, i32, vp]),
     "cips_siren_bwd_x3_rays": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, vp, vp, vp, i32, vp]),
     "cips_siren_bwd_x3_finalize": (i32, [C.POINTER(SirenWeights), vp, vp, i32, i32, C.POINTER(SirenGrads), vp]),
     "cips_march_fwd_x3": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, f32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "cips_siren_bwd_data": (i32, [C.POINTER(SirenWeights)] + [vp] * 14 + [i32, i32, vp]),
-    "cips_resample_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "cips_resample_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, C.POINTER(RayParams), vp]),
     "cips_composite_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_composite_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_gemm_f32": (i32, [C.POINTER(GemmDesc), vp]),

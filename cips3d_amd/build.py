@@ -25,7 +25,7 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
     objdir = os.path.join(HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "siren_fwd_chain.inc"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "siren_fwd_chain.inc"), os.path.join(CSRC, "raygen.h"),
                os.path.join(HERE, "..", "include", "cips3d_hip.h")]
     objs = []
     procs = []

@@ -5,6 +5,7 @@
 // feature channels of one sample with one float4 each, i.e. one full 128 B line per sample).
 #include "common.h"
 #include "../../include/cips3d_hip.h"
+#include "raygen.h"
 
 namespace {
 
@@ -70,6 +71,8 @@ __device__ __forceinline__ float clamp_density_grad(float x, int mode) {
 struct ResampleArgs {
   const float *sigma, *z, *noise, *u, *origins, *dirs;
   const float* cdf_in;      // optional (R, S-1): use this cdf instead of the one computed here (bookkeeping contract test)
+  RayGen rg;                // dirs == NULL: ray directions and origins come from the ray parameters
+  int have_rg;
   float noise_std;
   float *fine_z, *fine_pts, *weights_out, *cdf_out;
   long long* inds_out;
@@ -125,8 +128,18 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
   }
   __syncthreads();
   const int b = (int)(ray / a.n);
-  const float ox = a.origins[b * 3 + 0], oy = a.origins[b * 3 + 1], oz = a.origins[b * 3 + 2];
-  const float dx = a.dirs[ray * 3 + 0], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
+  float ox, oy, oz, dx, dy, dz;
+  if (a.have_rg) {          // same expressions as rays_kernel (directions) / the camera matrix' translation column
+    const float* M = a.rg.c2w + (long long)b * 16;
+    const RayDir d = ray_dir(a.rg, (int)(ray - (long long)b * a.n));
+    dx = (M[0] * d.dx + M[1] * d.dy) + M[2] * d.dz;
+    dy = (M[4] * d.dx + M[5] * d.dy) + M[6] * d.dz;
+    dz = (M[8] * d.dx + M[9] * d.dy) + M[10] * d.dz;
+    ox = M[3]; oy = M[7]; oz = M[11];
+  } else {
+    ox = a.origins[b * 3 + 0]; oy = a.origins[b * 3 + 1]; oz = a.origins[b * 3 + 2];
+    dx = a.dirs[ray * 3 + 0]; dy = a.dirs[ray * 3 + 1]; dz = a.dirs[ray * 3 + 2];
+  }
   for (int i = sub; i < S; i += SEG) {
     const float u = a.u[ray * S + i];
     int ind = 0;
@@ -140,8 +153,10 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
     const float smp = b0 + (u - c0) / denom * (b1 - b0);
     if (!active) continue;
     a.fine_z[ray * S + i] = smp;
-    float* fp = a.fine_pts + (ray * S + i) * 3;
-    fp[0] = ox + dx * smp; fp[1] = oy + dy * smp; fp[2] = oz + dz * smp;
+    if (a.fine_pts) {
+      float* fp = a.fine_pts + (ray * S + i) * 3;
+      fp[0] = ox + dx * smp; fp[1] = oy + dy * smp; fp[2] = oz + dz * smp;
+    }
     if (a.inds_out) a.inds_out[ray * S + i] = ind;
     if (a.weights_out) a.weights_out[ray * S + i] = ws[i];
   }
@@ -383,10 +398,13 @@ extern "C" int cips_rays_fwd(const float* xg, const float* yg, const float* zg, 
 extern "C" int cips_resample_fwd(const float* sigma, const float* z, const float* noise, float noise_std,
                                  const float* u, const float* origins, const float* dirs, float* fine_z,
                                  float* fine_pts, float* weights_out, float* cdf_out, long long* inds_out,
-                                 int B, int n, int S, int clamp_mode, const float* cdf_in, cips_stream_t stream) {
-  if (B <= 0 || n <= 0 || S < 3) return (int)hipErrorInvalidValue;
+                                 int B, int n, int S, int clamp_mode, const float* cdf_in, const cips_ray_params* rays,
+                                 cips_stream_t stream) {
+  if (B <= 0 || n <= 0 || S < 3 || !fine_z || (!rays && (!origins || !dirs || !fine_pts))) return (int)hipErrorInvalidValue;
   ResampleArgs a;
   a.cdf_in = cdf_in;
+  a.rg = RayGen{}; a.have_rg = 0;
+  if (rays) { const int rc = fill_raygen(a.rg, rays); if (rc) return rc; if (a.rg.n != n) return (int)hipErrorInvalidValue; a.have_rg = 1; }
   a.sigma = sigma; a.z = z; a.noise = noise; a.noise_std = noise_std; a.u = u; a.origins = origins;
   a.dirs = dirs; a.fine_z = fine_z; a.fine_pts = fine_pts; a.weights_out = weights_out;
   a.cdf_out = cdf_out; a.inds_out = inds_out; a.B = B; a.n = n; a.S = S; a.clamp_mode = clamp_mode;

@@ -34,6 +34,7 @@
 // 32 consecutive rows at one column and (b) the transpose read's 4 rows x 64 B both cover all 64 banks.
 #include "common.h"
 #include "../../include/cips3d_hip.h"
+#include "raygen.h"
 #include <cstdlib>
 
 namespace {
@@ -297,50 +298,6 @@ __device__ __forceinline__ f32x16 x2f(f32x16 acc, const Frag& a, const Frag& b) 
   return acc;
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// In-kernel ray set-up (what rays_kernel of render.hip materialises; exp/comm/comm_utils.py:365-438, 584-679): the
-// sample point of (image b, ray, sample s) from the three linspace grids, the camera matrix and the jitter draw — 4 B
-// per point read instead of 12 B, and no (B, n, S, 3) tensor in HBM.  Same expressions, in the same order, as
-// rays_kernel.
-struct RayGen {
-  const float *xg, *yg, *zg;   // torch.linspace grids (W), (H), (S)
-  const float* c2w;            // (B, 4, 4)
-  const float* jitter;         // (B, n, S) uniforms or NULL
-  float zc;
-  int W, n, S;
-};
-struct RayDir { float dx, dy, dz; };
-__device__ __forceinline__ RayDir ray_dir(const RayGen& g, int ray) {
-  const int row = ray / g.W, col = ray - row * g.W;
-  const float x = g.xg[col], y = g.yg[row];
-  const float nrm = sqrtf(x * x + y * y + g.zc * g.zc);
-  RayDir d = {x / nrm, y / nrm, g.zc / nrm};
-  return d;
-}
-// camera-space sample at depth grid value z0 with jitter draw u (raw uniform; ignored when has_jit is false) -> world
-// point and the jittered depth
-__device__ __forceinline__ void ray_point(const RayGen& g, const float* M, const RayDir& d, float z0, float u, bool has_jit,
-                                          float& wx, float& wy, float& wz, float& zout) {
-  float z = z0;
-  float px = d.dx * z, py = d.dy * z, pz = d.dz * z;
-  if (has_jit) {
-    const float off = (u - 0.5f) * (g.zg[1] - g.zg[0]);
-    z = z + off;
-    px = px + off * d.dx; py = py + off * d.dy; pz = pz + off * d.dz;
-  }
-  wx = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3];
-  wy = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7];
-  wz = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11];
-  zout = z;
-}
-// point-major index p = ray * S + s of image b -> world point
-__device__ __forceinline__ void gen_point(const RayGen& g, int b, int p, float& wx, float& wy, float& wz) {
-  const int ray = p / g.S, s = p - ray * g.S;
-  const RayDir d = ray_dir(g, ray);
-  const float u = g.jitter ? g.jitter[(long long)b * g.n * g.S + p] : 0.f;
-  float z;
-  ray_point(g, g.c2w + (long long)b * 16, d, g.zg[s], u, g.jitter != nullptr, wx, wy, wz, z);
-}
 
 struct BwdX3Args {
   cips_siren_weights w;
@@ -832,9 +789,11 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_x3_kernel(BwdX3Args a) {
 // dot with one cross-half add.  No weight-gradient accumulators, so eight waves (two per SIMD) share the LDS images.
 struct FwdX3Args {
   cips_siren_weights w;
-  const float* points;
+  const float* points;     // (B, P, 3) or NULL: generated from rg (point index = ray * S + s)
   float* feat;
   float* sigma;
+  float* zout;             // optional (B, P): the depth of every generated point
+  RayGen rg;
   int B, P, chunk;
 };
 
@@ -858,7 +817,9 @@ __global__ __launch_bounds__(512) void siren_fwd_x3_kernel(FwdX3Args a) {
     const int p = pbase + l31;
     const bool valid = p < cend;
     const long long gp = (long long)b * a.P + (valid ? p : cend - 1);
-    const float px = a.points[gp * 3 + 0], py = a.points[gp * 3 + 1], pz = a.points[gp * 3 + 2];
+    float px, py, pz, zpt = 0.f;
+    if (a.points) { px = a.points[gp * 3 + 0]; py = a.points[gp * 3 + 1]; pz = a.points[gp * 3 + 2]; }
+    else gen_point(a.rg, b, valid ? p : cend - 1, px, py, pz, zpt);
 
 #include "siren_fwd_chain.inc"
     if (valid) {
@@ -873,7 +834,10 @@ __global__ __launch_bounds__(512) void siren_fwd_x3_kernel(FwdX3Args a) {
         v.w = accf[0][4 * g + 3] + bfv[8 * g + 4 * hf + 3];
         *reinterpret_cast<float4*>(fo + 8 * g) = v;
       }
-      if (hf == 0) a.sigma[gp] = sig;
+      if (hf == 0) {
+        a.sigma[gp] = sig;
+        if (a.zout) a.zout[gp] = zpt;
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1141,12 +1105,6 @@ extern "C" int cips_siren_bwd_x3_prof(unsigned long long* host_out) {   // tunin
 }
 extern "C" int cips_siren_bwd_x3_sred(void) { return SRED; }
 
-static int fill_raygen(RayGen& g, const cips_ray_params* r) {
-  if (!r || !r->xg || !r->yg || !r->zg || !r->cam2world || r->W <= 0 || r->H <= 0 || r->S <= 1) return (int)hipErrorInvalidValue;
-  g.xg = r->xg; g.yg = r->yg; g.zg = r->zg; g.c2w = r->cam2world; g.jitter = r->jitter; g.zc = r->zc;
-  g.W = r->W; g.n = r->W * r->H; g.S = r->S;
-  return 0;
-}
 
 static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points, const cips_ray_params* rays,
                                const float* dfeat, const float* dsigma, float* sred, float* gpart, int B, int P,
@@ -1201,11 +1159,28 @@ static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points,
   return CIPS_CHECK_LAUNCH();
 }
 
+static int siren_fwd_x3_launch(const cips_siren_weights* w, const float* points, const cips_ray_params* rays, float* feat,
+                               float* sigma, float* zout, int B, int P, cips_stream_t stream);
+
 extern "C" int cips_siren_fwd_x3(const cips_siren_weights* w, const float* points, float* feat, float* sigma, int B, int P,
                                  cips_stream_t stream) {
-  if (!w || !points || !feat || !sigma || B <= 0 || P <= 0) return (int)hipErrorInvalidValue;
+  if (!points) return (int)hipErrorInvalidValue;
+  return siren_fwd_x3_launch(w, points, nullptr, feat, sigma, nullptr, B, P, stream);
+}
+
+extern "C" int cips_siren_fwd_x3_rays(const cips_siren_weights* w, const cips_ray_params* rays, float* feat, float* sigma,
+                                      float* zout, int B, cips_stream_t stream) {
+  if (!rays) return (int)hipErrorInvalidValue;
+  return siren_fwd_x3_launch(w, nullptr, rays, feat, sigma, zout, B, rays->W * rays->H * rays->S, stream);
+}
+
+static int siren_fwd_x3_launch(const cips_siren_weights* w, const float* points, const cips_ray_params* rays, float* feat,
+                               float* sigma, float* zout, int B, int P, cips_stream_t stream) {
+  if (!w || !feat || !sigma || B <= 0 || P <= 0) return (int)hipErrorInvalidValue;
   FwdX3Args a;
-  a.w = *w; a.points = points; a.feat = feat; a.sigma = sigma; a.B = B; a.P = P;
+  a.w = *w; a.points = points; a.feat = feat; a.sigma = sigma; a.zout = zout; a.B = B; a.P = P;
+  a.rg = RayGen{};
+  if (!points) { const int rc = fill_raygen(a.rg, rays); if (rc) return rc; }
   a.chunk = 4096;
   while (a.chunk > 512 && (long long)B * ((P + a.chunk - 1) / a.chunk) < 768) a.chunk >>= 1;
   dim3 grid((P + a.chunk - 1) / a.chunk, B);

@@ -184,6 +184,20 @@ class NeRFNetwork(nn.Module):
             self.color_layer_sine.linear.weight, self.color_layer_sine.linear.bias,
             self.color_layer_linear[0].weight, self.color_layer_linear[0].bias)
 
+    def evaluate_rays(self, style_dict, geom, xg, yg, zg, cam2world, jitter=None, zvals=None):
+        """evaluate() with the sample points generated in-kernel (coarse: from the jitter draw; fine: from the resampled
+        depths `zvals`) -> feat (b,P,32), sigma (b,P), z (b,P)"""
+        p = self.name_prefix
+        (g0, p0), (g1, p1), (gc, pc) = _film_all([self.network[0], self.network[1], self.color_layer_sine],
+                                                 [style_dict[f'{p}_w0'], style_dict[f'{p}_w1'], style_dict[f'{p}_rgb']])
+        return ops.SirenRaysFunction.apply(
+            geom, xg, yg, zg, cam2world, jitter, zvals, g0, p0, g1, p1, gc, pc,
+            self.network[0].linear.weight, self.network[0].linear.bias,
+            self.network[1].linear.weight, self.network[1].linear.bias,
+            self.final_layer.weight, self.final_layer.bias,
+            self.color_layer_sine.linear.weight, self.color_layer_sine.linear.bias,
+            self.color_layer_linear[0].weight, self.color_layer_linear[0].bias)
+
     def march(self, style_dict, geom, xg, yg, zg, cam2world, jitter, noise):
         """fused rays + SIREN + composite for non-hierarchical sampling -> pixels_fea (b,n,32), depth (b,n)"""
         p = self.name_prefix
@@ -573,7 +587,10 @@ class GeneratorNerfINR(nn.Module):
             # non-hierarchical sampling of whole images: rays + SIREN + composite fused in one kernel that walks the
             # samples along each ray (ops.RayMarchFunction); no (b,n,S,3) points, no per-sample features in HBM
             fused = (not hierarchical_sample) and (not part) and ops.march_available()
-            if not fused:
+            # hierarchical sampling of whole images: both SIREN passes and the resampler regenerate rays / points
+            # in-kernel (no rays kernel, no (b,n,S,3) point tensors for either pass)
+            gen_rays = hierarchical_sample and (not part) and ops.march_available()
+            if not fused and not gen_rays:
                 points, z_vals, dirs = ops.rays_fwd(xg, yg, zg, zc, cam2world, jitter.reshape(b, n, S), b, H, W, S)
             ray_origins = cam2world[:, :3, 3].contiguous()       # every ray starts at the camera
 
@@ -582,16 +599,27 @@ class GeneratorNerfINR(nn.Module):
             """points_forward (generator.py:1659-1762) for n rays per image: -> inr rgb (b,n,3), aux rgb or None"""
             ctx_nerf = torch.enable_grad() if nerf_grad else torch.no_grad()
             with ctx_nerf:
-                feat_c, sig_c = self.siren.evaluate(points.reshape(b, n * S, 3), nerf_styles)
+                if gen_rays:
+                    rgeom = (b, H, W, S, zc)
+                    jit3 = jitter.reshape(b, n, S)
+                    feat_c, sig_c, z_c = self.siren.evaluate_rays(nerf_styles, rgeom, xg, yg, zg, cam2world, jitter=jit3)
+                else:
+                    feat_c, sig_c = self.siren.evaluate(points.reshape(b, n * S, 3), nerf_styles)
+                    z_c = z_vals
                 feat_c = feat_c.view(b * n, S, 32)
                 sig_c = sig_c.view(b * n, S)
-                z_c = z_vals.reshape(b * n, S)
+                z_c = z_c.reshape(b * n, S)
                 if hierarchical_sample:
                     with torch.no_grad():
+                        rp = ops._ray_params(xg, yg, zg, zc, cam2world, None, H, W, S) if gen_rays else None
                         fine_z, fine_pts = ops.resample_fwd(
                             sig_c, z_c, noise_c.reshape(b * n, S) if nerf_noise != 0 else None, nerf_noise,
-                            u, ray_origins, dirs.reshape(b * n, 3), b, n, S, clamp)
-                    feat_f, sig_f = self.siren.evaluate(fine_pts.view(b, n * S, 3), nerf_styles)
+                            u, ray_origins, dirs.reshape(b * n, 3) if dirs is not None else None, b, n, S, clamp, rays=rp)
+                    if gen_rays:
+                        feat_f, sig_f, _ = self.siren.evaluate_rays(nerf_styles, rgeom, xg, yg, zg, cam2world,
+                                                                    zvals=fine_z.view(b, n * S))
+                    else:
+                        feat_f, sig_f = self.siren.evaluate(fine_pts.view(b, n * S, 3), nerf_styles)
                     feat_f = feat_f.view(b * n, S, 32)
                     sig_f = sig_f.view(b * n, S)
                 else:
@@ -612,7 +640,7 @@ class GeneratorNerfINR(nn.Module):
         if fused:
             ctx_nerf = torch.enable_grad() if nerf_grad else torch.no_grad()
             with ctx_nerf:
-                geom = (b, H, W, S, zc, float(nerf_noise), clamp, flags)
+                geom = (b, H, W, S, zc, float(nerf_noise), clamp, flags, torch.is_grad_enabled())
                 pixels_fea, _depth = self.siren.march(nerf_styles, geom, xg, yg, zg, cam2world, jitter.reshape(b, n, S),
                                                       noise_f.reshape(b, n, S) if nerf_noise != 0 else None)
                 aux_img = torch.tanh(_ToRGBFunction.apply(pixels_fea, self.aux_to_rbg[0].weight,
@@ -620,6 +648,8 @@ class GeneratorNerfINR(nn.Module):
             if not nerf_grad:
                 pixels_fea = pixels_fea.detach()
             inr_img = self.inr_net(pixels_fea, style_dict)
+        elif gen_rays:
+            inr_img, aux_img = pipeline(None, None, None, n, noise_c, u, noise_f, nerf_grad)
         elif not part:
             inr_img, aux_img = pipeline(points, z_vals, dirs, n, noise_c, u, noise_f, nerf_grad)
         else:

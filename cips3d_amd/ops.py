@@ -208,7 +208,11 @@ def _siren_backward(t, dfeat, dsigma, B, P, points=None, rays=None):
                 sg = SirenGrads()
                 for k, v in outs.items():
                     setattr(sg, k, _p(v))
-                check(lib.cips_siren_bwd_x3_finalize(C.byref(sw), _p(sred), _p(gpart), B, chunks, C.byref(sg), _stream()),
+                # the chunk partials are summed by two streaming reductions first (88 MB at C2: bandwidth-bound, one
+                # launch each); the finalisation then walks B rows instead of B * chunks
+                SRr = sred.view(B, chunks, sw_).sum(1) if chunks > 1 else sred
+                Gpr = gpart.view(B, chunks, gw).sum(1) if chunks > 1 else gpart
+                check(lib.cips_siren_bwd_x3_finalize(C.byref(sw), _p(SRr), _p(Gpr), B, 1, C.byref(sg), _stream()),
                       "cips_siren_bwd_x3_finalize")
                 return tuple(outs[k] for k in ("dg0", "dp0", "dg1", "dp1", "dgc", "dpc", "dw0", "db0", "dw1", "db1", "dws",
                                                "dbs", "dwc", "dbc", "dwf", "dbf"))
@@ -277,15 +281,17 @@ def _siren_backward(t, dfeat, dsigma, B, P, points=None, rays=None):
 # --------------------------------------------------------------------------------------
 # H3 resample / composite
 # --------------------------------------------------------------------------------------
-def resample_fwd(sigma, z, noise, noise_std, u, origins, dirs, B, n, S, clamp_mode=0, debug=False, cdf_in=None):
-    """sigma/z/noise/u (B*n,S) -> fine_z (B*n,S), fine_pts (B*n,S,3) [+ weights, cdf, inds]."""
+def resample_fwd(sigma, z, noise, noise_std, u, origins, dirs, B, n, S, clamp_mode=0, debug=False, cdf_in=None, rays=None):
+    """sigma/z/noise/u (B*n,S) -> fine_z (B*n,S), fine_pts (B*n,S,3) [+ weights, cdf, inds].
+    rays (RayParams): ray directions / origins recomputed in-kernel, no fine_pts (the fine pass regenerates its points
+    from fine_z): origins / dirs may be None, fine_pts is returned as None."""
     lib = _lib.load()
     dev = sigma.device
     sigma, z, noise, u, origins, dirs = _c(sigma), _c(z), _c(noise), _c(u), _c(origins), _c(dirs)
     _chk(sigma, z, noise, u, origins, dirs)
     R = B * n
     fine_z = torch.empty(R, S, device=dev)
-    fine_pts = torch.empty(R, S, 3, device=dev)
+    fine_pts = torch.empty(R, S, 3, device=dev) if rays is None else None
     w = cdf = inds = None
     if debug:
         w = torch.empty(R, S, device=dev)
@@ -293,7 +299,8 @@ def resample_fwd(sigma, z, noise, noise_std, u, origins, dirs, B, n, S, clamp_mo
         inds = torch.empty(R, S, device=dev, dtype=torch.int64)
     check(lib.cips_resample_fwd(_p(sigma), _p(z), _p(noise), float(noise_std), _p(u), _p(origins), _p(dirs),
                                 _p(fine_z), _p(fine_pts), _p(w), _p(cdf), _p(inds), B, n, S, clamp_mode,
-                                _p(_c(cdf_in)) if cdf_in is not None else None, _stream()), "cips_resample_fwd")
+                                _p(_c(cdf_in)) if cdf_in is not None else None,
+                                C.byref(rays) if rays is not None else None, _stream()), "cips_resample_fwd")
     if debug:
         return fine_z, fine_pts, w, cdf, inds
     return fine_z, fine_pts
@@ -454,12 +461,57 @@ def march_available():
     return MARCH_FUSED and SIREN_FWD_MODE == "x3" and SIREN_BWD_MODE == "x3"
 
 
-def _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S):
+def _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S, zvals=None):
     from ._lib import RayParams
     r = RayParams()
-    r.xg, r.yg, r.zg, r.cam2world, r.jitter = _p(xg), _p(yg), _p(zg), _p(cam2world), _p(jitter)
+    r.xg, r.yg, r.zg, r.cam2world, r.jitter, r.zvals = _p(xg), _p(yg), _p(zg), _p(cam2world), _p(jitter), _p(zvals)
     r.zc, r.H, r.W, r.S = float(zc), H, W, S
     return r
+
+
+class SirenRaysFunction(torch.autograd.Function):
+    """feat (B,P,32), sigma (B,P), z (B,P) = siren(points generated in-kernel) — SirenFunction without the (B,P,3)
+    points tensor, for the two passes of the hierarchical path: the coarse pass generates its stratified samples from
+    (grids, cam2world, jitter) (comm_utils.py:365-438, 584-679), the fine pass from the resampled depths
+    `zvals`: origin + direction * z (generator_nerf_inr.py:590-592).  Backward: cips_siren_bwd_x3_rays."""
+
+    @staticmethod
+    def forward(ctx, geom, xg, yg, zg, cam2world, jitter, zvals, g0, p0, g1, p1, gc, pc, w0, b0, w1, b1, ws, bs, wc, bc,
+                wf, bf):
+        lib = _lib.load()
+        B, H, W, S, zc = geom
+        t = dict(w0=w0, b0=b0, w1=w1, b1=b1, ws=ws, bs=bs, wc=wc, bc=bc, wf=wf, bf=bf,
+                 g0=g0, p0=p0, g1=g1, p1=p1, gc=gc, pc=pc)
+        t = {k: _c(v.detach()) for k, v in t.items()}
+        xg, yg, zg, cam2world = _c(xg), _c(yg), _c(zg), _c(cam2world)
+        jitter = _c(jitter) if jitter is not None else None
+        zvals = _c(zvals.detach()) if zvals is not None else None
+        _chk(xg, yg, zg, cam2world, jitter, zvals, *t.values())
+        dev = cam2world.device
+        P = H * W * S
+        feat = torch.empty(B, P, 32, device=dev)
+        sigma = torch.empty(B, P, device=dev)
+        z = torch.empty(B, P, device=dev) if zvals is None else zvals
+        sw = _siren_struct(t)
+        rp = _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S, zvals)
+        check(lib.cips_siren_fwd_x3_rays(C.byref(sw), C.byref(rp), _p(feat), _p(sigma), _p(z) if zvals is None else None, B,
+                                         _stream()), "cips_siren_fwd_x3_rays")
+        ctx.save_for_backward(xg, yg, zg, cam2world, jitter, zvals, *[t[k] for k in _SIREN_NAMES])
+        ctx.geom = geom
+        ctx.mark_non_differentiable(z)
+        return feat, sigma, z
+
+    @staticmethod
+    def backward(ctx, dfeat, dsigma, _dz):
+        xg, yg, zg, cam2world, jitter, zvals = ctx.saved_tensors[:6]
+        t = dict(zip(_SIREN_NAMES, ctx.saved_tensors[6:]))
+        B, H, W, S, zc = ctx.geom
+        P = H * W * S
+        dev = cam2world.device
+        dfeat = _c(dfeat) if dfeat is not None else torch.zeros(B, P, 32, device=dev)
+        dsigma = _c(dsigma) if dsigma is not None else torch.zeros(B, P, device=dev)
+        rp = _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S, zvals)
+        return (None,) * 7 + _siren_backward(t, dfeat, dsigma, B, P, rays=rp)
 
 
 class RayMarchFunction(torch.autograd.Function):
@@ -474,7 +526,7 @@ class RayMarchFunction(torch.autograd.Function):
     def forward(ctx, geom, xg, yg, zg, cam2world, jitter, noise, g0, p0, g1, p1, gc, pc, w0, b0, w1, b1, ws, bs, wc, bc,
                 wf, bf):
         lib = _lib.load()
-        B, H, W, S, zc, noise_std, clamp_mode, flags = geom
+        B, H, W, S, zc, noise_std, clamp_mode, flags, grad_mode = geom
         t = dict(w0=w0, b0=b0, w1=w1, b1=b1, ws=ws, bs=bs, wc=wc, bc=bc, wf=wf, bf=bf,
                  g0=g0, p0=p0, g1=g1, p1=p1, gc=gc, pc=pc)
         t = {k: _c(v.detach()) for k, v in t.items()}
@@ -484,7 +536,9 @@ class RayMarchFunction(torch.autograd.Function):
         _chk(xg, yg, zg, cam2world, jitter, noise, *t.values())
         dev = cam2world.device
         n = H * W
-        train = any(ctx.needs_input_grad)
+        # per-sample outputs only when a backward can follow: the caller's grad mode counts (inside forward() it is
+        # always off, and under torch.no_grad() needs_input_grad still reports the parameters' requires_grad)
+        train = grad_mode and any(ctx.needs_input_grad)
         fea = torch.empty(B, n, 32, device=dev)
         depth = torch.empty(B, n, device=dev)
         feat = torch.empty(B, n * S, 32, device=dev) if train else None
@@ -505,7 +559,7 @@ class RayMarchFunction(torch.autograd.Function):
         lib = _lib.load()
         xg, yg, zg, cam2world, jitter, noise, feat, sigma, z = ctx.saved_tensors[:9]
         t = dict(zip(_SIREN_NAMES, ctx.saved_tensors[9:]))
-        B, H, W, S, zc, noise_std, clamp_mode, flags = ctx.geom
+        B, H, W, S, zc, noise_std, clamp_mode, flags, _ = ctx.geom
         n = H * W
         R = B * n
         dfea = _c(dfea)
@@ -637,6 +691,7 @@ class InrHeadFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, nblocks, x0, *params):
+        nblocks, _grad_mode = nblocks if isinstance(nblocks, tuple) else (nblocks, True)
         x0 = _c(x0.detach())
         B, n, _ = x0.shape
         dev = x0.device
@@ -1007,6 +1062,7 @@ class InrHeadX3Function(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, nblocks, x0, *params):
+        nblocks, grad_mode = nblocks if isinstance(nblocks, tuple) else (nblocks, True)
         x0 = _c(x0.detach())
         B, n, in0 = x0.shape
         if n % 32 or in0 % 32:
@@ -1017,7 +1073,7 @@ class InrHeadX3Function(torch.autograd.Function):
             blocks.append(tuple(_c(p.detach()) for p in params[4 * k:4 * k + 4]))
         rgbp = [_c(p.detach()) for p in params[4 * nblocks:]]
         _chk(x0, *[t for blk in blocks for t in blk], *rgbp)
-        train = any(ctx.needs_input_grad)       # no-grad / inference: no transposed planes, nothing kept
+        train = grad_mode and any(ctx.needs_input_grad)       # no-grad / inference: no transposed planes, nothing kept
         want_t = train and not INR_W_KMAJOR     # K-major dW form reads the row-major planes: no transposed copies
         xP, xT = split_planes(x0, want_t=want_t)
         rgb = torch.empty(B, n, 3, device=dev)
@@ -1180,7 +1236,8 @@ def inr_head(nblocks, x0, *params):
     # grad_points, generator.py:1591-1593) runs on the exact fp32 MFMA path, which has no such granule
     x3 = INR_MODE == "bf16x3" and x0.shape[1] % 32 == 0 and x0.shape[2] % 32 == 0
     fn = InrHeadX3Function if x3 else InrHeadFunction
-    return fn.apply(nblocks, x0, *params)
+    # (nblocks, caller's grad mode): under torch.no_grad() nothing is kept for a backward
+    return fn.apply((nblocks, torch.is_grad_enabled()), x0, *params)
 
 
 # --------------------------------------------------------------------------------------

@@ -140,9 +140,16 @@ typedef struct cips_ray_params {
   const float* xg; const float* yg; const float* zg;   /* torch.linspace grids (W), (H), (S) */
   const float* cam2world;                                /* (B,4,4) */
   const float* jitter;                                   /* (B,n,S) uniforms in [0,1) or NULL */
+  const float* zvals;                                    /* (B,n,S) depths or NULL; if set: point = camera origin + world ray
+                                                            direction * zvals[p] (the resampled fine points,
+                                                            exp/dev/nerf_inr/models/generator_nerf_inr.py:590-592) */
   float zc;                                              /* -1/tan(fov/2) */
   int H, W, S;
 } cips_ray_params;
+
+/* cips_siren_fwd_x3 with the points generated in-kernel from `rays`; zout (optional, (B,P)) receives their depths. */
+int cips_siren_fwd_x3_rays(const cips_siren_weights* w, const cips_ray_params* rays, float* feat, float* sigma,
+                           float* zout, int B, cips_stream_t stream);
 
 /* cips_siren_bwd_x3 with the points generated in-kernel from `rays` (P = H*W*S points per image). */
 int cips_siren_bwd_x3_rays(const cips_siren_weights* w, const cips_ray_params* rays, const float* dfeat,
@@ -176,12 +183,15 @@ int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_params* rays, 
  * clamp_mode: 0 = relu, 1 = softplus.
  * cdf_in (optional, (R,S-1)): take the cdf from the caller instead of computing it — the "bit-exact integer bookkeeping
  * on identical float inputs" contract: with the reference's cdf and u the indices must equal
- * torch.searchsorted's exactly. */
+ * torch.searchsorted's exactly.
+ * rays (optional): ray directions and origins are recomputed from the ray parameters (origins / dirs may then be NULL,
+ * and fine_pts may be NULL when the fine pass regenerates its points from fine_z, cips_ray_params.zvals). */
 int cips_resample_fwd(const float* sigma, const float* z, const float* noise, float noise_std,
                       const float* u, const float* origins, const float* dirs,
                       float* fine_z, float* fine_pts,
                       float* weights_out, float* cdf_out, long long* inds_out,
-                      int B, int n, int S, int clamp_mode, const float* cdf_in, cips_stream_t stream);
+                      int B, int n, int S, int clamp_mode, const float* cdf_in, const cips_ray_params* rays,
+                      cips_stream_t stream);
 
 /* Merge (coarse + fine, ascending z) and alpha-composite.
  * replaces exp/cips3d/models/generator.py:1733-1752 (cat/sort/gather) and

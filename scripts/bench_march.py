@@ -34,12 +34,12 @@ def main():
     c2w = torch.eye(4, device=d).repeat(b, 1, 1); c2w[:, 2, 3] = 1.0
     jit = torch.rand(b, n, S, device=d)
     up = torch.randn(b, n, 32, device=d)
-    geom = (b, img, img, S, zc, 0.0, 0, 0)
+    geom = (b, img, img, S, zc, 0.0, 0, 0, True)
     res = {}
 
     def fused_ng():
         with torch.no_grad():
-            G.siren.march(style, geom, xg, yg, zg, c2w, jit, None)
+            G.siren.march(style, geom[:-1] + (False,), xg, yg, zg, c2w, jit, None)
 
     def unfused_ng():
         with torch.no_grad():

@@ -17,5 +17,5 @@ c2w = torch.eye(4, device=d).repeat(b, 1, 1); c2w[:, 2, 3] = 1.0
 jit = torch.rand(b, n, S, device=d)
 with torch.no_grad():
     for _ in range(6):
-        G.siren.march(style, (b, img, img, S, zc, 0.0, 0, 0), xg, yg, zg, c2w, jit, None)
+        G.siren.march(style, (b, img, img, S, zc, 0.0, 0, 0, False), xg, yg, zg, c2w, jit, None)
 torch.cuda.synchronize()

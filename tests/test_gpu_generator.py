@@ -158,24 +158,27 @@ def test_generator_matches_reference_golden(tag, inr_mode):
     assert not bad, bad
 
 
-def test_fused_and_unfused_march_agree_on_the_flat_golden_case(monkeypatch):
-    """hierarchical_sample=False runs the fused ray-march by default (ops.RayMarchFunction); CIPS_MARCH_FUSED=0 keeps the
-    five-kernel path (rays, SIREN, composite).  Both against the reference's images on the flat golden case, and against
-    each other, forward and parameter gradients."""
+@pytest.mark.parametrize("tag", ["g_r8_flat_noise", "g_r16_hier", "g_r8_hier_noise"])
+def test_fused_and_unfused_march_agree_on_the_flat_golden_case(tag, monkeypatch):
+    """By default the ray set-up lives inside the SIREN kernels: hierarchical_sample=False runs the fused ray-march
+    (ops.RayMarchFunction: rays + SIREN + composite in one kernel), hierarchical_sample=True regenerates the coarse and
+    the fine points in-kernel (ops.SirenRaysFunction, resampler with in-kernel ray directions).  CIPS_MARCH_FUSED=0
+    keeps the materialised path (rays kernel, (b,n,S,3) point tensors).  Both against the reference's images, and
+    against each other, forward and parameter gradients."""
     from cips3d_amd import ops
-    fix = load_golden("g_r8_flat_noise")
+    fix = load_golden(tag)
     d = torch.device("cuda:0")
     res = {}
     for fused in (True, False):
         monkeypatch.setattr(ops, "MARCH_FUSED", fused)
         G = seeded_generator(fix["seed"], device=d)
-        imgs, _, grads = _run_product(G, fix, d, pin=[pack_bitplane(g) for g in load_gates("g_r8_flat_noise")])
+        imgs, _, grads = _run_product(G, fix, d, pin=[pack_bitplane(g) for g in load_gates(tag)])
         assert max_rel(imgs, fix["imgs"]) < TOL
         res[fused] = (imgs, grads)
     e = max_rel(res[True][0], res[False][0])
     worst = max(float((a - b).norm() / b.norm().clamp_min(1e-300)) for a, b in
                 ((res[True][1][k], res[False][1][k]) for k in res[True][1] if res[True][1][k] is not None))
-    print(f"fused vs unfused march: imgs {e:.2e}, worst parameter gradient {worst:.2e}")
+    print(f"{tag}: in-kernel rays vs materialised points: imgs {e:.2e}, worst parameter gradient {worst:.2e}")
     assert e < 1e-5 and worst < GRAD_TOL
 
 

@@ -251,7 +251,7 @@ def test_fused_march_forward_backward(img, S, b, noise_std, clamp, flags):
           f"fea {e[3]:.2e} depth {e[4]:.2e}")
     assert max(e) < 2e-4
     # ---- HIP: the autograd function (forward that keeps nothing per sample under no_grad; training forward + backward) ----
-    geom = (b, img, img, S, zc, float(noise_std), ops._CLAMP[clamp], flags)
+    geom = (b, img, img, S, zc, float(noise_std), ops._CLAMP[clamp], flags, True)
     with torch.no_grad():
         f0, d0 = net.march(sdict, geom, xg, yg, zg, c2w, jd, nd)
     # (the FiLM vectors of net.march come from the grouped-linear kernel, those above from torch: equal to rounding)
