@@ -63,12 +63,14 @@ for k, cs in agg.items():
     mm = {c: sum(v) / len(v) for c, v in cs.items()}
     n = len(next(iter(cs.values())))
     gui = mm.get("GRBM_GUI_ACTIVE", 0.0)
-    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the chip's SIMDs-with-MFMA (4 per CU x 256 CUs); GRBM_GUI_ACTIVE
-    # = shader-clock cycles of the launch: busy fraction = MFMA_BUSY / (GUI_ACTIVE x 1024)
+    # SQ_VALU_MFMA_BUSY_CYCLES = matrix-pipe busy cycles summed over the chip's 1024 SIMDs (= 32 x the number of
+    # v_mfma_f32_32x32x16_bf16 issued: checked against the GEMMs' MFMA counts); GRBM_GUI_ACTIVE is summed over the 8 XCDs,
+    # so the launch lasted GUI_ACTIVE / 8 shader cycles: busy fraction = MFMA_BUSY / (1024 x GUI_ACTIVE / 8)
     rows[k] = {"launches": n, **{c: round(v, 1) for c, v in mm.items()},
-               "mfma_busy_frac": round(mm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024), 4) if gui else None}
+               "launch_kcycles": round(gui / 8 / 1e3, 1),
+               "mfma_busy_frac": round(mm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * 8 / (gui * 1024), 4) if gui else None}
 json.dump({"method": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES over "
-                     "2 eager bench steps at C2; per-kernel means; mfma_busy_frac = MFMA_BUSY / (GUI_ACTIVE * 256 CUs * 4 SIMDs)",
+                     "2 eager bench steps at C2 (+1 warm-up); per-kernel means over the launches; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
            "kernels": rows}, open("gpurun_out/r2_mfma_busy.json", "w"), indent=1)
 for k, v in sorted(rows.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0) * kv[1]["launches"])[:16]:
     print(k[:70], v)
