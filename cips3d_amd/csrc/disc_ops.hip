@@ -277,6 +277,166 @@ inline unsigned grid_for(long long total) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
+// DiffAugment (exp/cips3d/models/diffaug.py:9-85, policy 'color,translation,cutout': what Discriminator_MultiScale
+// .diff_aug_img applies to every input, discriminator.py:507-508) as ONE affine operator y = A x + c and its adjoint.
+//   brightness  x1 = x + (rb - 0.5)                                  (:31-33)
+//   saturation  x2 = (x1 - mean_c x1) * (2 rs) + mean_c x1           (:36-39)
+//   contrast    x3 = (x2 - mean_chw x2) * (rc + 0.5) + mean_chw x2   (:42-45); mean_chw x2 = mean_chw x1 exactly
+//   translation x4[i][j] = x3[i + tx][j + ty], zero outside          (:48-62)
+//   cutout      y = x4 * mask, mask = 0 on rows [max(ox - ch/2, 0), min(ox - ch/2 + ch - 1, H-1)] x the same in columns
+// The random draws (rb, rs, rc uniform; tx, ty, ox, oy integers) are made by the host with the reference's calls, in
+// its order.  Forward = per-image sum of x (for the contrast mean) + one elementwise pass; the adjoint (the backward,
+// and through its own backward the R1 double-backward, train.py:387-394) has the same shape: per-image sum of the
+// shifted, masked upstream gradient + one elementwise pass.  `affine` = 0 drops the brightness constant (the operator
+// applied to a perturbation: backward of the adjoint).
+struct DiffAugArgs {
+  const float* x; float* y;
+  const float *rb, *rs, *rc;                     // (B) raw uniform draws
+  const long long *tx, *ty, *ox, *oy;            // (B) integer draws
+  const float* sums;                             // (B) per-image sums from diffaug_sum_kernel
+  int B, C, H, W, ch, cw, affine;
+};
+
+__device__ __forceinline__ bool da_masked(const DiffAugArgs& a, int b, int i, int j) {
+  const int lo_i = (int)a.ox[b] - a.ch / 2, lo_j = (int)a.oy[b] - a.cw / 2;
+  const int r0 = max(lo_i, 0), r1 = min(lo_i + a.ch - 1, a.H - 1);
+  const int c0 = max(lo_j, 0), c1 = min(lo_j + a.cw - 1, a.W - 1);
+  return i >= r0 && i <= r1 && j >= c0 && j <= c1;
+}
+
+// mode 0: sums[b] = sum of x[b]; mode 1: sums[b] = sum over the source pixels of the shifted, masked gradient
+// g3[c][i'][j'] = (g * mask)[c][i' - tx][j' - ty]
+__global__ __launch_bounds__(256) void diffaug_sum_kernel(DiffAugArgs a, float* __restrict__ out, int mode) {
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  const int HW = a.H * a.W, n = a.C * HW;
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    float v = a.x[(long long)b * n + e];
+    if (mode == 1) {
+      const int p = e % HW, i = p / a.W, j = p - i * a.W;            // (i, j) = position in the OUTPUT of the forward
+      const int si = i + (int)a.tx[b], sj = j + (int)a.ty[b];        // its source pixel
+      if (da_masked(a, b, i, j) || si < 0 || si >= a.H || sj < 0 || sj >= a.W) v = 0.f;
+    }
+    acc += v;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s_ = 128; s_ > 0; s_ >>= 1) {
+    if (threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[b] = red[0];
+}
+
+__global__ __launch_bounds__(256) void diffaug_fwd_kernel(DiffAugArgs a) {
+  const int HW = a.H * a.W;
+  const long long total = (long long)a.B * HW;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int b = (int)(t / HW), p = (int)(t - (long long)b * HW), i = p / a.W, j = p - i * a.W;
+    const int si = i + (int)a.tx[b], sj = j + (int)a.ty[b];
+    const bool zero = da_masked(a, b, i, j) || si < 0 || si >= a.H || sj < 0 || sj >= a.W;
+    const float off = a.affine ? a.rb[b] - 0.5f : 0.f;
+    const float s2 = a.rs[b] * 2.f, k = a.rc[b] + 0.5f;
+    const float m2 = a.sums[b] / (float)(a.C * HW) + off;
+    float x1[4], m1 = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+      x1[c] = zero ? 0.f : a.x[((long long)b * a.C + c) * HW + si * a.W + sj] + off;
+      m1 += x1[c];
+    }
+    m1 /= (float)a.C;
+    for (int c = 0; c < a.C; ++c) {
+      const float x2 = (x1[c] - m1) * s2 + m1;
+      a.y[((long long)b * a.C + c) * HW + p] = zero ? 0.f : (x2 - m2) * k + m2;
+    }
+  }
+}
+
+// dx = A^T g: one thread per SOURCE pixel (i', j'): g3 = (g * mask)[i' - tx][j' - ty]; contrast^T: g2 = k g3 +
+// (1 - k) / (C H W) * sum(g3); saturation^T: g1 = s g2 + (1 - s) mean_c g2; brightness^T: identity.
+__global__ __launch_bounds__(256) void diffaug_adj_kernel(DiffAugArgs a) {
+  const int HW = a.H * a.W;
+  const long long total = (long long)a.B * HW;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int b = (int)(t / HW), p = (int)(t - (long long)b * HW), si = p / a.W, sj = p - si * a.W;
+    const int i = si - (int)a.tx[b], j = sj - (int)a.ty[b];          // where this source pixel went
+    const bool none = i < 0 || i >= a.H || j < 0 || j >= a.W || da_masked(a, b, i, j);
+    const float s2 = a.rs[b] * 2.f, k = a.rc[b] + 0.5f;
+    const float spread = (1.f - k) * a.sums[b] / (float)(a.C * HW);
+    float g2[4], mg = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+      const float g3 = none ? 0.f : a.x[((long long)b * a.C + c) * HW + i * a.W + j];
+      g2[c] = k * g3 + spread;
+      mg += g2[c];
+    }
+    mg /= (float)a.C;
+    for (int c = 0; c < a.C; ++c) a.y[((long long)b * a.C + c) * HW + p] = s2 * g2[c] + (1.f - s2) * mg;
+  }
+}
+
+extern "C" int cips_diffaug(const float* x, float* y, const float* rb, const float* rs, const float* rc,
+                            const long long* tx, const long long* ty, const long long* ox, const long long* oy,
+                            float* sums, int B, int C, int H, int W, int cut_h, int cut_w, int adjoint, int affine,
+                            cips_stream_t stream) {
+  if (!x || !y || !rb || !rs || !rc || !tx || !ty || !ox || !oy || !sums || B <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0 ||
+      cut_h < 0 || cut_w < 0)
+    return (int)hipErrorInvalidValue;
+  DiffAugArgs a;
+  a.x = x; a.y = y; a.rb = rb; a.rs = rs; a.rc = rc; a.tx = tx; a.ty = ty; a.ox = ox; a.oy = oy; a.sums = sums;
+  a.B = B; a.C = C; a.H = H; a.W = W; a.ch = cut_h; a.cw = cut_w; a.affine = affine;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(diffaug_sum_kernel, dim3(B), dim3(256), 0, st, a, sums, adjoint ? 1 : 0);
+  const long long total = (long long)B * H * W;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (adjoint) hipLaunchKernelGGL(diffaug_adj_kernel, dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(diffaug_fwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  return CIPS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Progressive fade-in of the discriminator input (discriminator.py:524-534): F.interpolate(x, scale_factor=0.5,
+// mode='bilinear') on even sizes is the 2x2 mean, h0 (w0 v00 + w1 v01) + h1 (w0 v10 + w1 v11) with all weights 0.5
+// (ATen upsample_bilinear2d, align_corners False); its adjoint spreads 0.25 g.  out = a x + b y is the blend
+// alpha * cur + (1 - alpha) * down (y may be NULL: out = a x, the blend's backward).
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int H, int W,
+                                                       int adjoint) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long long total = planes * Ho * Wo;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long pl = t / (Ho * Wo);
+    const int p = (int)(t - pl * (Ho * Wo)), i = p / Wo, j = p - i * Wo;
+    if (!adjoint) {
+      const float* q = x + pl * H * W + (2 * i) * W + 2 * j;
+      const float top = __fadd_rn(0.5f * q[0], 0.5f * q[1]), bot = __fadd_rn(0.5f * q[W], 0.5f * q[W + 1]);
+      y[t] = __fadd_rn(0.5f * top, 0.5f * bot);
+    } else {
+      const float g = 0.25f * x[t];
+      float* q = y + pl * H * W + (2 * i) * W + 2 * j;
+      q[0] = g; q[1] = g; q[W] = g; q[W + 1] = g;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, float a,
+                                                    float b, long long n) {
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256)
+    out[t] = y ? __fadd_rn(__fmul_rn(a, x[t]), __fmul_rn(b, y[t])) : __fmul_rn(a, x[t]);
+}
+
+extern "C" int cips_avgpool2(const float* x, float* y, long long planes, int H, int W, int adjoint, cips_stream_t stream) {
+  if (!x || !y || planes <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
+  const long long total = planes * (H / 2) * (W / 2);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, planes, H, W, adjoint);
+  return CIPS_CHECK_LAUNCH();
+}
+extern "C" int cips_axpby(const float* x, const float* y, float* out, float a, float b, long long n, cips_stream_t stream) {
+  if (!x || !out || n <= 0) return (int)hipErrorInvalidValue;
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(axpby_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, out, a, b, n);
+  return CIPS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // FID path (exp/cips3d/scripts/gen_images.py:56-60): torchvision.utils.save_image(img, normalize=True,
 // value_range=(lo, hi)) turns the generator's float image into the uint8 pixels that are JPEG-encoded and fed to the
 // Inception network: clamp to [lo, hi], (x - lo) * (1 / max(hi - lo, 1e-5)) (ATen's CUDA div-by-scalar is a multiply by

@@ -620,11 +620,62 @@ class EqualLinear(nn.Module):
         return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
 
 
+class _DiffAugFunction(Function):
+    """y = A x (+ c): the fused DiffAugment operator (cips_diffaug) or, with adjoint=True, its transpose.  The two are
+    each other's backward, which gives the R1 double-backward for free (the operator is affine)."""
+
+    @staticmethod
+    def forward(ctx, x, draws, adjoint, affine):
+        import ctypes as C
+        from . import _lib
+        rb, rs, rc, tx, ty, ox, oy = draws
+        x = x.contiguous().float()
+        B, Cc, H, W = x.shape
+        y = torch.empty_like(x)
+        sums = torch.empty(B, device=x.device)
+        lib = _lib.load()
+        P = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(x.device):
+            _lib.check(lib.cips_diffaug(P(x), P(y), P(rb), P(rs), P(rc), P(tx), P(ty), P(ox), P(oy), P(sums), B, Cc, H, W,
+                                        int(H * 0.2 + 0.5), int(W * 0.2 + 0.5), 1 if adjoint else 0, 1 if affine else 0,
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "cips_diffaug")
+        ctx.draws, ctx.adjoint = draws, adjoint
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _DiffAugFunction.apply(g, ctx.draws, not ctx.adjoint, False), None, None, None
+
+
+def _diffaug_hip(x):
+    """policy 'color,translation,cutout' on a GPU batch: the reference's seven draws, in its order and with its calls
+    (diffaug.py:32, 38, 44, 50-51, 66-67), then one fused operator"""
+    b, _, h, w = x.shape
+    dev = x.device
+    rb = torch.rand(b, 1, 1, 1, dtype=x.dtype, device=dev)
+    rs = torch.rand(b, 1, 1, 1, dtype=x.dtype, device=dev)
+    rc = torch.rand(b, 1, 1, 1, dtype=x.dtype, device=dev)
+    sx, sy = int(h * 0.125 + 0.5), int(w * 0.125 + 0.5)
+    tx = torch.randint(-sx, sx + 1, size=[b, 1, 1], device=dev)
+    ty = torch.randint(-sy, sy + 1, size=[b, 1, 1], device=dev)
+    ch, cw = int(h * 0.2 + 0.5), int(w * 0.2 + 0.5)
+    ox = torch.randint(0, h + (1 - ch % 2), size=[b, 1, 1], device=dev)
+    oy = torch.randint(0, w + (1 - cw % 2), size=[b, 1, 1], device=dev)
+    draws = tuple(t.reshape(b).contiguous() for t in (rb.float(), rs.float(), rc.float(), tx.long(), ty.long(), ox.long(), oy.long()))
+    return _DiffAugFunction.apply(x, draws, False, True)
+
+
+DIFFAUG_HIP = _os.environ.get("CIPS_DIFFAUG_HIP", "1") != "0"
+
+
 def DiffAugment(x, policy='', channels_first=True):
-    """exp/cips3d/models/diffaug.py:9-85 (color, translation, cutout) — elementwise / gather torch ops
-    ('next' row; only the r256 stages enable it)."""
+    """exp/cips3d/models/diffaug.py:9-85 (color, translation, cutout).  The discriminator's policy on a GPU batch runs as
+    one fused HIP operator with its adjoint (cips_diffaug); other policies / CPU tensors take the op-by-op torch
+    restatement below (same draws, same order)."""
     if not policy:
         return x
+    if DIFFAUG_HIP and policy == 'color,translation,cutout' and channels_first and x.is_cuda and x.dim() == 4 and x.shape[1] <= 4:
+        return _diffaug_hip(x)
     if not channels_first:
         x = x.permute(0, 3, 1, 2)
     for p in policy.split(','):
@@ -680,6 +731,57 @@ _AUGMENT_FNS = {'color': [_rand_brightness, _rand_saturation, _rand_contrast],
                 'translation': [_rand_translation], 'cutout': [_rand_cutout]}
 
 
+def _hip_unary(name, *args):
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args, C.c_void_p(torch.cuda.current_stream().cuda_stream)), name)
+
+
+class _AvgPool2Function(Function):
+    """the 2x2 mean of the fade-in path (discriminator.py:525) and its transpose, each the other's backward"""
+
+    @staticmethod
+    def forward(ctx, x, adjoint):
+        import ctypes as C
+        x = x.contiguous().float()
+        B, Cc, H, W = x.shape
+        Ho, Wo = (H * 2, W * 2) if adjoint else (H // 2, W // 2)
+        y = torch.empty(B, Cc, Ho, Wo, device=x.device)
+        with torch.cuda.device(x.device):
+            _hip_unary("cips_avgpool2", C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), B * Cc, max(H, Ho), max(W, Wo),
+                       1 if adjoint else 0)
+        ctx.adjoint = adjoint
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _AvgPool2Function.apply(g, not ctx.adjoint), None
+
+
+class _BlendFunction(Function):
+    """out = a x + b y (alpha * cur + (1 - alpha) * down, discriminator.py:534); y None: out = a x"""
+
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        import ctypes as C
+        x = x.contiguous().float()
+        y = y.contiguous().float() if y is not None else None
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _hip_unary("cips_axpby", C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()) if y is not None else None,
+                       C.c_void_p(out.data_ptr()), a, b, x.numel())
+        ctx.ab, ctx.has_y = (a, b), y is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.ab
+        gx = _BlendFunction.apply(g, None, a, 0.0) if ctx.needs_input_grad[0] else None
+        gy = _BlendFunction.apply(g, None, b, 0.0) if (ctx.has_y and ctx.needs_input_grad[1]) else None
+        return gx, gy, None, None
+
+
 class Discriminator_MultiScale(nn.Module):
     """discriminator.py:406-585"""
 
@@ -724,9 +826,14 @@ class Discriminator_MultiScale(nn.Module):
         cur = self.conv_in[f"{2 ** log_size}"](input)
         cur = self.convs[f"{2 ** log_size}"](cur)
         if alpha < 1:
-            down_input = F.interpolate(input, scale_factor=0.5, mode='bilinear')
-            down = self.conv_in[f"{2 ** (log_size - 1)}"](down_input)
-            out = alpha * cur + (1 - alpha) * down
+            if input.is_cuda and input.shape[-1] % 2 == 0 and input.shape[-2] % 2 == 0:
+                down_input = _AvgPool2Function.apply(input, False)       # = F.interpolate(input, 0.5, 'bilinear') on even sizes
+                down = self.conv_in[f"{2 ** (log_size - 1)}"](down_input)
+                out = _BlendFunction.apply(cur, down, float(alpha), float(1 - alpha))
+            else:
+                down_input = F.interpolate(input, scale_factor=0.5, mode='bilinear')
+                down = self.conv_in[f"{2 ** (log_size - 1)}"](down_input)
+                out = alpha * cur + (1 - alpha) * down
         else:
             out = cur
         for i in range(log_size - 1, 2, -1):

@@ -419,6 +419,20 @@ int cips_upfirdn2d(const float* input, const float* kernel, float* out,
                    int up_x, int up_y, int down_x, int down_y,
                    int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream);
 
+/* DiffAugment with policy 'color,translation,cutout' (exp/cips3d/models/diffaug.py:9-85; applied to every discriminator
+ * input, exp/cips3d/models/discriminator.py:507-508) as one affine operator and its adjoint.  rb, rs, rc: the (B) raw
+ * uniform draws of brightness / saturation / contrast; tx, ty, ox, oy: the (B) int64 draws of translation and cutout
+ * centre, all made by the host with the reference's calls.  x, y (B, C <= 4, H, W); sums: (B) floats of scratch.
+ * adjoint 0: y = A x + c (affine != 0) or y = A x (affine == 0); adjoint 1: y = A^T x (the backward; its own backward
+ * is the forward with affine == 0: the R1 double-backward of train.py:387-394).  cut_h / cut_w = int(size * 0.2 + 0.5). */
+int cips_diffaug(const float* x, float* y, const float* rb, const float* rs, const float* rc, const long long* tx,
+                 const long long* ty, const long long* ox, const long long* oy, float* sums, int B, int C, int H, int W,
+                 int cut_h, int cut_w, int adjoint, int affine, cips_stream_t stream);
+/* Progressive fade-in (discriminator.py:524-534): the 2x2 mean that F.interpolate(scale_factor=0.5, 'bilinear') computes
+ * on even sizes (adjoint 1: its transpose, 0.25 g to the four sources), and out = a x + b y (y may be NULL). */
+int cips_avgpool2(const float* x, float* y, long long planes, int H, int W, int adjoint, cips_stream_t stream);
+int cips_axpby(const float* x, const float* y, float* out, float a, float b, long long n, cips_stream_t stream);
+
 /* FID path: float image (B, C <= 4, H, W) -> uint8 pixels (B, H, W, C) exactly as torchvision.utils.save_image(img,
  * normalize=True, value_range=(lo, hi)) quantises them before JPEG encoding (exp/cips3d/scripts/gen_images.py:56-60;
  * torchvision/utils.py make_grid norm_ip + save_image): clamp to [lo, hi], (x - lo) * (1 / max(hi - lo, 1e-5)),

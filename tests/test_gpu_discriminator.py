@@ -158,3 +158,68 @@ def test_discriminator_matches_reference_golden(tag, conv_mode, monkeypatch):
     if flips:
         o64, g64, grads64, _ = _d_oracle64(fix, own)
     check(out, grad_real, loss, grads, o64.float(), g64.float(), grads64, "free-running (vs fp64 oracle at the product's gates)", False)
+
+
+def test_diffaugment_hip_operator_matches_reference_golden_and_torch():
+    """The fused DiffAugment operator (cips_diffaug: forward, adjoint, and — the forward without its constant — the
+    adjoint's backward) against (1) the vectors minted from the reference with its recorded draws (output and input
+    gradient) and (2) the op-by-op torch restatement through a double-backward: an R1-style penalty on the input
+    gradient, differentiated w.r.t. a parameter that scales the input."""
+    from conftest import ReplayDraws
+    from cips3d_amd import discriminator as dm
+    d = torch.device("cuda:0")
+    case = [c for c in load_golden("diffaug_cases") if c["policy"] == "color,translation,cutout"][0]
+    x = case["x"].to(d).requires_grad_(True)
+    with ReplayDraws(case["draws"]):
+        y = dm.DiffAugment(x, policy=case["policy"])
+    assert y.shape == case["y"].shape and max_rel(y, case["y"]) < 1e-6
+    gx, = torch.autograd.grad((y * case["g0"].to(d)).sum(), x)
+    assert max_rel(gx, case["gx"]) < 1e-6
+
+    def penalty(fused):
+        old = dm.DIFFAUG_HIP
+        dm.DIFFAUG_HIP = fused
+        try:
+            w = torch.tensor(0.7, device=d, requires_grad=True)
+            xi = case["x"].to(d).requires_grad_(True)
+            with ReplayDraws(case["draws"]):
+                yy = dm.DiffAugment(xi * w, policy=case["policy"])
+            out = (yy * yy * case["g0"].to(d)).sum()                 # nonlinear in y: the input gradient depends on w
+            g, = torch.autograd.grad(out, xi, create_graph=True)
+            pen = g.pow(2).sum()
+            gw, = torch.autograd.grad(pen, w)
+            return float(out), g.detach(), float(gw)
+        finally:
+            dm.DIFFAUG_HIP = old
+
+    o1, g1, w1 = penalty(True)
+    o0, g0, w0 = penalty(False)
+    assert abs(o1 - o0) <= 1e-5 * abs(o0) and max_rel(g1, g0) < 1e-5 and abs(w1 - w0) <= 1e-4 * abs(w0), (o1, o0, w1, w0)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (3, 3, 64, 32)])
+def test_fade_in_ops_match_torch(shape):
+    """the 2x2 mean standing in for F.interpolate(scale_factor=0.5, mode='bilinear') (discriminator.py:525), its
+    transpose, and the blend alpha * cur + (1 - alpha) * down — values and first / second derivatives"""
+    from cips3d_amd import discriminator as dm
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(shape[2])
+    x = torch.randn(*shape, generator=g)
+    ref = torch.nn.functional.interpolate(x, scale_factor=0.5, mode="bilinear")
+    xd = x.to(d).requires_grad_(True)
+    y = dm._AvgPool2Function.apply(xd, False)
+    assert torch.equal(y.cpu(), ref)
+    up = torch.randn(ref.shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.interpolate(xr, scale_factor=0.5, mode="bilinear")
+    gr, = torch.autograd.grad((yr * yr * up).sum(), xr, create_graph=True)
+    gr.pow(2).sum().backward()
+    gd, = torch.autograd.grad((y * y * up.to(d)).sum(), xd, create_graph=True)
+    gd.pow(2).sum().backward()
+    assert max_rel(gd, gr) < 1e-6 and max_rel(xd.grad, xr.grad) < 1e-6
+    a = torch.randn(*ref.shape, generator=g); b = torch.randn(*ref.shape, generator=g)
+    ad, bd = a.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    out = dm._BlendFunction.apply(ad, bd, 0.3, 0.7)
+    assert torch.equal(out.cpu(), 0.3 * a + 0.7 * b)
+    ga, gb = torch.autograd.grad((out * up.to(d)).sum(), (ad, bd))
+    assert torch.equal(ga.cpu(), 0.3 * up) and torch.equal(gb.cpu(), 0.7 * up)
