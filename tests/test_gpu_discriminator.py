@@ -208,7 +208,7 @@ def test_fade_in_ops_match_torch(shape):
     ref = torch.nn.functional.interpolate(x, scale_factor=0.5, mode="bilinear")
     xd = x.to(d).requires_grad_(True)
     y = dm._AvgPool2Function.apply(xd, False)
-    assert torch.equal(y.cpu(), ref)
+    assert max_rel(y, ref) < 1e-6           # (ATen's CPU kernel associates the four products differently: 1 ulp)
     up = torch.randn(ref.shape, generator=g)
     xr = x.clone().requires_grad_(True)
     yr = torch.nn.functional.interpolate(xr, scale_factor=0.5, mode="bilinear")
@@ -220,6 +220,6 @@ def test_fade_in_ops_match_torch(shape):
     a = torch.randn(*ref.shape, generator=g); b = torch.randn(*ref.shape, generator=g)
     ad, bd = a.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
     out = dm._BlendFunction.apply(ad, bd, 0.3, 0.7)
-    assert torch.equal(out.cpu(), 0.3 * a + 0.7 * b)
+    assert max_rel(out, 0.3 * a + 0.7 * b) < 1e-6
     ga, gb = torch.autograd.grad((out * up.to(d)).sum(), (ad, bd))
-    assert torch.equal(ga.cpu(), 0.3 * up) and torch.equal(gb.cpu(), 0.7 * up)
+    assert max_rel(ga, 0.3 * up) < 1e-6 and max_rel(gb, 0.7 * up) < 1e-6
