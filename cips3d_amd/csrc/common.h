@@ -70,6 +70,15 @@ __device__ __forceinline__ float film_sin(float x) {
   if (HW) return __builtin_amdgcn_sinf(r * CIPS_INV_2PI);
   float s, c; sincos_reduced(r, &s, &c); return s;
 }
+// Forward chain of the split-bf16 kernels: one multiply to revolutions + v_fract_f32 + v_sin_f32 (3 instructions
+// instead of 6).  |arg| is tens of radians: the product's rounding is <= 6e-6 rad, an order of magnitude below what the
+// 3-pass bf16 pre-activations carry (~5e-6 relative of arguments that large); the exact-fp32 kernels keep the
+// two-term Cody-Waite reduction.
+template <bool HW>
+__device__ __forceinline__ float film_sin_x3(float x) {
+  if (HW) return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * CIPS_INV_2PI));
+  float s, c; sincos_reduced(reduce_2pi(x), &s, &c); return s;
+}
 template <bool HW>
 __device__ __forceinline__ void film_sincos(float x, float* s, float* c) {
   float r = reduce_2pi(x);

@@ -109,9 +109,11 @@ __global__ __launch_bounds__(256) void glin_fwd_kernel(GLJobs J, int B, float ou
   }
 }
 
-// dw[o][i] = sum_b dy[b][o] x[b][i];  db[o] = sum_b dy[b][o].  Thread = one i (16-byte column group), the x column in
-// registers, dy[b][o] uniform per workgroup row -> scalar operand; 16 outputs per workgroup.
+// dw[o][i] = sum_b dy[b][o] x[b][i];  db[o] = sum_b dy[b][o].  Thread = one 16-byte column group of x, held in
+// registers for 32 batch rows at a time; the workgroup's dy tile (32 rows x 16 outputs) sits in LDS and is read as
+// broadcasts; 16 outputs per workgroup.
 __global__ __launch_bounds__(128) void glin_bwd_w_kernel(GLJobs J, int B) {
+  __shared__ float dys[GL_ROWS][16];
   const int job = find_job(J, blockIdx.x);
   const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
   const int o0 = (blockIdx.x - J.tile0[job]) * 16;
@@ -119,51 +121,82 @@ __global__ __launch_bounds__(128) void glin_bwd_w_kernel(GLJobs J, int B) {
   const float* __restrict__ dy = J.dy[job];
   const int i4 = threadIdx.x;                                       // in_dim / 4 <= 128
   const bool on = i4 < in_dim / 4;
-  for (int oo = 0; oo < 16; ++oo) {
-    const int o = o0 + oo;
-    if (o >= out_dim) break;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float sb = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float g = dy[(long long)b * out_dim + o];
-      sb += g;
-      if (on) {
-        const float4 xv = reinterpret_cast<const float4*>(x + (long long)b * in_dim)[i4];
-        acc.x = fmaf(g, xv.x, acc.x); acc.y = fmaf(g, xv.y, acc.y); acc.z = fmaf(g, xv.z, acc.z); acc.w = fmaf(g, xv.w, acc.w);
+  float4 acc[16];
+  float sb[16];
+#pragma unroll
+  for (int oo = 0; oo < 16; ++oo) { acc[oo] = make_float4(0.f, 0.f, 0.f, 0.f); sb[oo] = 0.f; }
+  for (int b0 = 0; b0 < B; b0 += GL_ROWS) {
+    const int nb = min(GL_ROWS, B - b0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < GL_ROWS * 16; e += 128) {
+      const int r = e >> 4, oo = e & 15;
+      dys[r][oo] = (r < nb && o0 + oo < out_dim) ? dy[(long long)(b0 + r) * out_dim + o0 + oo] : 0.f;
+    }
+    __syncthreads();
+    for (int r = 0; r < nb; ++r) {                                  // (dys rows >= nb are zero; x rows are only read below nb)
+      const float4 xv = on ? reinterpret_cast<const float4*>(x + (long long)(b0 + r) * in_dim)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int oo = 0; oo < 16; ++oo) {
+        const float g = dys[r][oo];
+        sb[oo] += g;
+        acc[oo].x = fmaf(g, xv.x, acc[oo].x); acc[oo].y = fmaf(g, xv.y, acc[oo].y);
+        acc[oo].z = fmaf(g, xv.z, acc[oo].z); acc[oo].w = fmaf(g, xv.w, acc[oo].w);
       }
     }
-    if (on) reinterpret_cast<float4*>(J.dw[job] + (long long)o * in_dim)[i4] = acc;
-    if (threadIdx.x == 0 && J.db[job]) J.db[job][o] = sb;
+  }
+#pragma unroll
+  for (int oo = 0; oo < 16; ++oo) {
+    const int o = o0 + oo;
+    if (o < out_dim) {
+      if (on) reinterpret_cast<float4*>(J.dw[job] + (long long)o * in_dim)[i4] = acc[oo];
+      if (threadIdx.x == 0 && J.db[job]) J.db[job][o] = sb[oo];
+    }
   }
 }
 
 // dx partials: part[chunk][b][i] = sum over the chunk's (job, o) pairs of dy[b][o] w[o][i]; chunk = 64 outputs of one
-// job; thread = 4 consecutive i, 32 batch rows in registers.  All jobs of a launch share x (same in_dim).
+// job; thread = 4 consecutive i, 32 batch rows in registers, the chunk's dy tile (32 x 64) in LDS (broadcast reads of 4
+// outputs at a time).  All jobs of a launch share x (same in_dim).
 __global__ __launch_bounds__(128) void glin_bwd_x_kernel(GLJobs J, int B, int in_dim, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float dys[GL_ROWS][64];
   const int job = find_job(J, blockIdx.x);
   const int out_dim = J.out_dim[job];
   const int o0 = (blockIdx.x - J.tile0[job]) * 64;
   const float* __restrict__ w = J.w[job];
   const float* __restrict__ dy = J.dy[job];
   const int i4 = threadIdx.x;
-  if (i4 >= in_dim / 4) return;
+  const bool on = i4 < in_dim / 4;
   for (int b0 = 0; b0 < B; b0 += GL_ROWS) {
     const int nb = min(GL_ROWS, B - b0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < GL_ROWS * 64; e += 128) {
+      const int r = e >> 6, oo = e & 63;
+      dys[r][oo] = (r < nb && o0 + oo < out_dim) ? dy[(long long)(b0 + r) * out_dim + o0 + oo] : 0.f;
+    }
+    __syncthreads();
     float4 acc[GL_ROWS];
 #pragma unroll
     for (int r = 0; r < GL_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int oend = min(o0 + 64, out_dim);
-    for (int o = o0; o < oend; ++o) {
-      const float4 wv = reinterpret_cast<const float4*>(w + (long long)o * in_dim)[i4];
+    const int oend = min(64, out_dim - o0);
+    for (int oo = 0; oo < oend; oo += 4) {
+      float4 wv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        wv[q] = (on && oo + q < oend) ? reinterpret_cast<const float4*>(w + (long long)(o0 + oo + q) * in_dim)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int r = 0; r < GL_ROWS; ++r) {
-        const float g = (r < nb) ? dy[(long long)(b0 + r) * out_dim + o] : 0.f;
-        acc[r].x = fmaf(g, wv.x, acc[r].x); acc[r].y = fmaf(g, wv.y, acc[r].y);
-        acc[r].z = fmaf(g, wv.z, acc[r].z); acc[r].w = fmaf(g, wv.w, acc[r].w);
+        const float4 g = *reinterpret_cast<const float4*>(&dys[r][oo]);
+        acc[r].x = fmaf(g.x, wv[0].x, fmaf(g.y, wv[1].x, fmaf(g.z, wv[2].x, fmaf(g.w, wv[3].x, acc[r].x))));
+        acc[r].y = fmaf(g.x, wv[0].y, fmaf(g.y, wv[1].y, fmaf(g.z, wv[2].y, fmaf(g.w, wv[3].y, acc[r].y))));
+        acc[r].z = fmaf(g.x, wv[0].z, fmaf(g.y, wv[1].z, fmaf(g.z, wv[2].z, fmaf(g.w, wv[3].z, acc[r].z))));
+        acc[r].w = fmaf(g.x, wv[0].w, fmaf(g.y, wv[1].w, fmaf(g.z, wv[2].w, fmaf(g.w, wv[3].w, acc[r].w))));
       }
     }
-    for (int r = 0; r < nb; ++r)
-      reinterpret_cast<float4*>(part + ((long long)blockIdx.x * B + b0 + r) * in_dim)[i4] = acc[r];
+    if (on) {
+#pragma unroll
+      for (int r = 0; r < GL_ROWS; ++r)                             // (constant indices: acc stays in registers)
+        if (r < nb) reinterpret_cast<float4*>(part + ((long long)blockIdx.x * B + b0 + r) * in_dim)[i4] = acc[r];
+    }
   }
 }
 

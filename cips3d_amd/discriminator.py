@@ -598,6 +598,9 @@ class ResBlock(nn.Module):
     def forward(self, input):
         out = self.conv2(self.conv1(input))
         skip = self.skip(input)
+        if out.is_cuda:
+            c = 1.0 / math.sqrt(2)
+            return _BlendFunction.apply(out, skip, c, c)         # (out + skip) / sqrt(2) in one pass (cips_axpby)
         return (out + skip) / math.sqrt(2)
 
 
@@ -778,7 +781,10 @@ class _BlendFunction(Function):
     def backward(ctx, g):
         a, b = ctx.ab
         gx = _BlendFunction.apply(g, None, a, 0.0) if ctx.needs_input_grad[0] else None
-        gy = _BlendFunction.apply(g, None, b, 0.0) if (ctx.has_y and ctx.needs_input_grad[1]) else None
+        if ctx.has_y and ctx.needs_input_grad[1]:
+            gy = gx if (gx is not None and a == b) else _BlendFunction.apply(g, None, b, 0.0)    # same scale: one pass
+        else:
+            gy = None
         return gx, gy, None, None
 
 
