@@ -235,9 +235,35 @@ def _implicit_ok(C, N, O):
 
 # NHWC planes of an activation / gradient are shared between the convolution ops that read the same tensor inside ONE
 # autograd node (dy feeds both the data and the weight gradient; the forward's planes of x feed its weight gradient):
-# a memo that only lives while that node's backward runs, keyed by the tensor's storage address and shape.
-_shared = {}
-_sharing = [0]
+# a memo that only lives while that node's forward / backward runs.  It is per thread (autograd runs backward nodes
+# on its own threads) and every entry holds the SOURCE tensor as well as its planes: while the memo is alive the
+# source's storage cannot be freed and handed to another tensor of the same shape, so the (address, shape, version) key
+# cannot alias stale planes.
+import threading as _threading
+_tls = _threading.local()
+
+
+def _memo():
+    if not hasattr(_tls, "shared"):
+        _tls.shared, _tls.depth = {}, 0
+    return _tls
+
+
+def _key(t):
+    return (t.data_ptr(), tuple(t.shape), t._version)
+
+
+class _Shared:
+    """dict-like view used by the Functions below: key -> planes"""
+
+    @staticmethod
+    def get(key_or_tensor):
+        m = _memo()
+        ent = m.shared.get(key_or_tensor)
+        return ent[1] if ent is not None else None
+
+
+_shared = _Shared()
 
 
 class _share_planes:
@@ -245,24 +271,28 @@ class _share_planes:
         self.pairs = pairs
 
     def __enter__(self):
-        _sharing[0] += 1
+        m = _memo()
+        m.depth += 1
         for t, p in self.pairs:
             if p is not None:
-                _shared[(t.data_ptr(), tuple(t.shape))] = p
+                m.shared[_key(t)] = (t, p)
 
     def __exit__(self, *exc):
-        _sharing[0] -= 1
-        if _sharing[0] == 0:
-            _shared.clear()
+        m = _memo()
+        m.depth -= 1
+        if m.depth == 0:
+            m.shared.clear()
 
 
 def _nhwc(t):
-    key = (t.data_ptr(), tuple(t.shape))
-    p = _shared.get(key)
-    if p is None:
-        p = ops.split_planes_nhwc(t)
-        if _sharing[0]:
-            _shared[key] = p
+    m = _memo()
+    key = _key(t)
+    ent = m.shared.get(key)
+    if ent is not None:
+        return ent[1]
+    p = ops.split_planes_nhwc(t)
+    if m.depth:
+        m.shared[key] = (t, p)
     return p
 
 
@@ -435,7 +465,7 @@ class Conv2dFunction(Function):
         ctx.w_obj = w if isinstance(w, nn.Parameter) else None       # the Parameter object: the cache key
         with _share_planes():
             y = _conv_fwd(x, w, stride, pad, scale)
-            ctx.xP = _shared.get((x.data_ptr(), tuple(x.shape))) if ctx.needs_input_grad[1] else None
+            ctx.xP = _shared.get(_key(x)) if ctx.needs_input_grad[1] else None
         return y
 
     @staticmethod

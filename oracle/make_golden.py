@@ -368,6 +368,48 @@ def make_camera_cases():
     print("camera ->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_pigan_cases():
+    """Second, independent pin: the original pi-GAN implementations in
+    piGAN_lib/generators/volumetric_rendering.py — fancy_integration (:18-55, dim_rgb = 3), sample_pdf (:205-246),
+    get_initial_rays_trig + transform_sampled_points (:58-116) — run under captured draws.  exp/ carries its own copies of
+    these functions (exp/pigan/pigan_utils.py, exp/comm/comm_utils.py); the oracle and the HIP kernels are checked
+    against BOTH lineages."""
+    import importlib
+    vr = importlib.import_module("piGAN_lib.generators.volumetric_rendering")
+    torch.manual_seed(41)
+    out = dict(integrate=[], sample_pdf=[], rays=[])
+    b, n, S = 2, 40, 7
+    for clamp, noise_std, lb, wb in [("relu", 0.0, False, False), ("relu", 0.4, True, False), ("softplus", 0.2, False, True),
+                                     ("relu", 0.3, True, True)]:
+        rgb_sigma = torch.randn(b, n, S, 4) * torch.tensor([1., 1., 1., 4.])
+        z = torch.sort(0.88 + 0.24 * torch.rand(b, n, S, 1), dim=-2)[0]
+        with Capture() as cap:
+            rgb, depth, w = vr.fancy_integration(rgb_sigma, z, "cpu", noise_std=noise_std, last_back=lb, white_back=wb,
+                                                 clamp_mode=clamp)
+        (_, noise), = cap.draws
+        out["integrate"].append(dict(rgb_sigma=rgb_sigma, z=z, noise=noise, noise_std=noise_std, clamp=clamp, last_back=lb,
+                                     white_back=wb, rgb=rgb.clone(), depth=depth.clone(), weights=w.clone()))
+    for R, S_ in [(50, 12), (33, 5)]:
+        zz = torch.sort(0.88 + 0.24 * torch.rand(R, S_), dim=-1)[0]
+        bins = 0.5 * (zz[:, :-1] + zz[:, 1:])
+        weights = torch.rand(R, S_ - 2) ** 3
+        with Capture() as cap:
+            smp = vr.sample_pdf(bins, weights, S_, det=False)
+        (_, u), = cap.draws
+        out["sample_pdf"].append(dict(z=zz, bins=bins, weights=weights, u=u, samples=smp.clone()))
+    for (bb, img, S_) in [(2, 6, 5), (1, 9, 4)]:
+        pts, zv, dcam = vr.get_initial_rays_trig(bb, S_, "cpu", fov=12, resolution=(img, img), ray_start=0.88, ray_end=1.12)
+        with Capture() as cap:
+            tp, tz, td, to, pitch, yaw = vr.transform_sampled_points(pts, zv, dcam, "cpu", h_stddev=0.3, v_stddev=0.155,
+                                                                     h_mean=math.pi * 0.5, v_mean=math.pi * 0.5, mode="normal")
+        (_, jit), (_, th), (_, ph) = cap.draws
+        out["rays"].append(dict(b=bb, img=img, S=S_, jitter=jit, theta=th, phi=ph, points=tp.clone(), z=tz.clone(), dirs=td.clone(),
+                                origins=to.clone(), pitch=pitch.clone(), yaw=yaw.clone()))
+    path = os.path.join(OUT, "pigan_cases.pt")
+    torch.save(out, path)
+    print("pigan ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def make_op_cases():
     """Known-answer vectors for the two native ops from the reference's own restatement
     (upfirdn2d_native, upfirdn2d.py:152-186) and the kernel's switch (fused_bias_act_kernel.cu:36-47)."""
@@ -416,7 +458,12 @@ def make_rest():
     make_diffaug_case()
     make_camera_cases()
     make_op_cases()
+    make_pigan_cases()
 
 
 if __name__ == "__main__":
-    main("gates" if "gates" in sys.argv[1:] else "fixture")
+    if "pigan" in sys.argv[1:]:
+        os.makedirs(OUT, exist_ok=True)
+        make_pigan_cases()
+    else:
+        main("gates" if "gates" in sys.argv[1:] else "fixture")

@@ -825,3 +825,43 @@ def test_grouped_linear_forward_backward(B, in_dim, outs):
                 assert rel_err(l.bias.grad, ups[j].double().sum(0)) < 1e-6, j
         else:
             assert l.weight.grad is None or float(l.weight.grad.abs().max()) == 0.0
+
+
+def test_hip_kernels_match_pigan_lib_second_lineage():
+    """The HIP ray set-up, resampler and composite against vectors minted from the ORIGINAL pi-GAN implementations
+    (piGAN_lib/generators/volumetric_rendering.py; tests/golden/pigan_cases.pt) — the second lineage of SURVEY.md §8c,
+    independent of the exp/ copies the oracle restates."""
+    from cips3d_amd import ops
+    from cips3d_amd.generator import camera_origin_from_angles, create_cam2world_matrix, _normalize
+    d = dev()
+    fix = load_golden("pigan_cases")
+    for c in fix["rays"]:
+        b, img, S = c["b"], c["img"], c["S"]
+        theta = c["theta"].to(d) * 0.3 + math.pi * 0.5
+        phi = c["phi"].to(d) * 0.155 + math.pi * 0.5
+        origin, pitch = camera_origin_from_angles(theta, phi)
+        c2w = create_cam2world_matrix(_normalize(-origin), origin)
+        xg = torch.linspace(-1, 1, img, device=d); yg = torch.linspace(1, -1, img, device=d); zg = torch.linspace(0.88, 1.12, S, device=d)
+        zc = float((-torch.ones(1) / torch.tan(torch.tensor((2 * math.pi * 12 / 360) / 2))).item())
+        pts, z, dirs = ops.rays_fwd(xg, yg, zg, zc, c2w, c["jitter"].to(d).reshape(b, img * img, S), b, img, img, S)
+        assert max_rel(pts, c["points"]) < 1e-5 and max_rel(z, c["z"].squeeze(-1)) < 1e-6 and max_rel(dirs, c["dirs"]) < 1e-5
+        assert max_rel(pitch, c["pitch"]) < 1e-6
+    for c in fix["sample_pdf"]:
+        R, S = c["z"].shape
+        cdf = orc.sample_pdf(c["bins"], c["weights"], c["u"])[1]["cdf"]
+        zero = torch.zeros(R, S, device=d)
+        fz, _ = ops.resample_fwd(zero, c["z"].to(d), None, 0.0, c["u"].to(d), torch.zeros(1, 3, device=d), torch.zeros(R, 3, device=d), 1, R, S,
+                                 0, cdf_in=cdf.to(d))
+        assert max_rel(fz, c["samples"]) < 1e-6
+    for c in fix["integrate"]:
+        b, n, S, _ = c["rgb_sigma"].shape
+        feat = torch.zeros(b * n, S, 32); feat[..., :3] = c["rgb_sigma"][..., :3].reshape(b * n, S, 3)
+        sig = c["rgb_sigma"][..., 3].reshape(b * n, S)
+        flags = (1 if c["last_back"] else 0) | (2 if c["white_back"] else 0)
+        fea, depth, w, order, zs = ops.CompositeFunction.apply(
+            feat.to(d), sig.to(d), c["z"].reshape(b * n, S).to(d), None, None, None,
+            c["noise"].reshape(b * n, S).to(d) if c["noise_std"] else None, c["noise_std"], ops._CLAMP[c["clamp"]], flags)
+        assert max_rel(fea[:, :3], c["rgb"].reshape(b * n, 3)) < 1e-5 and max_rel(depth, c["depth"].reshape(-1)) < 1e-5
+        assert max_rel(w, c["weights"].reshape(b * n, S)) < 1e-5
+        if flags == 2:      # (with last_back the returned weights already carry the top-up)
+            assert max_rel(fea[:, 3:], (1 - c["weights"].sum(2)).reshape(b * n, 1).expand(-1, 29)) < 1e-4

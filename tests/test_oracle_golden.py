@@ -171,3 +171,23 @@ def test_camera_distributions_match_reference():
         assert max_rel(o, c["origin"]) < 1e-6 and max_rel(phi, c["phi"]) < 1e-6 and max_rel(theta, c["theta"]) < 1e-6, c["mode"]
     with pytest.raises(AssertionError):
         sample_camera_positions("cpu", mode=None)
+
+
+def test_oracle_matches_pigan_lib_second_lineage():
+    """Second, independent pin: vectors minted from the ORIGINAL pi-GAN implementations in
+    piGAN_lib/generators/volumetric_rendering.py (fancy_integration with 3 colour channels, sample_pdf,
+    get_initial_rays_trig + transform_sampled_points) — the oracle restates the exp/ copies of these functions and
+    must reproduce the other lineage too."""
+    fix = load_golden("pigan_cases")
+    for c in fix["integrate"]:
+        rgb, depth, w = orc.integrate(c["rgb_sigma"], c["z"], c["noise"], c["noise_std"], dim_rgb=3, clamp_mode=c["clamp"],
+                                      last_back=c["last_back"], white_back=c["white_back"])
+        assert torch.equal(rgb, c["rgb"]) and torch.equal(depth, c["depth"]) and torch.equal(w, c["weights"])
+    for c in fix["sample_pdf"]:
+        smp, book = orc.sample_pdf(c["bins"], c["weights"], c["u"])
+        assert torch.equal(smp, c["samples"])
+    for c in fix["rays"]:
+        r = orc.rays(c["b"], c["img"], 12, 0.88, 1.12, c["S"], c["jitter"], c["theta"], c["phi"], 0.3, 0.155)
+        assert torch.equal(r["points"], c["points"]) and torch.equal(r["z"], c["z"])
+        assert torch.equal(r["dirs"], c["dirs"]) and torch.equal(r["origins"], c["origins"])
+        assert torch.equal(r["pitch"], c["pitch"]) and torch.equal(r["yaw"], c["yaw"])
