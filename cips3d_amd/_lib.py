@@ -133,6 +133,8 @@ SIGNATURES = {
     "cips_grouped_linear_fwd": (i32, [C.POINTER(GlinJob), i32, i32, vp]),
     "cips_grouped_linear_scratch": (i64, [C.POINTER(GlinJob), i32, i32]),
     "cips_grouped_linear_bwd": (i32, [C.POINTER(GlinJob), i32, i32, vp, vp, i64, vp]),
+    "cips_rownorm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "cips_rownorm_bwd": (i32, [vp] * 9 + [i32, i32, i32, f32, vp]),
     "cips_torgb_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
     "cips_torgb_bwd_partials": (i32, [i64]),
     "cips_torgb_bwd_w": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),

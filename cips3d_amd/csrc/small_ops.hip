@@ -224,6 +224,142 @@ int fill(GLJobs& J, const cips_glin_job* jobs, int njobs, int outs_per_tile) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Row-wise normalisation + activation of the two z -> style mapping MLPs (exp/cips3d/models/multi_head_mapping.py:13-19
+// PixelNorm, :62-84 [Linear, LayerNorm, LeakyReLU(0.2)] x L): one workgroup per batch row, the row in registers.
+//   mode bit 0: LayerNorm (biased variance, eps 1e-5, affine gamma / beta) | bit 1: LeakyReLU(slope) after it
+//   mode bit 2: PixelNorm  y = x * rsqrt(mean(x^2) + 1e-8)  (no affine, no activation)
+// stats (rows, 2): [mean, rstd] (LayerNorm) or [unused, r] (PixelNorm), kept for the backward.
+constexpr int RN_MAXC = 1024;
+
+__device__ __forceinline__ float rn_block_sum(float v, float* red) {
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int s_ = 128; s_ > 0; s_ >>= 1) {
+    if (t < s_) red[t] += red[t + s_];
+    __syncthreads();
+  }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          float* __restrict__ stats, int cols, int mode, float slope) {
+  __shared__ float red[256];
+  const int row = blockIdx.x, t = threadIdx.x;
+  const float* xr = x + (long long)row * cols;
+  float v[RN_MAXC / 256];
+#pragma unroll
+  for (int q = 0; q < RN_MAXC / 256; ++q) v[q] = (t + 256 * q < cols) ? xr[t + 256 * q] : 0.f;
+  float out[RN_MAXC / 256];
+  if (mode & 4) {
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < RN_MAXC / 256; ++q) ss = fmaf(v[q], v[q], ss);
+    const float r = rsqrtf(rn_block_sum(ss, red) / (float)cols + 1e-8f);
+#pragma unroll
+    for (int q = 0; q < RN_MAXC / 256; ++q) out[q] = v[q] * r;
+    if (t == 0) { stats[2 * row] = 0.f; stats[2 * row + 1] = r; }
+  } else {
+    float mean = 0.f, rstd = 1.f;
+    if (mode & 1) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < RN_MAXC / 256; ++q) s1 += v[q];
+      mean = rn_block_sum(s1, red) / (float)cols;
+      float s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < RN_MAXC / 256; ++q) { const float dlt = (t + 256 * q < cols) ? v[q] - mean : 0.f; s2 = fmaf(dlt, dlt, s2); }
+      rstd = rsqrtf(rn_block_sum(s2, red) / (float)cols + 1e-5f);
+    }
+#pragma unroll
+    for (int q = 0; q < RN_MAXC / 256; ++q) {
+      const int c = t + 256 * q;
+      float o = v[q];
+      if ((mode & 1) && c < cols) o = (v[q] - mean) * rstd * gamma[c] + beta[c];
+      if (mode & 2) o = o > 0.f ? o : o * slope;
+      out[q] = o;
+    }
+    if (t == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  }
+#pragma unroll
+  for (int q = 0; q < RN_MAXC / 256; ++q)
+    if (t + 256 * q < cols) y[(long long)row * cols + t + 256 * q] = out[q];
+}
+
+// dx for one row; dyhat (rows, cols) = dL/d(gamma * xhat + beta) is written for the column reductions of d gamma / d beta
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ yout,
+                                                          const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                          const float* __restrict__ dy, float* __restrict__ dx,
+                                                          float* __restrict__ dyhat, int cols, int mode, float slope) {
+  __shared__ float red[256];
+  const int row = blockIdx.x, t = threadIdx.x;
+  const long long base = (long long)row * cols;
+  float xv[RN_MAXC / 256], g[RN_MAXC / 256];
+#pragma unroll
+  for (int q = 0; q < RN_MAXC / 256; ++q) {
+    const int c = t + 256 * q;
+    const bool ok = c < cols;
+    xv[q] = ok ? x[base + c] : 0.f;
+    float gg = ok ? dy[base + c] : 0.f;
+    if ((mode & 2) && ok) gg *= (yout[base + c] > 0.f) ? 1.f : slope;      // gate from the stored output (same sign)
+    g[q] = gg;
+  }
+  if (mode & 4) {                     // y = x r: dx = r (dy - y mean(dy y))
+    const float r = stats[2 * row + 1];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < RN_MAXC / 256; ++q) s = fmaf(g[q], xv[q] * r, s);
+    const float m = rn_block_sum(s, red) / (float)cols;
+#pragma unroll
+    for (int q = 0; q < RN_MAXC / 256; ++q)
+      if (t + 256 * q < cols) dx[base + t + 256 * q] = r * (g[q] - xv[q] * r * m);
+    return;
+  }
+  if (!(mode & 1)) {                  // activation only
+#pragma unroll
+    for (int q = 0; q < RN_MAXC / 256; ++q)
+      if (t + 256 * q < cols) dx[base + t + 256 * q] = g[q];
+    return;
+  }
+  const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  float xh[RN_MAXC / 256], gx[RN_MAXC / 256], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < RN_MAXC / 256; ++q) {
+    const int c = t + 256 * q;
+    const bool ok = c < cols;
+    xh[q] = ok ? (xv[q] - mean) * rstd : 0.f;
+    gx[q] = ok ? g[q] * gamma[c] : 0.f;
+    if (ok) dyhat[base + c] = g[q];
+    s1 += gx[q];
+    s2 = fmaf(gx[q], xh[q], s2);
+  }
+  const float m1 = rn_block_sum(s1, red) / (float)cols;
+  const float m2 = rn_block_sum(s2, red) / (float)cols;
+#pragma unroll
+  for (int q = 0; q < RN_MAXC / 256; ++q)
+    if (t + 256 * q < cols) dx[base + t + 256 * q] = rstd * (gx[q] - m1 - xh[q] * m2);
+}
+
+// d gamma[c] = sum_rows dyhat * xhat, d beta[c] = sum_rows dyhat  (fixed order)
+__global__ __launch_bounds__(256) void rownorm_bwd_affine_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                 const float* __restrict__ dyhat, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, int rows, int cols) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f, b = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    const float g = dyhat[(long long)r * cols + c];
+    a = fmaf(g, (x[(long long)r * cols + c] - stats[2 * r]) * stats[2 * r + 1], a);
+    b += g;
+  }
+  dgamma[c] = a; dbeta[c] = b;
+}
+
 }  // namespace
 
 extern "C" int cips_grouped_linear_max_jobs(void) { return GL_MAX; }
@@ -271,4 +407,24 @@ extern "C" long long cips_grouped_linear_scratch(const cips_glin_job* jobs, int 
   long long chunks = 0;
   for (int j = 0; j < njobs; ++j) chunks += (jobs[j].out_dim + 63) / 64;
   return chunks * B * jobs[0].in_dim;
+}
+
+extern "C" int cips_rownorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int rows,
+                                int cols, int mode, float slope, cips_stream_t stream) {
+  if (!x || !y || !stats || rows <= 0 || cols <= 0 || cols > RN_MAXC || ((mode & 1) && (!gamma || !beta)) || ((mode & 4) && (mode & 3)))
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(rownorm_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, stats, cols, mode, slope);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_rownorm_bwd(const float* x, const float* y, const float* gamma, const float* stats, const float* dy,
+                                float* dx, float* dyhat, float* dgamma, float* dbeta, int rows, int cols, int mode, float slope,
+                                cips_stream_t stream) {
+  if (!x || !y || !stats || !dy || !dx || rows <= 0 || cols <= 0 || cols > RN_MAXC || ((mode & 4) && (mode & 3))) return (int)hipErrorInvalidValue;
+  if ((mode & 1) && (!gamma || !dyhat || !dgamma || !dbeta)) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(rows), dim3(256), 0, st, x, y, gamma, stats, dy, dx, dyhat, cols, mode, slope);
+  if (mode & 1)
+    hipLaunchKernelGGL(rownorm_bwd_affine_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, x, stats, dyhat, dgamma, dbeta, rows, cols);
+  return CIPS_CHECK_LAUNCH();
 }

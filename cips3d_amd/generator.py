@@ -100,10 +100,45 @@ class MultiHeadMappingNetwork(nn.Module):
                 head_net = nn.Identity()
             self.add_module(name, head_net)
 
+    def _base_hip(self, z):
+        """base_net on the HIP kernels: PixelNorm, then per layer the Linear (grouped-linear kernel, one job) and one
+        fused LayerNorm / LeakyReLU launch (cips_rownorm_*) instead of three torch modules"""
+        x = ops.RowNormFunction.apply(z, None, None, 4)
+        mods = list(self.base_net)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear):
+                x = ops.grouped_linear([(x, m)])[0]
+                i += 1
+                ln = mods[i] if i < len(mods) and isinstance(mods[i], nn.LayerNorm) else None
+                if ln is not None:
+                    i += 1
+                act = i < len(mods) and isinstance(mods[i], nn.LeakyReLU)
+                if act:
+                    i += 1
+                if ln is not None or act:
+                    x = ops.RowNormFunction.apply(x, ln.weight if ln is not None else None, ln.bias if ln is not None else None,
+                                                  (1 if ln is not None else 0) | (2 if act else 0))
+            else:               # anything else the constructor could have put here
+                x = m(x)
+                i += 1
+        return x
+
+    def _hip_ok(self, z):
+        # (large batches — the 10 000 latents of generate_avg_frequencies — stay on hipBLASLt: the row kernels are built for
+        # the few rows of a training batch)
+        return (ops.GROUPED_LINEAR and z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and z.shape[0] <= 256 and z.shape[1] <= 512 and z.shape[1] % 4 == 0
+                and all(not isinstance(m, nn.Linear) or (m.in_features <= 512 and m.in_features % 4 == 0 and m.out_features <= 1024)
+                        for m in self.base_net))
+
     def forward(self, z):
         if self.base_net is not None:
-            z = self.norm(z)
-            base_fea = self.base_net(z)
+            if self._hip_ok(z):
+                base_fea = self._base_hip(z)
+            else:
+                z = self.norm(z)
+                base_fea = self.base_net(z)
             head_inputs = {name: base_fea for name in self.head_dim_dict.keys()}
         else:
             head_inputs = {name: self.norm(z[idx]) for idx, name in enumerate(self.head_dim_dict.keys())}

@@ -433,7 +433,7 @@ def grouped_linear(pairs):
     mx = 32
     for idxs in groups.values():
         x = pairs[idxs[0]][0]
-        if x.dim() != 2 or x.shape[1] % 4 or x.shape[1] > 512 or not x.is_cuda:
+        if x.dim() != 2 or x.shape[1] % 4 or x.shape[1] > 512 or x.shape[0] > 256 or not x.is_cuda:
             for i in idxs:
                 out[i] = pairs[i][1](pairs[i][0])
             continue
@@ -447,6 +447,45 @@ def grouped_linear(pairs):
             for i, y in zip(chunk, ys):
                 out[i] = y
     return out
+
+
+# --------------------------------------------------------------------------------------
+# Row-wise normalisation + activation of the mapping MLPs
+# --------------------------------------------------------------------------------------
+class RowNormFunction(torch.autograd.Function):
+    """y = act(norm(x)) per batch row (cips_rownorm_fwd / _bwd): mode bit 0 LayerNorm(gamma, beta; eps 1e-5), bit 1
+    LeakyReLU(0.2) after it, bit 2 PixelNorm (multi_head_mapping.py:13-19, :62-84)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mode):
+        lib = _lib.load()
+        x = _c(x.detach())
+        gamma = _c(gamma.detach()) if gamma is not None else None
+        beta = _c(beta.detach()) if beta is not None else None
+        _chk(x, gamma, beta)
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(rows, 2, device=x.device)
+        check(lib.cips_rownorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), rows, cols, mode, LRELU_SLOPE, _stream()),
+              "cips_rownorm_fwd")
+        ctx.save_for_backward(x, y, gamma, stats)
+        ctx.mode = mode
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y, gamma, stats = ctx.saved_tensors
+        rows, cols = x.shape
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        ln = bool(ctx.mode & 1)
+        dyhat = torch.empty_like(x) if ln else None
+        dgamma = torch.empty(cols, device=x.device) if ln else None
+        dbeta = torch.empty(cols, device=x.device) if ln else None
+        check(lib.cips_rownorm_bwd(_p(x), _p(y), _p(gamma), _p(stats), _p(dy), _p(dx), _p(dyhat), _p(dgamma), _p(dbeta), rows,
+                                   cols, ctx.mode, LRELU_SLOPE, _stream()), "cips_rownorm_bwd")
+        return dx, dgamma, dbeta, None
 
 
 # --------------------------------------------------------------------------------------

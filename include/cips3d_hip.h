@@ -379,6 +379,17 @@ long long cips_grouped_linear_scratch(const cips_glin_job* jobs, int njobs, int 
 int cips_grouped_linear_bwd(const cips_glin_job* jobs, int njobs, int B, float* dx, float* scratch,
                             long long scratch_floats, cips_stream_t stream);
 
+/* Row-wise normalisation + activation of the z -> style mapping MLPs (exp/cips3d/models/multi_head_mapping.py:13-19
+ * PixelNorm; :62-84 LayerNorm / LeakyReLU(0.2) after every Linear).  x, y (rows, cols <= 1024); stats (rows, 2) scratch
+ * kept for the backward.  mode bit 0: LayerNorm (eps 1e-5, affine gamma / beta), bit 1: LeakyReLU(slope) after it,
+ * bit 2: PixelNorm y = x * rsqrt(mean(x^2) + 1e-8) (alone).  Backward: dx (and d gamma, d beta through the (rows, cols)
+ * scratch dyhat when bit 0 is set); `y` is the forward's output (the LeakyReLU gate is its sign). */
+int cips_rownorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int rows, int cols,
+                     int mode, float slope, cips_stream_t stream);
+int cips_rownorm_bwd(const float* x, const float* y, const float* gamma, const float* stats, const float* dy, float* dx,
+                     float* dyhat, float* dgamma, float* dbeta, int rows, int cols, int mode, float slope,
+                     cips_stream_t stream);
+
 /* ToRGB (generator.py:983-1006): rgb (M,3) (+)= x (M,K) @ w^T (3,K) + bias.
  * accumulate != 0: rgb += ...  */
 int cips_torgb_fwd(const float* x, const float* w, const float* bias, float* rgb,

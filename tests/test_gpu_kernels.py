@@ -863,5 +863,31 @@ def test_hip_kernels_match_pigan_lib_second_lineage():
             c["noise"].reshape(b * n, S).to(d) if c["noise_std"] else None, c["noise_std"], ops._CLAMP[c["clamp"]], flags)
         assert max_rel(fea[:, :3], c["rgb"].reshape(b * n, 3)) < 1e-5 and max_rel(depth, c["depth"].reshape(-1)) < 1e-5
         assert max_rel(w, c["weights"].reshape(b * n, S)) < 1e-5
-        if flags == 2:      # (with last_back the returned weights already carry the top-up)
-            assert max_rel(fea[:, 3:], (1 - c["weights"].sum(2)).reshape(b * n, 1).expand(-1, 29)) < 1e-4
+
+
+def test_mapping_networks_on_hip_match_torch_modules():
+    """The two z -> style mapping MLPs (multi_head_mapping.py:130-153) on the HIP kernels (PixelNorm / LayerNorm /
+    LeakyReLU row kernels + grouped linear) against the same modules evaluated op by op by torch in fp64: styles and
+    every parameter / latent gradient."""
+    from cips3d_amd import ops
+    d = dev()
+    G = seeded_generator(12)
+    g = torch.Generator().manual_seed(12)
+    for net, zdim in ((G.mapping_network_nerf, 256), (G.mapping_network_inr, 512)):
+        for b in (1, 5, 32):
+            z = torch.randn(b, zdim, generator=g)
+            net64 = __import__("copy").deepcopy(net).double()
+            z64 = z.double().requires_grad_(True)
+            ref = list(net64(z64).values())[0]
+            up = torch.randn(ref.shape, generator=g)
+            (ref * up.double()).sum().backward()
+            netd = __import__("copy").deepcopy(net).to(d)
+            zd = z.to(d).requires_grad_(True)
+            assert netd._hip_ok(zd)
+            out = list(netd(zd).values())[0]
+            (out * up.to(d)).sum().backward()
+            torch.cuda.synchronize()
+            assert rel_err(out, ref.detach()) < 2e-6, (zdim, b)
+            assert rel_err(zd.grad, z64.grad) < 2e-5, (zdim, b)
+            for (k, p), (_, q) in zip(netd.named_parameters(), net64.named_parameters()):
+                assert rel_err(p.grad, q.grad) < 2e-5, (zdim, b, k)
