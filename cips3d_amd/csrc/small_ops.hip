@@ -30,11 +30,11 @@ __device__ __forceinline__ int find_job(const GLJobs& J, int tile) {
 
 // y[b][o] = sum_i x[b][i] w[o][i] + bias[o].  One wave per 4 outputs: the lanes stride over i with 16-byte loads of the
 // weight row (coalesced) and of the x rows (LDS), 32 batch rows in registers, then a transpose-reduce over the lanes.
-__global__ __launch_bounds__(256) void glin_fwd_kernel(GLJobs J, int B, float out_scale_unused) {
+__global__ __launch_bounds__(256) void glin_fwd_kernel(GLJobs J, int B, int opw) {      // opw = outputs per wave (4 or 1)
   extern __shared__ __attribute__((aligned(16))) float xs[];       // [GL_ROWS][in_dim]
   const int job = find_job(J, blockIdx.x);
   const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
-  const int o0 = (blockIdx.x - J.tile0[job]) * 16;                  // 16 outputs per workgroup (4 waves x 4)
+  const int o0 = (blockIdx.x - J.tile0[job]) * 4 * opw;             // 4 waves x opw outputs per workgroup
   const float* __restrict__ x = J.x[job];
   const float* __restrict__ w = J.w[job];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void glin_fwd_kernel(GLJobs J, int B, float ou
                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    for (int oo = 0; oo < 4; ++oo) {
-      const int o = o0 + wave * 4 + oo;
+    for (int oo = 0; oo < opw; ++oo) {
+      const int o = o0 + wave * opw + oo;
       if (o >= out_dim) break;
       float acc[GL_ROWS];
 #pragma unroll
@@ -112,31 +112,32 @@ __global__ __launch_bounds__(256) void glin_fwd_kernel(GLJobs J, int B, float ou
 // dw[o][i] = sum_b dy[b][o] x[b][i];  db[o] = sum_b dy[b][o].  Thread = one 16-byte column group of x, held in
 // registers for 32 batch rows at a time; the workgroup's dy tile (32 rows x 16 outputs) sits in LDS and is read as
 // broadcasts; 16 outputs per workgroup.
+template <int OT>      // outputs per workgroup: 16, or 4 when the launch would otherwise have too few workgroups
 __global__ __launch_bounds__(128) void glin_bwd_w_kernel(GLJobs J, int B) {
-  __shared__ float dys[GL_ROWS][16];
+  __shared__ float dys[GL_ROWS][OT];
   const int job = find_job(J, blockIdx.x);
   const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
-  const int o0 = (blockIdx.x - J.tile0[job]) * 16;
+  const int o0 = (blockIdx.x - J.tile0[job]) * OT;
   const float* __restrict__ x = J.x[job];
   const float* __restrict__ dy = J.dy[job];
   const int i4 = threadIdx.x;                                       // in_dim / 4 <= 128
   const bool on = i4 < in_dim / 4;
-  float4 acc[16];
-  float sb[16];
+  float4 acc[OT];
+  float sb[OT];
 #pragma unroll
-  for (int oo = 0; oo < 16; ++oo) { acc[oo] = make_float4(0.f, 0.f, 0.f, 0.f); sb[oo] = 0.f; }
+  for (int oo = 0; oo < OT; ++oo) { acc[oo] = make_float4(0.f, 0.f, 0.f, 0.f); sb[oo] = 0.f; }
   for (int b0 = 0; b0 < B; b0 += GL_ROWS) {
     const int nb = min(GL_ROWS, B - b0);
     __syncthreads();
-    for (int e = threadIdx.x; e < GL_ROWS * 16; e += 128) {
-      const int r = e >> 4, oo = e & 15;
+    for (int e = threadIdx.x; e < GL_ROWS * OT; e += 128) {
+      const int r = e / OT, oo = e % OT;
       dys[r][oo] = (r < nb && o0 + oo < out_dim) ? dy[(long long)(b0 + r) * out_dim + o0 + oo] : 0.f;
     }
     __syncthreads();
     for (int r = 0; r < nb; ++r) {                                  // (dys rows >= nb are zero; x rows are only read below nb)
       const float4 xv = on ? reinterpret_cast<const float4*>(x + (long long)(b0 + r) * in_dim)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int oo = 0; oo < 16; ++oo) {
+      for (int oo = 0; oo < OT; ++oo) {
         const float g = dys[r][oo];
         sb[oo] += g;
         acc[oo].x = fmaf(g, xv.x, acc[oo].x); acc[oo].y = fmaf(g, xv.y, acc[oo].y);
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(128) void glin_bwd_w_kernel(GLJobs J, int B) {
     }
   }
 #pragma unroll
-  for (int oo = 0; oo < 16; ++oo) {
+  for (int oo = 0; oo < OT; ++oo) {
     const int o = o0 + oo;
     if (o < out_dim) {
       if (on) reinterpret_cast<float4*>(J.dw[job] + (long long)o * in_dim)[i4] = acc[oo];
@@ -157,11 +158,12 @@ __global__ __launch_bounds__(128) void glin_bwd_w_kernel(GLJobs J, int B) {
 // dx partials: part[chunk][b][i] = sum over the chunk's (job, o) pairs of dy[b][o] w[o][i]; chunk = 64 outputs of one
 // job; thread = 4 consecutive i, 32 batch rows in registers, the chunk's dy tile (32 x 64) in LDS (broadcast reads of 4
 // outputs at a time).  All jobs of a launch share x (same in_dim).
+template <int OC>      // outputs per chunk: 64, or 16 for launches of few chunks
 __global__ __launch_bounds__(128) void glin_bwd_x_kernel(GLJobs J, int B, int in_dim, float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float dys[GL_ROWS][64];
+  __shared__ __attribute__((aligned(16))) float dys[GL_ROWS][OC];
   const int job = find_job(J, blockIdx.x);
   const int out_dim = J.out_dim[job];
-  const int o0 = (blockIdx.x - J.tile0[job]) * 64;
+  const int o0 = (blockIdx.x - J.tile0[job]) * OC;
   const float* __restrict__ w = J.w[job];
   const float* __restrict__ dy = J.dy[job];
   const int i4 = threadIdx.x;
@@ -169,15 +171,15 @@ __global__ __launch_bounds__(128) void glin_bwd_x_kernel(GLJobs J, int B, int in
   for (int b0 = 0; b0 < B; b0 += GL_ROWS) {
     const int nb = min(GL_ROWS, B - b0);
     __syncthreads();
-    for (int e = threadIdx.x; e < GL_ROWS * 64; e += 128) {
-      const int r = e >> 6, oo = e & 63;
+    for (int e = threadIdx.x; e < GL_ROWS * OC; e += 128) {
+      const int r = e / OC, oo = e % OC;
       dys[r][oo] = (r < nb && o0 + oo < out_dim) ? dy[(long long)(b0 + r) * out_dim + o0 + oo] : 0.f;
     }
     __syncthreads();
     float4 acc[GL_ROWS];
 #pragma unroll
     for (int r = 0; r < GL_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int oend = min(64, out_dim - o0);
+    const int oend = min(OC, out_dim - o0);
     for (int oo = 0; oo < oend; oo += 4) {
       float4 wv[4];
 #pragma unroll
@@ -369,13 +371,15 @@ extern "C" int cips_grouped_linear_fwd(const cips_glin_job* jobs, int njobs, int
   int rc = fill(J, jobs, njobs, 16);
   if (rc) return rc;
   if (B <= 0) return (int)hipErrorInvalidValue;
+  int opw = 4;
+  if (J.tile0[njobs] < 128) { opw = 1; rc = fill(J, jobs, njobs, 4); if (rc) return rc; }     // few outputs: 4 per workgroup
   int max_in = 0;
   for (int j = 0; j < njobs; ++j) { if (!jobs[j].y) return (int)hipErrorInvalidValue; max_in = jobs[j].in_dim > max_in ? jobs[j].in_dim : max_in; }
   const size_t smem = (size_t)GL_ROWS * max_in * sizeof(float);
   static bool attr_set = false;
   CIPS_PER_DEVICE(attr_set, false);
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)glin_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GL_ROWS * 512 * 4); attr_set = true; }
-  hipLaunchKernelGGL(glin_fwd_kernel, dim3(J.tile0[njobs]), dim3(256), smem, (hipStream_t)stream, J, B, 1.f);
+  hipLaunchKernelGGL(glin_fwd_kernel, dim3(J.tile0[njobs]), dim3(256), smem, (hipStream_t)stream, J, B, opw);
   return CIPS_CHECK_LAUNCH();
 }
 
@@ -386,16 +390,25 @@ extern "C" int cips_grouped_linear_bwd(const cips_glin_job* jobs, int njobs, int
   if (rc) return rc;
   if (B <= 0) return (int)hipErrorInvalidValue;
   for (int j = 0; j < njobs; ++j) if (!jobs[j].dy || !jobs[j].dw) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(glin_bwd_w_kernel, dim3(J.tile0[njobs]), dim3(128), 0, (hipStream_t)stream, J, B);
+  if (J.tile0[njobs] < 128) {
+    rc = fill(J, jobs, njobs, 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(glin_bwd_w_kernel<4>, dim3(J.tile0[njobs]), dim3(128), 0, (hipStream_t)stream, J, B);
+  } else {
+    hipLaunchKernelGGL(glin_bwd_w_kernel<16>, dim3(J.tile0[njobs]), dim3(128), 0, (hipStream_t)stream, J, B);
+  }
   if (dx) {
     const int in_dim = jobs[0].in_dim;
     for (int j = 1; j < njobs; ++j) if (jobs[j].in_dim != in_dim || jobs[j].x != jobs[0].x) return (int)hipErrorInvalidValue;
     GLJobs K;
     rc = fill(K, jobs, njobs, 64);
     if (rc) return rc;
+    const bool fine = K.tile0[njobs] < 64;
+    if (fine) { rc = fill(K, jobs, njobs, 16); if (rc) return rc; }
     const int nchunks = K.tile0[njobs];
     if (!scratch || scratch_floats < (long long)nchunks * B * in_dim) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(glin_bwd_x_kernel, dim3(nchunks), dim3(128), 0, (hipStream_t)stream, K, B, in_dim, scratch);
+    if (fine) hipLaunchKernelGGL(glin_bwd_x_kernel<16>, dim3(nchunks), dim3(128), 0, (hipStream_t)stream, K, B, in_dim, scratch);
+    else hipLaunchKernelGGL(glin_bwd_x_kernel<64>, dim3(nchunks), dim3(128), 0, (hipStream_t)stream, K, B, in_dim, scratch);
     const long long n = (long long)B * in_dim;
     hipLaunchKernelGGL(glin_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch, dx, nchunks, n);
   }
@@ -406,6 +419,10 @@ extern "C" long long cips_grouped_linear_scratch(const cips_glin_job* jobs, int 
   if (!jobs || njobs <= 0) return 0;
   long long chunks = 0;
   for (int j = 0; j < njobs; ++j) chunks += (jobs[j].out_dim + 63) / 64;
+  if (chunks < 64) {            // the finer chunking of cips_grouped_linear_bwd
+    chunks = 0;
+    for (int j = 0; j < njobs; ++j) chunks += (jobs[j].out_dim + 15) / 16;
+  }
   return chunks * B * jobs[0].in_dim;
 }
 

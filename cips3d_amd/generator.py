@@ -39,6 +39,9 @@ def kaiming_leaky_init(m):
 # ------------------------------------------------------------------------------------------
 # parameter holders
 # ------------------------------------------------------------------------------------------
+MAPPING_HIP = __import__("os").environ.get("CIPS_MAPPING_HIP", "1") != "0"    # mapping MLPs on the HIP row kernels
+
+
 class PixelNorm(nn.Module):
     """multi_head_mapping.py:13-19"""
 
@@ -128,7 +131,7 @@ class MultiHeadMappingNetwork(nn.Module):
     def _hip_ok(self, z):
         # (large batches — the 10 000 latents of generate_avg_frequencies — stay on hipBLASLt: the row kernels are built for
         # the few rows of a training batch)
-        return (ops.GROUPED_LINEAR and z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and z.shape[0] <= 256 and z.shape[1] <= 512 and z.shape[1] % 4 == 0
+        return (MAPPING_HIP and ops.GROUPED_LINEAR and z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and z.shape[0] <= 256 and z.shape[1] <= 512 and z.shape[1] % 4 == 0
                 and all(not isinstance(m, nn.Linear) or (m.in_features <= 512 and m.in_features % 4 == 0 and m.out_features <= 1024)
                         for m in self.base_net))
 
