@@ -116,6 +116,8 @@ SIGNATURES = {
     "cips_gemm_bf16x3_km_grouped": (i32, [C.POINTER(GemmX3Desc), i32, vp]),
     "cips_conv1x1_smallk": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_conv1x1_smallk_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "cips_conv1x1_smallk_bwd_weight_splits": (i32, [i32, i32]),
+    "cips_conv1x1_smallk_bwd_weight": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_conv2d_x3": (i32, [C.POINTER(ConvX3Desc), vp]),
     "cips_conv2d_x3_wgrad": (i32, [C.POINTER(ConvWgradDesc), vp]),
     "cips_split_planes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, vp]),

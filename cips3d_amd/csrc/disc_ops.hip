@@ -306,12 +306,16 @@ __device__ __forceinline__ bool da_masked(const DiffAugArgs& a, int b, int i, in
 
 // mode 0: sums[b] = sum of x[b]; mode 1: sums[b] = sum over the source pixels of the shifted, masked gradient
 // g3[c][i'][j'] = (g * mask)[c][i' - tx][j' - ty]
+// Grid (B, DA_SPLITS): block (b, s) sums slice s of image b into out[B + s * B + b]; diffaug_sum_final_kernel adds the
+// slices of an image in slice order into out[b] (one workgroup per image was 223 us at 256 x 256).
+constexpr int DA_SPLITS = 32;
 __global__ __launch_bounds__(256) void diffaug_sum_kernel(DiffAugArgs a, float* __restrict__ out, int mode) {
   __shared__ float red[256];
   const int b = blockIdx.x;
   const int HW = a.H * a.W, n = a.C * HW;
+  const int per = (n + DA_SPLITS - 1) / DA_SPLITS, e0 = blockIdx.y * per, e1 = min(n, e0 + per);
   float acc = 0.f;
-  for (int e = threadIdx.x; e < n; e += 256) {
+  for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
     float v = a.x[(long long)b * n + e];
     if (mode == 1) {
       const int p = e % HW, i = p / a.W, j = p - i * a.W;            // (i, j) = position in the OUTPUT of the forward
@@ -326,7 +330,14 @@ __global__ __launch_bounds__(256) void diffaug_sum_kernel(DiffAugArgs a, float* 
     if (threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[b] = red[0];
+  if (threadIdx.x == 0) out[a.B + blockIdx.y * a.B + b] = red[0];
+}
+__global__ __launch_bounds__(256) void diffaug_sum_final_kernel(float* __restrict__ out, int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float t = 0.f;
+  for (int s_ = 0; s_ < DA_SPLITS; ++s_) t += out[B + s_ * B + b];
+  out[b] = t;
 }
 
 __global__ __launch_bounds__(256) void diffaug_fwd_kernel(DiffAugArgs a) {
@@ -385,7 +396,8 @@ extern "C" int cips_diffaug(const float* x, float* y, const float* rb, const flo
   a.x = x; a.y = y; a.rb = rb; a.rs = rs; a.rc = rc; a.tx = tx; a.ty = ty; a.ox = ox; a.oy = oy; a.sums = sums;
   a.B = B; a.C = C; a.H = H; a.W = W; a.ch = cut_h; a.cw = cut_w; a.affine = affine;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(diffaug_sum_kernel, dim3(B), dim3(256), 0, st, a, sums, adjoint ? 1 : 0);
+  hipLaunchKernelGGL(diffaug_sum_kernel, dim3(B, DA_SPLITS), dim3(256), 0, st, a, sums, adjoint ? 1 : 0);
+  hipLaunchKernelGGL(diffaug_sum_final_kernel, dim3((B + 255) / 256), dim3(256), 0, st, sums, B);
   const long long total = (long long)B * H * W;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   if (adjoint) hipLaunchKernelGGL(diffaug_adj_kernel, dim3(blocks), dim3(256), 0, st, a);
@@ -515,6 +527,47 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
   return CIPS_CHECK_LAUNCH();
 }
 
+// Weight gradient of the same layer: dw[o][c] = sum_{b,p} dy[b][o][p] x[b][c][p] — O*C dot products over B*HW pixels.
+// As a GEMM this is one 128-row tile per image with a contraction of 65 536 (r256): four workgroups on the whole chip,
+// 4.6 ms.  Here a workgroup owns one output channel and one slice of the pixel range of every image (16-byte loads, the
+// C rows of x come from L2), reduces through shuffles + LDS and writes one partial row; the S partial rows are summed by
+// the caller in a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void conv1x1_smallk_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                        float* __restrict__ part, int B, int C, int O, int hw4,
+                                                                        int per) {
+  __shared__ float red[4][4];
+  const int o = blockIdx.x, s = blockIdx.y;
+  const int p_lo = s * per, p_hi = min(hw4, p_lo + per);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    const float4* g = reinterpret_cast<const float4*>(dy) + ((long long)b * O + o) * hw4;
+    const float4* xs = reinterpret_cast<const float4*>(x) + (long long)b * C * hw4;
+    for (int p = p_lo + (int)threadIdx.x; p < p_hi; p += 256) {
+      const float4 gv = g[p];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < C) {
+          const float4 xv = xs[(long long)c * hw4 + p];
+          acc[c] = fmaf(gv.x, xv.x, fmaf(gv.y, xv.y, fmaf(gv.z, xv.z, fmaf(gv.w, xv.w, acc[c]))));
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) red[wave][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < (unsigned)C) {
+    const int c = threadIdx.x;
+    part[((long long)s * O + o) * C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  }
+}
+
 extern "C" int cips_conv1x1_smallk(const float* x, const float* w, float* y, int B, int C, int O, int HW,
                                    cips_stream_t stream) {
   if (B <= 0 || C <= 0 || C > 4 || O <= 0 || HW <= 0 || (HW & 3)) return (int)hipErrorInvalidValue;
@@ -530,6 +583,23 @@ extern "C" int cips_conv1x1_smallk_bwd_data(const float* dy, const float* w, flo
   const long long blocks = (long long)B * ((hw4 + 63) / 64);
   if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(conv1x1_smallk_bwd_data_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, w, dx, C, O, hw4);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_conv1x1_smallk_bwd_weight_splits(int O, int HW) {
+  if (O <= 0 || HW <= 0 || (HW & 3)) return 0;
+  const int hw4 = HW / 4;
+  int S = (2048 + O - 1) / O;                  // enough workgroups to fill 256 CUs a few times over
+  if (S > hw4 / 256) S = hw4 / 256;            // but at least one full 256-thread sweep per image and slice
+  return S < 1 ? 1 : S;
+}
+
+extern "C" int cips_conv1x1_smallk_bwd_weight(const float* dy, const float* x, float* part, int B, int C, int O, int HW,
+                                              cips_stream_t stream) {
+  if (!dy || !x || !part || B <= 0 || C <= 0 || C > 4 || O <= 0 || HW <= 0 || (HW & 3)) return (int)hipErrorInvalidValue;
+  const int hw4 = HW / 4, S = cips_conv1x1_smallk_bwd_weight_splits(O, HW);
+  const int per = (hw4 + S - 1) / S;
+  hipLaunchKernelGGL(conv1x1_smallk_bwd_weight_kernel, dim3(O, S), dim3(256), 0, (hipStream_t)stream, dy, x, part, B, C, O, hw4, per);
   return CIPS_CHECK_LAUNCH();
 }
 

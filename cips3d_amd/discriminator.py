@@ -195,6 +195,7 @@ IMPLICIT = _os.environ.get("CIPS_D_CONV_IMPLICIT", "1") != "0"
 
 
 _RGB_STREAM = _os.environ.get("CIPS_D_RGB_STREAM", "1") != "0"
+_SKIP_DOWN2 = _os.environ.get("CIPS_D_SKIP_DOWN2", "1") != "0"      # skip branch: blur at down = 2 + stride-1 1x1 conv
 # Small output planes (8x8, 4x4: fewer than 256 pixels per image): the batch is folded into the pixel dimension, one
 # GEMM over B*Ho*Wo columns with the shared weights instead of B GEMMs whose 16- or 64-column tiles are mostly padding
 # (the 4x4 layers spent 14 ms per GAN step in the fp32 GEMM for 5 GFLOP).  CIPS_D_CONV_FOLD=0 restores that.
@@ -431,6 +432,8 @@ def _conv_bwd_weight(dy, x, w_shape, stride, pad):
     x = x.contiguous()
     dy = dy.contiguous()
     K, N = C * kh * kw, dy.shape[2] * dy.shape[3]
+    if _RGB_STREAM and kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and N % 4 == 0:
+        return ops.conv1x1_smallk_bwd_weight(dy, x).view(O, C, 1, 1)       # RGB input convs: streaming reduction
     if _implicit_ok(C, N, O):
         dw = ops.conv2d_x3_wgrad(_nhwc(dy), _nhwc(x), B, C, x.shape[2], x.shape[3], O, kh, kw, stride, pad)
         if dw is not None:
@@ -610,6 +613,22 @@ class ConvLayer(nn.Sequential):
                 layers['slrelu'] = ScaledLeakyReLU(0.2)
         super().__init__(layers)
 
+    def forward(self, input):
+        # Blur followed by a 1x1 stride-2 conv (the ResBlock skip branch) only ever reads blur[2i][2j]: ask upfirdn2d for
+        # exactly those samples (down = 2: a quarter of the blur's output bytes, the same taps in the same order) and run
+        # the 1x1 conv at stride 1 on the quarter-size map — implicit GEMM forward and backward, no im2col / col2im.
+        blur = getattr(self, "down_blur", None)
+        conv = self.equal_conv
+        if (_SKIP_DOWN2 and blur is not None and input.is_cuda and conv.weight.shape[2] == 1 and conv.weight.shape[3] == 1
+                and conv.stride == 2 and conv.padding == 0):
+            x = upfirdn2d(input, blur.kernel, down=2, pad=blur.pad)
+            x = conv2d(x, conv.weight, bias=conv.bias, stride=1, padding=0, scale=conv.scale)
+            for name, m in self.named_children():
+                if name not in ("down_blur", "equal_conv"):
+                    x = m(x)
+            return x
+        return super().forward(input)
+
 
 class ResBlock(nn.Module):
     """discriminator.py:224-252"""
@@ -665,7 +684,7 @@ class _DiffAugFunction(Function):
         x = x.contiguous().float()
         B, Cc, H, W = x.shape
         y = torch.empty_like(x)
-        sums = torch.empty(B, device=x.device)
+        sums = torch.empty(33 * B, device=x.device)          # per-image sums + 32 slices of partials (cips_diffaug)
         lib = _lib.load()
         P = lambda t: C.c_void_p(t.data_ptr())
         with torch.cuda.device(x.device):

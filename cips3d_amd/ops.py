@@ -947,6 +947,17 @@ def conv1x1_smallk_bwd_data(dy, w, C):
     return dx
 
 
+def conv1x1_smallk_bwd_weight(dy, x):
+    """dy (B, O, H, W), x (B, C<=4, H, W) -> dw (O, C) = sum over images and pixels of dy x^T"""
+    lib = _lib.load()
+    B, O, H, W = dy.shape
+    C = x.shape[1]
+    S = lib.cips_conv1x1_smallk_bwd_weight_splits(O, H * W)
+    part = torch.empty(S, O, C, device=dy.device)
+    check(lib.cips_conv1x1_smallk_bwd_weight(_p(dy), _p(x), _p(part), B, C, O, H * W, _stream()), "cips_conv1x1_smallk_bwd_weight")
+    return part.sum(0) if S > 1 else part[0]
+
+
 def split_planes_nhwc(x):
     """x (B, C, H, W) fp32 NCHW -> NHWC split planes (B*H*W + 1, C): the transposing form of cips_split_planes; the
     extra last row is zero (the implicit-GEMM convolution reads it wherever a tap falls into the padding)."""

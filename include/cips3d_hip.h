@@ -433,7 +433,8 @@ int cips_upfirdn2d(const float* input, const float* kernel, float* out,
 /* DiffAugment with policy 'color,translation,cutout' (exp/cips3d/models/diffaug.py:9-85; applied to every discriminator
  * input, exp/cips3d/models/discriminator.py:507-508) as one affine operator and its adjoint.  rb, rs, rc: the (B) raw
  * uniform draws of brightness / saturation / contrast; tx, ty, ox, oy: the (B) int64 draws of translation and cutout
- * centre, all made by the host with the reference's calls.  x, y (B, C <= 4, H, W); sums: (B) floats of scratch.
+ * centre, all made by the host with the reference's calls.  x, y (B, C <= 4, H, W); sums: 33 * B floats of scratch
+ * (per-image sums, then 32 slices of partial sums per image).
  * adjoint 0: y = A x + c (affine != 0) or y = A x (affine == 0); adjoint 1: y = A^T x (the backward; its own backward
  * is the forward with affine == 0: the R1 double-backward of train.py:387-394).  cut_h / cut_w = int(size * 0.2 + 0.5). */
 int cips_diffaug(const float* x, float* y, const float* rb, const float* rs, const float* rc, const long long* tx,
@@ -457,6 +458,12 @@ int cips_conv1x1_smallk(const float* x, const float* w, float* y, int B, int C, 
 /* its data gradient: dx (B, C, HW) = w^T (C, O) . dy (B, O, HW) */
 int cips_conv1x1_smallk_bwd_data(const float* dy, const float* w, float* dx, int B, int C, int O, int HW,
                                  cips_stream_t stream);
+/* its weight gradient (autograd of discriminator.py:44-48 for the RGB layers): part (S, O, C), S =
+ * cips_conv1x1_smallk_bwd_weight_splits(O, HW) partial rows that the caller sums over S:
+ * sum_s part[s][o][c] = sum_{b,p} dy[b][o][p] x[b][c][p] */
+int cips_conv1x1_smallk_bwd_weight_splits(int O, int HW);
+int cips_conv1x1_smallk_bwd_weight(const float* dy, const float* x, float* part, int B, int C, int O, int HW,
+                                   cips_stream_t stream);
 
 /* im2col for the EqualConv2d GEMM path (exp/cips3d/models/discriminator.py:40-48).
  * x (B,C,H,W) NCHW -> col (B, C*kh*kw, Ho*Wo) row-major ("colT": k-major B operand, so that

@@ -223,3 +223,79 @@ def test_fade_in_ops_match_torch(shape):
     assert max_rel(out, 0.3 * a + 0.7 * b) < 1e-6
     ga, gb = torch.autograd.grad((out * up.to(d)).sum(), (ad, bd))
     assert max_rel(ga, 0.3 * up) < 1e-6 and max_rel(gb, 0.7 * up) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 64, 64), (4, 3, 64, 256, 256), (3, 4, 24, 8, 12), (1, 1, 8, 4, 4)])
+def test_rgb_conv_weight_gradient_streaming_kernel(shape):
+    """dw[o][c] = sum_{b,p} dy[b][o][p] x[b][c][p] of the RGB input convs (cips_conv1x1_smallk_bwd_weight: one workgroup
+    per output channel and pixel slice, partial rows summed in slice order) against fp64, and through conv2d's autograd
+    including the R1-style double backward"""
+    from cips3d_amd import ops
+    from cips3d_amd.discriminator import conv2d
+    B, C, O, H, W = shape
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(B, O, H, W, generator=g).to(d)
+    x = torch.randn(B, C, H, W, generator=g).to(d)
+    dw = ops.conv1x1_smallk_bwd_weight(dy, x)
+    ref = torch.einsum("bohw,bchw->oc", dy.double(), x.double())
+    assert dw.shape == (O, C) and rel_err(dw, ref) < 2e-6
+    assert torch.equal(dw, ops.conv1x1_smallk_bwd_weight(dy, x))          # fixed summation order: run-to-run identical
+    if H * W <= 4096:
+        xr = x.double().cpu().requires_grad_(True)
+        wr = (torch.randn(O, C, 1, 1, generator=g, dtype=torch.float64) / C ** 0.5).requires_grad_(True)
+        y = torch.nn.functional.conv2d(xr, wr)
+        gx, = torch.autograd.grad((y * dy.double().cpu()).sum(), xr, create_graph=True)
+        ((gx ** 2).sum() + (y ** 2).sum()).backward()
+        xd = x.clone().requires_grad_(True); wd = wr.detach().float().to(d).requires_grad_(True)
+        yd = conv2d(xd, wd)
+        gxd, = torch.autograd.grad((yd * dy).sum(), xd, create_graph=True)
+        ((gxd ** 2).sum() + (yd ** 2).sum()).backward()
+        assert rel_err(yd, y) < 1e-5 and rel_err(gxd, gx) < 1e-5
+        assert rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(xd.grad, xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 96, 32), (2, 32, 64, 64), (3, 32, 32, 8)])
+def test_skip_branch_blur_down2_equals_blur_then_stride2(cfg, monkeypatch):
+    """ResBlock skip branch (discriminator.py:239-241): Blur + 1x1 stride-2 conv run as upfirdn2d(down = 2) + stride-1 conv
+    must give the unfused composition's output bit for bit in the blur and to GEMM rounding after the conv, and the same
+    input / weight gradients including the R1 double backward"""
+    from cips3d_amd import discriminator as dm
+    B, C, O, H = cfg
+    d = torch.device("cuda:0")
+    torch.manual_seed(3)
+    layer = dm.ConvLayer(C, O, 1, downsample=True, activate=False, bias=False).to(d)
+    x0 = torch.randn(B, C, H, H, device=d)
+    up = torch.randn(B, O, H // 2, H // 2, device=d)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(dm, "_SKIP_DOWN2", fused)
+        layer.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        y = layer(x)
+        gx, = torch.autograd.grad((y * up).sum(), x, create_graph=True)
+        ((gx ** 2).sum() + (y ** 2).sum()).backward()
+        res[fused] = (y.detach(), gx.detach(), x.grad.clone(), layer.equal_conv.weight.grad.clone())
+    blur = layer.down_blur
+    assert torch.equal(dm.upfirdn2d(x0, blur.kernel, down=2, pad=blur.pad), dm.upfirdn2d(x0, blur.kernel, pad=blur.pad)[:, :, ::2, ::2])
+    for a, b, what in zip(res[True], res[False], ("y", "dx", "x.grad", "w.grad")):
+        assert a.shape == b.shape and rel_err(a, b) < 2e-5, (what, float(rel_err(a, b)))
+
+
+def test_diffaug_sums_at_256_match_torch():
+    """the per-image sums of cips_diffaug are reduced in 32 slices per image: brightness / contrast means at 256 x 256
+    against the op-by-op torch restatement with the same device draws"""
+    from cips3d_amd import discriminator as dm
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 3, 256, 256, generator=g).to(d)
+    outs = []
+    for fused in (True, False):
+        old = dm.DIFFAUG_HIP
+        dm.DIFFAUG_HIP = fused
+        try:
+            torch.manual_seed(11)
+            outs.append(dm.DiffAugment(x, policy="color,translation,cutout"))
+        finally:
+            dm.DIFFAUG_HIP = old
+    assert max_rel(outs[0], outs[1]) < 2e-6
