@@ -121,6 +121,8 @@ SIGNATURES = {
     "cips_conv2d_x3": (i32, [C.POINTER(ConvX3Desc), vp]),
     "cips_conv2d_x3_wgrad": (i32, [C.POINTER(ConvWgradDesc), vp]),
     "cips_split_planes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
+    "cips_split_planes_nhwc": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "cips_conv_wgrad_finish": (i32, [vp, vp, i32, i32, i32, i32, f32, vp]),
     "cips_modfc_prep_x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cips_torgb_fwd_x3": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "cips_torgb_bwd_w_x3": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp]),

@@ -4,6 +4,11 @@
 #include "common.h"
 #include "../../include/cips3d_hip.h"
 
+// A readable zero outside any tensor: out-of-range taps of the register-tiled upfirdn2d kernels are redirected here by
+// ADDRESS (value selects let hipcc sink each load into its own predicated block with a full wait behind it: 49 serial
+// round trips per thread).  External linkage on purpose, so that the loads cannot be folded to a constant.
+__device__ float cips_zero_word[4];
+
 namespace {
 
 // exp/comm/op/fused_bias_act_kernel.cu:18-49
@@ -83,11 +88,133 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirArgs a) {
 // (16-byte global loads), every thread produces strips of four neighbouring outputs from registers (7 or 10 LDS values
 // per kernel row instead of 16 loads per output), and stores them coalesced.  Same taps in the same order (rows
 // outer, columns inner; padding contributes exact zeros), so the results are those of the generic kernel.
+// Register-tiled form for the 4 x 4 blur the discriminator uses everywhere (up 1, down 1 or 2): a thread produces a 4 x 4
+// block of outputs straight from global memory — (3 DOWN + 4)^2 clamped dword loads that neighbouring lanes share through
+// L1 (7 x 7 for 16 outputs at down 1), 256 FMAs, no LDS, no barriers, no per-element divisions (two per 16 outputs).  The
+// LDS-band kernel below spends ~30 instructions of index arithmetic per staged element and serialises stage / barrier /
+// compute per plane: 125 us on the 8192 64 x 64 planes whose bytes need 45, 117 us on down-2 calls that need 30.  Same
+// taps in the same order (kernel rows outer, columns inner, one fma chain per output), so the results are bit-identical
+// to the generic kernel's.
+template <int DOWN>
+__global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(UpfirArgs a, int bw, int bh) {
+  constexpr int R = 4, NX = 3 * DOWN + 4, NR = (R - 1) * DOWN + 4;
+  float ck[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ck[i] = a.k[15 - i];                   // flipped 4 x 4 kernel (uniform: scalar loads)
+  const long long per_plane = (long long)bh * bw, nblk = a.major * per_plane;
+  const bool vec = (a.out_w & 3) == 0;
+  const float* zp = cips_zero_word;
+  for (long long t = blockIdx.x * 256LL + threadIdx.x; t < nblk; t += gridDim.x * 256LL) {
+    const long long mj = t / per_plane;
+    const int rem = (int)(t - mj * per_plane), by = rem / bw, bx = rem - by * bw;
+    const int oy0 = by * R, ox0 = bx * 4;
+    const int iyb = oy0 * DOWN - a.pad_y0, ixb = ox0 * DOWN - a.pad_x0;
+    const float* src = a.in + mj * (long long)a.in_h * a.in_w;
+    int colx[NX];
+    bool cok[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int ix = ixb + i;
+      cok[i] = (unsigned)ix < (unsigned)a.in_w;
+      colx[i] = min(max(ix, 0), a.in_w - 1);
+    }
+    float v[R][4];
+#pragma unroll
+    for (int ry = 0; ry < R; ++ry)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) v[ry][o] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int iy = iyb + r;
+      const bool rok = (unsigned)iy < (unsigned)a.in_h;
+      const float* rowp = src + (long long)min(max(iy, 0), a.in_h - 1) * a.in_w;
+      float x[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = *((rok && cok[i]) ? rowp + colx[i] : zp);
+#pragma unroll
+      for (int ry = 0; ry < R; ++ry) {
+        const int ky = r - ry * DOWN;
+        if (ky >= 0 && ky < 4) {
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) v[ry][o] = fmaf(x[o * DOWN + kx], ck[ky * 4 + kx], v[ry][o]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ry = 0; ry < R; ++ry) {
+      const int oy = oy0 + ry;
+      if (oy < a.out_h) {
+        float* q = a.out + (mj * a.out_h + oy) * (long long)a.out_w + ox0;
+        if (vec) {
+          *reinterpret_cast<float4*>(q) = make_float4(v[ry][0], v[ry][1], v[ry][2], v[ry][3]);
+        } else {
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+            if (ox0 + o < a.out_w) q[o] = v[ry][o];
+        }
+      }
+    }
+  }
+}
+
+// up 2, down 1, 4 x 4 kernel (the backward of the down-2 blur of the skip branch): each output has 2 x 2 taps.  A
+// thread produces four neighbouring outputs of one row; the quarter-size input stays in L1 / L2.  Same polyphase
+// arithmetic and tap order as the generic kernel.
+__global__ __launch_bounds__(256) void upfirdn2d_up2_kernel(UpfirArgs a, int bw) {
+  __shared__ float sk[16];
+  if (threadIdx.x < 16) sk[threadIdx.x] = a.k[15 - threadIdx.x];
+  __syncthreads();
+  const long long per_plane = (long long)a.out_h * bw, nblk = a.major * per_plane;
+  const bool vec = (a.out_w & 3) == 0;
+  const float* zp = cips_zero_word;
+  for (long long t = blockIdx.x * 256LL + threadIdx.x; t < nblk; t += gridDim.x * 256LL) {
+    const long long mj = t / per_plane;
+    const int rem = (int)(t - mj * per_plane), oy = rem / bw, bx = rem - oy * bw, ox0 = bx * 4;
+    const float* src = a.in + mj * (long long)a.in_h * a.in_w;
+    const int mid_y = oy + 1 - a.pad_y0, in_y0 = floor_div(mid_y, 2), ky0 = (in_y0 + 1) * 2 - mid_y - 1;
+    float v[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int mid_x = ox0 + o + 1 - a.pad_x0, in_x0 = floor_div(mid_x, 2), kx0 = (in_x0 + 1) * 2 - mid_x - 1;
+      float acc = 0.f;
+#pragma unroll
+      for (int yy = 0; yy < 2; ++yy) {
+        const int iy = in_y0 + yy, ky = ky0 + 2 * yy;
+        const bool rok = (unsigned)iy < (unsigned)a.in_h;
+        const float* rowp = src + (long long)min(max(iy, 0), a.in_h - 1) * a.in_w;
+#pragma unroll
+        for (int xx = 0; xx < 2; ++xx) {
+          const int ix = in_x0 + xx, kx = kx0 + 2 * xx;
+          const bool ok = rok && (unsigned)ix < (unsigned)a.in_w;
+          const float q = *(ok ? rowp + min(max(ix, 0), a.in_w - 1) : zp);
+          acc = fmaf(q, sk[ky * 4 + kx], acc);
+        }
+      }
+      v[o] = acc;
+    }
+    float* q = a.out + (mj * a.out_h + oy) * (long long)a.out_w + ox0;
+    if (vec) {
+      *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (ox0 + o < a.out_w) q[o] = v[o];
+    }
+  }
+}
+
+// Occupancy: the band lives in DYNAMIC LDS sized to what the launch needs and small planes run in one-wave workgroups —
+// with a fixed 32 KiB tile and 256 threads per plane the 32x32 / 16x16 / 8x8 stages (16 384 planes of a few KiB each)
+// ran 4 workgroups per CU, one plane each, and took 116 us per call where their bytes need 3-20 us.
 constexpr int UF_MAX_LDS_FLOATS = 8192;          // 32 KiB band
 template <int DOWN>
 __global__ __launch_bounds__(256) void upfirdn2d_blur_kernel(UpfirArgs a, int band_rows, int bands, int lds_w) {
-  __shared__ float sk[16];
-  __shared__ __attribute__((aligned(16))) float tile[UF_MAX_LDS_FLOATS];
+  extern __shared__ __attribute__((aligned(16))) float uf_smem[];
+  float* sk = uf_smem;
+  float* tile = uf_smem + 16;
+  const int nthr = blockDim.x;
   if (threadIdx.x < 16) {
     const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
     sk[threadIdx.x] = (ky < a.kh && kx < a.kw) ? a.k[(a.kh - 1 - ky) * a.kw + (a.kw - 1 - kx)] : 0.f;
@@ -105,14 +232,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur_kernel(UpfirArgs a, int ba
     __syncthreads();                                          // previous band fully consumed (and sk written)
     // stage: tile[r][pad_x0 + x] = in[iy0 + r][x], zeros elsewhere
     const int nrows_in = (nrows_out - 1) * DOWN + a.kh;
-    for (int e = threadIdx.x; e < nrows_in * lds_w; e += 256) {
+    for (int e = threadIdx.x; e < nrows_in * lds_w; e += nthr) {
       const int r = e / lds_w, c = e - r * lds_w;
       const int iy = iy0 + r, ix = c - a.pad_x0;
       tile[e] = (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) ? src[(long long)iy * a.in_w + ix] : 0.f;
     }
     __syncthreads();
     float* dst = a.out + (mj * a.out_h + oy0) * (long long)a.out_w;
-    for (int sidx = threadIdx.x; sidx < nrows_out * strips_w; sidx += 256) {
+    for (int sidx = threadIdx.x; sidx < nrows_out * strips_w; sidx += nthr) {
       const int ry = sidx / strips_w, sx = sidx - ry * strips_w;
       const int ox = sx * 4;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -266,6 +393,47 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ c
       }
     }
     dx[idx] = v;
+  }
+}
+
+// The same gather with the filter geometry known at compile time: one workgroup per (b, c) plane, 32-bit index math,
+// parity tests and divisions by constants (the generic kernel spends four 64-bit divisions and 2 kh kw runtime modulos
+// per element: 839 us for the 35 M-element gradient of the 64 -> 32 stage whose bytes need 90 us).  Same taps in the same
+// order (ky outer, kx inner), so the sums are those of the generic kernel bit for bit.
+template <int KH, int KW, int STRIDE, int PAD>
+__global__ __launch_bounds__(256) void col2im_fixed_kernel(const float* __restrict__ col, float* __restrict__ dx, int H, int W,
+                                                           int Ho, int Wo) {
+  // polyphase: only taps ky = (iy + PAD) % STRIDE + a * STRIDE can hit row iy.  Every candidate is LOADED (index clamped
+  // to 0 when it does not exist) and selected afterwards: with the loads inside per-tap branches each element waited for
+  // up to four dependent memory round trips (693 us for the 69 M-element gradient of the 64 -> 32 stage).
+  constexpr int TY = (KH + STRIDE - 1) / STRIDE, TX = (KW + STRIDE - 1) / STRIDE;
+  const long long plane = blockIdx.x;
+  const float* cp = col + plane * (long long)(KH * KW) * Ho * Wo;
+  float* dp = dx + plane * (long long)H * W;
+  const unsigned n = (unsigned)(H * W), uw = (unsigned)W;
+  for (unsigned e = blockIdx.y * 256 + threadIdx.x; e < n; e += gridDim.y * 256) {
+    const unsigned iy = e / uw, ix = e - iy * uw;
+    const int ry = ((int)iy + PAD) % STRIDE, rx = ((int)ix + PAD) % STRIDE;
+    float t[TY][TX];
+    bool ok[TY][TX];
+#pragma unroll
+    for (int a = 0; a < TY; ++a) {
+      const int ky = ry + a * STRIDE, ny = (int)iy + PAD - ky, oy = ny / STRIDE;
+      const bool yok = ky < KH && ny >= 0 && oy < Ho;
+#pragma unroll
+      for (int b = 0; b < TX; ++b) {
+        const int kx = rx + b * STRIDE, nx = (int)ix + PAD - kx, ox = nx / STRIDE;
+        ok[a][b] = yok && kx < KW && nx >= 0 && ox < Wo;
+        const int idx = ok[a][b] ? ((ky * KW + kx) * Ho + oy) * Wo + ox : 0;
+        t[a][b] = cp[idx];
+      }
+    }
+    float v = 0.f;
+#pragma unroll
+    for (int a = 0; a < TY; ++a)
+#pragma unroll
+      for (int b = 0; b < TX; ++b) v += ok[a][b] ? t[a][b] : 0.f;
+    dp[e] = v;
   }
 }
 
@@ -505,6 +673,24 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
   a.out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w) / down_x + 1;
   long long total = (long long)major * a.out_h * a.out_w * minor;
   if (total <= 0) return 0;
+  if (minor == 1 && kernel_h == 4 && kernel_w == 4 && up_x == up_y && down_x == down_y) {
+    hipStream_t st = (hipStream_t)stream;
+    if (up_x == 1 && (down_x == 1 || down_x == 2)) {
+      const int bw = (a.out_w + 3) / 4, bh = (a.out_h + 3) / 4;
+      const long long nthreads = (long long)major * bw * bh;
+      const unsigned grid = (unsigned)((nthreads + 255) / 256 < 131072 ? (nthreads + 255) / 256 : 131072);
+      if (down_x == 1) hipLaunchKernelGGL(upfirdn2d_direct_kernel<1>, dim3(grid), dim3(256), 0, st, a, bw, bh);
+      else hipLaunchKernelGGL(upfirdn2d_direct_kernel<2>, dim3(grid), dim3(256), 0, st, a, bw, bh);
+      return CIPS_CHECK_LAUNCH();
+    }
+    if (up_x == 2 && down_x == 1) {
+      const int bw = (a.out_w + 3) / 4;
+      const long long nthreads = (long long)major * a.out_h * bw;
+      const unsigned grid = (unsigned)((nthreads + 255) / 256 < 131072 ? (nthreads + 255) / 256 : 131072);
+      hipLaunchKernelGGL(upfirdn2d_up2_kernel, dim3(grid), dim3(256), 0, st, a, bw);
+      return CIPS_CHECK_LAUNCH();
+    }
+  }
   if (up_x == 1 && up_y == 1 && minor == 1 && kernel_h <= 4 && kernel_w <= 4 && down_x == down_y && (down_x == 1 || down_x == 2) &&
       pad_x0 >= 0 && pad_x1 >= 0 && pad_y0 >= 0 && pad_y1 >= 0) {
     // LDS row: left padding + input + enough on the right for the last strip's reads (4 outputs past out_w at most)
@@ -517,9 +703,13 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
     if (((band_rows - 1) * down + kernel_h) * lds_w <= UF_MAX_LDS_FLOATS) {
       const int bands = (a.out_h + band_rows - 1) / band_rows;
       const long long nwork = (long long)major * bands;
-      const unsigned grid = (unsigned)(nwork < 16384 ? nwork : 16384);
-      if (down == 1) hipLaunchKernelGGL(upfirdn2d_blur_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, band_rows, bands, lds_w);
-      else hipLaunchKernelGGL(upfirdn2d_blur_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, band_rows, bands, lds_w);
+      const int strips = band_rows * ((a.out_w + 3) / 4);                 // 4-output strips per work item
+      const int nthr = strips <= 320 ? 64 : (strips <= 640 ? 128 : 256);
+      const size_t lds_bytes = (size_t)(16 + ((band_rows - 1) * down + kernel_h) * lds_w) * sizeof(float);
+      const long long cap = nthr == 64 ? 65536 : 16384;
+      const unsigned grid = (unsigned)(nwork < cap ? nwork : cap);
+      if (down == 1) hipLaunchKernelGGL(upfirdn2d_blur_kernel<1>, dim3(grid), dim3(nthr), lds_bytes, (hipStream_t)stream, a, band_rows, bands, lds_w);
+      else hipLaunchKernelGGL(upfirdn2d_blur_kernel<2>, dim3(grid), dim3(nthr), lds_bytes, (hipStream_t)stream, a, band_rows, bands, lds_w);
       return CIPS_CHECK_LAUNCH();
     }
   }
@@ -628,6 +818,19 @@ extern "C" int cips_col2im(const float* col, float* dx, int B, int C, int H, int
   const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
   long long total = (long long)B * C * H * W;
   if (total <= 0) return (int)hipErrorInvalidValue;
+  const long long planes = (long long)B * C;
+  if (planes <= 0x7fffffffLL && (long long)H * W < 0x40000000LL && (long long)kh * kw * Ho * Wo < 0x7fffffffLL) {
+    const int per = (H * W + 255) / 256;
+    const dim3 grid((unsigned)planes, (unsigned)(per < 8 ? per : 8)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define CIPS_C2I(KH, KW, S, P)                                                                                   \
+    if (kh == KH && kw == KW && stride == S && pad == P) {                                                       \
+      hipLaunchKernelGGL((col2im_fixed_kernel<KH, KW, S, P>), grid, blk, 0, st, col, dx, H, W, Ho, Wo);          \
+      return CIPS_CHECK_LAUNCH();                                                                                \
+    }
+    CIPS_C2I(3, 3, 2, 0) CIPS_C2I(3, 3, 1, 1) CIPS_C2I(1, 1, 2, 0) CIPS_C2I(1, 1, 1, 0) CIPS_C2I(4, 4, 1, 0)
+#undef CIPS_C2I
+  }
   hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, col, dx, B, C, H, W,
                      kh, kw, stride, pad, Ho, Wo);
   return CIPS_CHECK_LAUNCH();

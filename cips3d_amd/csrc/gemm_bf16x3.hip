@@ -689,6 +689,64 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
+
+// NCHW fp32 (B, C, n) -> NHWC split planes (B*n + 1, C) with a zero last row: the operand form of the implicit-GEMM
+// convolutions.  64 x 64 tiles: 256-byte read segments along n (float4 per thread), 128-byte write segments along C
+// (8 bf16 per thread and plane) — the generic 32 x 32 kernel above writes 64-byte segments and reached 1.9 TB/s on
+// the 134 MB activation of the 64 x 64 stage.  Block (0, 0, 0) also writes the zero row (was two torch fills per call).
+__global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict__ x, u16* __restrict__ thi, u16* __restrict__ tlo,
+                                                         int C, int n, int B) {
+  __shared__ __attribute__((aligned(16))) u16 sh[64][72], sl[64][72];      // [n local][c local], 144-byte rows
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  const float* xb = x + (long long)b * C * n;
+  {
+    const int col4 = t & 15, r_ = t >> 4;                // 16 float4 per 64-float row, 16 rows per pass
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cl = r_ + 16 * k, c = c0 + cl, nn = n0 + 4 * col4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C && nn < n) v = *reinterpret_cast<const float4*>(xb + (long long)c * n + nn);      // n % 4 == 0
+      u16 h, l;
+      split2(v.x, h, l); sh[4 * col4 + 0][cl] = h; sl[4 * col4 + 0][cl] = l;
+      split2(v.y, h, l); sh[4 * col4 + 1][cl] = h; sl[4 * col4 + 1][cl] = l;
+      split2(v.z, h, l); sh[4 * col4 + 2][cl] = h; sl[4 * col4 + 2][cl] = l;
+      split2(v.w, h, l); sh[4 * col4 + 3][cl] = h; sl[4 * col4 + 3][cl] = l;
+    }
+  }
+  __syncthreads();
+  {
+    const int c8 = t & 7, r_ = t >> 3;                   // 8 x 16 B per 64-channel row, 32 rows per pass
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int nl = r_ + 32 * k, nn = n0 + nl, c = c0 + 8 * c8;
+      if (nn < n && c < C) {                             // C % 8 == 0
+        const long long o = ((long long)b * n + nn) * C + c;
+        *reinterpret_cast<uint4*>(thi + o) = *reinterpret_cast<const uint4*>(&sh[nl][8 * c8]);
+        *reinterpret_cast<uint4*>(tlo + o) = *reinterpret_cast<const uint4*>(&sl[nl][8 * c8]);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    const long long z = (long long)B * n * C;
+    for (int i = t; i < C; i += 256) { thi[z + i] = 0; tlo[z + i] = 0; }
+  }
+}
+
+// dw[o][c][tap] = scale * sum_chunk part[chunk][tap][o][c]: the tail of the implicit-GEMM weight gradient (was a torch
+// reduction, a permuting copy and a scalar multiply per convolution)
+__global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int nch,
+                                                                int taps, long long oc, float scale) {
+  const long long total = (long long)taps * oc;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+    const int tap = (int)(i / oc);
+    const long long j = i - (long long)tap * oc;
+    float v = part[i];
+    for (int ch = 1; ch < nch; ++ch) v += part[ch * total + i];
+    dw[j * taps + tap] = v * scale;
+  }
+}
+
 }  // namespace
 
 extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream);   // gemm_bf16x3_wide.hip
@@ -804,5 +862,22 @@ extern "C" int cips_split_planes(const float* x, void* p_hi, void* p_lo, void* t
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
   hipLaunchKernelGGL(split_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (u16*)p_hi, (u16*)p_lo,
                      (u16*)t_hi, (u16*)t_lo, rows, cols, ldx, ldp, ldt, stride_x, stride_p, stride_t);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_split_planes_nhwc(const float* x, void* t_hi, void* t_lo, int B, int C, int n, cips_stream_t stream) {
+  if (!x || !t_hi || !t_lo || B <= 0 || C <= 0 || n <= 0 || (C & 7) || (n & 3)) return (int)hipErrorInvalidValue;
+  dim3 grid((n + 63) / 64, (C + 63) / 64, B);
+  hipLaunchKernelGGL(split_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (u16*)t_hi, (u16*)t_lo, C, n, B);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_conv_wgrad_finish(const float* part, float* dw, int nchunks, int taps, int O, int C, float scale,
+                                      cips_stream_t stream) {
+  if (!part || !dw || nchunks <= 0 || taps <= 0 || O <= 0 || C <= 0) return (int)hipErrorInvalidValue;
+  const long long oc = (long long)O * C, total = oc * taps;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(conv_wgrad_finish_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream,
+                     part, dw, nchunks, taps, oc, scale);
   return CIPS_CHECK_LAUNCH();
 }

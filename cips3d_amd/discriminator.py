@@ -426,7 +426,15 @@ def _conv_bwd_data(dy, w, in_shape, stride, pad, scale=1.0):
     return ops.col2im(dcol, B, C, H, W, kh, kw, stride, pad)
 
 
-def _conv_bwd_weight(dy, x, w_shape, stride, pad):
+def _conv_bwd_weight(dy, x, w_shape, stride, pad, scale=1.0):
+    """d/dw of conv(x, w * scale): scale * (dy correlated with x)"""
+    dw = _conv_bwd_weight_raw(dy, x, w_shape, stride, pad, scale)
+    if isinstance(dw, tuple):            # (tensor,): the path applied the scale itself
+        return dw[0]
+    return dw if scale == 1.0 else dw * scale
+
+
+def _conv_bwd_weight_raw(dy, x, w_shape, stride, pad, scale):
     O, C, kh, kw = w_shape
     B = x.shape[0]
     x = x.contiguous()
@@ -435,9 +443,9 @@ def _conv_bwd_weight(dy, x, w_shape, stride, pad):
     if _RGB_STREAM and kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and N % 4 == 0:
         return ops.conv1x1_smallk_bwd_weight(dy, x).view(O, C, 1, 1)       # RGB input convs: streaming reduction
     if _implicit_ok(C, N, O):
-        dw = ops.conv2d_x3_wgrad(_nhwc(dy), _nhwc(x), B, C, x.shape[2], x.shape[3], O, kh, kw, stride, pad)
+        dw = ops.conv2d_x3_wgrad(_nhwc(dy), _nhwc(x), B, C, x.shape[2], x.shape[3], O, kh, kw, stride, pad, scale)
         if dw is not None:
-            return dw
+            return (dw,)
     if _fold_ok(K, N, B, O):
         colP, _, _ = _folded_col_planes(x, kh, kw, stride, pad)
         nch = _split_count(((O + 255) // 256) * ((K + 127) // 128), B * N)
@@ -481,9 +489,7 @@ class Conv2dFunction(Function):
             if ctx.needs_input_grad[0]:
                 dx = Conv2dBwdDataFunction.apply(dy, w, x.shape, ctx.stride, ctx.pad, ctx.scale)
             if ctx.needs_input_grad[1]:
-                dw = Conv2dBwdWeightFunction.apply(dy, x, w.shape, ctx.stride, ctx.pad)
-                if ctx.scale != 1.0:
-                    dw = dw * ctx.scale
+                dw = Conv2dBwdWeightFunction.apply(dy, x, w.shape, ctx.stride, ctx.pad, ctx.scale)
         ctx.xP = None
         return dx, dw, None, None, None
 
@@ -506,28 +512,28 @@ class Conv2dBwdDataFunction(Function):
             if ctx.needs_input_grad[0]:
                 g_dy = Conv2dFunction.apply(ggx, w, ctx.stride, ctx.pad, ctx.scale)
             if ctx.needs_input_grad[1]:
-                g_w = Conv2dBwdWeightFunction.apply(dy, ggx, w.shape, ctx.stride, ctx.pad)
-                if ctx.scale != 1.0:
-                    g_w = g_w * ctx.scale
+                g_w = Conv2dBwdWeightFunction.apply(dy, ggx, w.shape, ctx.stride, ctx.pad, ctx.scale)
         return g_dy, g_w, None, None, None, None
 
 
 class Conv2dBwdWeightFunction(Function):
+    """dw = scale * wgrad(dy, x): the gradient of conv(x, w * scale) w.r.t. w"""
+
     @staticmethod
-    def forward(ctx, dy, x, w_shape, stride, pad):
+    def forward(ctx, dy, x, w_shape, stride, pad, scale=1.0):
         ctx.save_for_backward(dy, x)
-        ctx.w_shape, ctx.stride, ctx.pad = w_shape, stride, pad
-        return _conv_bwd_weight(dy, x, w_shape, stride, pad)
+        ctx.w_shape, ctx.stride, ctx.pad, ctx.scale = w_shape, stride, pad, scale
+        return _conv_bwd_weight(dy, x, w_shape, stride, pad, scale)
 
     @staticmethod
     def backward(ctx, ggw):
         dy, x = ctx.saved_tensors
         g_dy = g_x = None
         if ctx.needs_input_grad[0]:
-            g_dy = Conv2dFunction.apply(x, ggw, ctx.stride, ctx.pad)
+            g_dy = Conv2dFunction.apply(x, ggw, ctx.stride, ctx.pad, ctx.scale)
         if ctx.needs_input_grad[1]:
-            g_x = Conv2dBwdDataFunction.apply(dy, ggw, x.shape, ctx.stride, ctx.pad)
-        return g_dy, g_x, None, None, None
+            g_x = Conv2dBwdDataFunction.apply(dy, ggw, x.shape, ctx.stride, ctx.pad, ctx.scale)
+        return g_dy, g_x, None, None, None, None
 
 
 def conv2d(x, w, bias=None, stride=1, padding=0, scale=1.0):

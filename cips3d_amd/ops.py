@@ -966,6 +966,9 @@ def split_planes_nhwc(x):
     n = H * W
     hi = torch.empty(B * n + 1, C, device=x.device, dtype=BF)
     lo = torch.empty(B * n + 1, C, device=x.device, dtype=BF)
+    if C % 8 == 0 and n % 4 == 0 and x.dtype == torch.float32 and x.is_contiguous():
+        check(lib.cips_split_planes_nhwc(_p(x), _p(hi), _p(lo), B, C, n, _stream()), "cips_split_planes_nhwc")
+        return Planes(hi, lo)
     hi[B * n:].zero_(); lo[B * n:].zero_()
     check(lib.cips_split_planes(_p(x), None, None, _p(hi), _p(lo), C, n, n, n, C, B, C * n, C * n, C * n, _stream()),
           "cips_split_planes")
@@ -986,10 +989,11 @@ def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad):
     return y
 
 
-def conv2d_x3_wgrad(dyP, xP, B, C, H, W, O, kh, kw, stride, pad):
+def conv2d_x3_wgrad(dyP, xP, B, C, H, W, O, kh, kw, stride, pad, scale=1.0):
     """Weight gradient of conv2d_x3: dyP, xP NHWC Planes from split_planes_nhwc -> dW (O, C, kh, kw) fp32, or None when
     the pixel count does not split into 32-row k-tiles.  The pixel range is cut into chunks so that a 512x512 filter bank
-    still fills the chip (4 tiles per tap and chunk); the partial sums are added here."""
+    still fills the chip (4 tiles per tap and chunk); cips_conv_wgrad_finish adds the partial sums, applies `scale` and
+    lays the result out as (O, C, kh, kw)."""
     lib = _lib.load()
     from ._lib import ConvWgradDesc
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
@@ -1011,8 +1015,9 @@ def conv2d_x3_wgrad(dyP, xP, B, C, H, W, O, kh, kw, stride, pad):
     d.dy_hi, d.dy_lo, d.x_hi, d.x_lo, d.part = _p(dyP.hi), _p(dyP.lo), _p(xP.hi), _p(xP.lo), _p(part)
     d.B, d.C, d.H, d.W, d.O, d.kh, d.kw, d.stride, d.pad, d.nchunks = B, C, H, W, O, kh, kw, stride, pad, nch
     check(lib.cips_conv2d_x3_wgrad(_ct.byref(d), _stream()), "cips_conv2d_x3_wgrad")
-    dw = part.sum(0) if nch > 1 else part[0]
-    return dw.permute(1, 2, 0).reshape(O, C, kh, kw)
+    dw = torch.empty(O, C, kh, kw, device=xP.hi.device)
+    check(lib.cips_conv_wgrad_finish(_p(part), _p(dw), nch, kh * kw, O, C, float(scale), _stream()), "cips_conv_wgrad_finish")
+    return dw
 
 
 def modfc_prep_x3(W, s, eps=1e-8):

@@ -319,6 +319,13 @@ typedef struct cips_conv_wgrad_desc {
   int B, C, H, W, O, kh, kw, stride, pad, nchunks;
 } cips_conv_wgrad_desc;
 int cips_conv2d_x3_wgrad(const cips_conv_wgrad_desc* d, cips_stream_t stream);
+/* Tail of the weight gradient: dw (O, C, kh, kw) = scale * sum over chunks of part (nchunks, kh*kw, O, C); scale is
+ * EqualConv2d's 1/sqrt(C k^2) (discriminator.py:33, 44), which the autograd of `weight * scale` applies to the gradient. */
+int cips_conv_wgrad_finish(const float* part, float* dw, int nchunks, int taps, int O, int C, float scale,
+                           cips_stream_t stream);
+/* Activation operand of cips_conv2d_x3 / cips_conv2d_x3_wgrad: x (B, C, n = H*W) fp32 NCHW -> NHWC split planes
+ * t_hi, t_lo (B*n + 1, C) bf16, the last row zero (read wherever a tap falls into the padding).  C % 8 == 0, n % 4 == 0. */
+int cips_split_planes_nhwc(const float* x, void* t_hi, void* t_lo, int B, int C, int n, cips_stream_t stream);
 
 /* fp32 (rows, cols) [ldx] -> split bf16 planes row-major [rows][ldp] and/or transposed [cols][ldt]. */
 int cips_split_planes(const float* x, void* p_hi, void* p_lo, void* t_hi, void* t_lo, int rows, int cols,

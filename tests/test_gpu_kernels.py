@@ -254,8 +254,9 @@ def test_fused_march_forward_backward(img, S, b, noise_std, clamp, flags):
     geom = (b, img, img, S, zc, float(noise_std), ops._CLAMP[clamp], flags, True)
     with torch.no_grad():
         f0, d0 = net.march(sdict, geom, xg, yg, zg, c2w, jd, nd)
-    # (the FiLM vectors of net.march come from the grouped-linear kernel, those above from torch: equal to rounding)
-    assert max_rel(f0, o_fea) < 1e-5 and max_rel(d0, o_depth) < 1e-5
+    # (the FiLM vectors of net.march come from the grouped-linear kernel, those above from torch/hipBLASLt, whose
+    # summation order depends on the algorithm it picks on the box: equal to rounding amplified by the FiLM gains of ~30)
+    assert max_rel(f0, o_fea) < 5e-5 and max_rel(d0, o_depth) < 5e-5
     f1, d1 = net.march(sdict, geom, xg, yg, zg, c2w, jd, nd)
     assert torch.equal(f1, f0) and torch.equal(d1, d0)
     (f1 * up.to(d)).sum().backward()
@@ -718,7 +719,10 @@ def test_upfirdn2d_golden_and_fused_bias_act():
 
 @pytest.mark.parametrize("shape,down,pad", [((5, 64, 64), 1, (2, 2)), ((3, 63, 65), 1, (1, 1)), ((2, 200, 260), 1, (2, 2)),
                                             ((4, 65, 65), 2, (1, 1)), ((2, 130, 258), 2, (2, 2)), ((7, 16, 16), 1, (2, 1)),
-                                            ((3, 33, 31), 2, (1, 2)), ((1, 8, 1030), 1, (2, 2))])
+                                            ((3, 33, 31), 2, (1, 2)), ((1, 8, 1030), 1, (2, 2)),
+                                            # small planes: one-wave workgroups, many planes (the 32x32 ... 4x4 stages)
+                                            ((700, 32, 32), 1, (2, 2)), ((300, 16, 16), 2, (1, 1)), ((513, 8, 8), 1, (2, 2)),
+                                            ((100, 4, 4), 2, (1, 1)), ((70000, 4, 4), 1, (2, 2))])
 def test_upfirdn2d_blur_fast_path(shape, down, pad):
     """The LDS-tiled form of upfirdn2d the Blur layers take (up 1, minor 1, 4x4 kernel, down 1 or 2): whole planes,
     planes cut in row bands, odd sizes, asymmetric padding — against the oracle's restatement of upfirdn2d_native."""
@@ -891,3 +895,53 @@ def test_mapping_networks_on_hip_match_torch_modules():
             assert rel_err(zd.grad, z64.grad) < 2e-5, (zdim, b)
             for (k, p), (_, q) in zip(netd.named_parameters(), net64.named_parameters()):
                 assert rel_err(p.grad, q.grad) < 2e-5, (zdim, b, k)
+
+
+@pytest.mark.parametrize("cfg", [(2, 5, 65, 65, 3, 2, 0), (3, 4, 33, 17, 3, 2, 0), (2, 3, 16, 20, 3, 1, 1), (2, 6, 31, 31, 1, 2, 0),
+                                 (1, 7, 9, 9, 1, 1, 0), (2, 3, 7, 7, 4, 1, 0), (2, 3, 12, 12, 2, 2, 1), (1, 2, 257, 257, 3, 2, 0)])
+def test_col2im_matches_fold(cfg):
+    """cips_col2im (compile-time geometries and the generic kernel) against torch.nn.functional.fold: the adjoint of
+    im2col, (B, C kh kw, Ho Wo) -> (B, C, H, W); integer-valued inputs make every summation order exact"""
+    from cips3d_amd import ops
+    B, C, H, W, k, stride, pad = cfg
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(13)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    col = torch.randint(-8, 9, (B, C * k * k, Ho * Wo), generator=g).float()
+    ref = torch.nn.functional.fold(col, (H, W), kernel_size=k, stride=stride, padding=pad)
+    dx = ops.col2im(col.to(d), B, C, H, W, k, k, stride, pad)
+    assert dx.shape == ref.shape and torch.equal(dx.cpu(), ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 96, 17, 12), (1, 32, 65, 65 - 1), (2, 8, 2, 2), (4, 256, 64, 64)])
+def test_split_planes_nhwc_equals_generic_split(shape):
+    """cips_split_planes_nhwc (64 x 64 tiles, in-kernel zero row) against the generic transposing cips_split_planes: the
+    same RNE hi / lo split, bit for bit, and hi + lo reproduces x to 2^-16 relative"""
+    from cips3d_amd import ops, _lib
+    B, C, H, W = shape
+    d = torch.device("cuda:0")
+    x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(C + H)).to(d)
+    P = ops.split_planes_nhwc(x)
+    n = H * W
+    assert P.hi.shape == (B * n + 1, C) and not P.hi[B * n:].any() and not P.lo[B * n:].any()
+    lib = _lib.load()
+    hi = torch.empty(B * n, C, device=d, dtype=torch.bfloat16); lo = torch.empty_like(hi)
+    _lib.check(lib.cips_split_planes(ops._p(x), None, None, ops._p(hi), ops._p(lo), C, n, n, n, C, B, C * n, C * n, C * n,
+                                     ops._stream()), "cips_split_planes")
+    assert torch.equal(P.hi[:B * n], hi) and torch.equal(P.lo[:B * n], lo)
+    back = (P.hi[:B * n].float() + P.lo[:B * n].float()).view(B, n, C).permute(0, 2, 1).reshape(B, C, H, W)
+    assert float((back - x).abs().max()) <= float(x.abs().max()) * 2.0 ** -15
+
+
+def test_conv_wgrad_finish_sums_scales_and_permutes():
+    from cips3d_amd import ops, _lib
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    for (nch, taps, O, C, scale) in [(1, 9, 32, 64, 1.0), (4, 9, 64, 32, 0.125), (8, 1, 96, 32, 0.3), (3, 16, 8, 8, 2.0)]:
+        part = torch.randn(nch, taps, O, C, generator=g).to(d)
+        dw = torch.empty(O, C, taps, device=d)
+        _lib.check(_lib.load().cips_conv_wgrad_finish(ops._p(part), ops._p(dw), nch, taps, O, C, scale, ops._stream()), "finish")
+        acc = part[0].clone()
+        for ch in range(1, nch):
+            acc += part[ch]
+        assert torch.equal(dw, (acc * scale).permute(1, 2, 0).contiguous())
