@@ -98,13 +98,13 @@ def test_siren_forward(trig, b, P, monkeypatch):
     with torch.no_grad():
         ref = orc.siren(sd, pts, style)
     Gd = G.to(dev())
-    ops.TRIG_MODE = trig
+    old_trig, ops.TRIG_MODE = ops.TRIG_MODE, trig
     try:
         with torch.no_grad():
             sdict = {"nerf_w0": style.to(dev()), "nerf_w1": style.to(dev()), "nerf_rgb": style.to(dev())}
             out = Gd.siren(pts.to(dev()), sdict)
     finally:
-        ops.TRIG_MODE = 0
+        ops.TRIG_MODE = old_trig
     torch.cuda.synchronize()
     e_f, e_s = max_rel(out[..., :32], ref[..., :32]), max_rel(out[..., 32], ref[..., 32])
     print(f"siren fwd trig={trig} b={b} P={P}: feat max_rel {e_f:.3e} sigma max_rel {e_s:.3e}")
@@ -122,12 +122,12 @@ def test_siren_forward_x3(trig, b, P, monkeypatch):
         ref = orc.siren(sd, pts, style)
     Gd = G.to(dev())
     st = style.to(dev())
-    ops.TRIG_MODE = trig
+    old_trig, ops.TRIG_MODE = ops.TRIG_MODE, trig
     try:
         with torch.no_grad():
             out = Gd.siren(pts.to(dev()), {"nerf_w0": st, "nerf_w1": st, "nerf_rgb": st})
     finally:
-        ops.TRIG_MODE = 0
+        ops.TRIG_MODE = old_trig
     torch.cuda.synchronize()
     e_f, e_s = max_rel(out[..., :32], ref[..., :32]), max_rel(out[..., 32], ref[..., 32])
     print(f"siren fwd x3 trig={trig} b={b} P={P}: feat max_rel {e_f:.3e} sigma max_rel {e_s:.3e}")
@@ -152,12 +152,12 @@ def test_siren_backward(trig, mode, b, P, monkeypatch):
     G.zero_grad()
     Gd = G.to(dev())
     st = style.to(dev()).requires_grad_(True)
-    ops.TRIG_MODE = trig
+    old_trig, ops.TRIG_MODE = ops.TRIG_MODE, trig
     try:
         out = Gd.siren(pts.to(dev()), {"nerf_w0": st, "nerf_w1": st, "nerf_rgb": st})
         (out * up.to(dev())).sum().backward()
     finally:
-        ops.TRIG_MODE = 0
+        ops.TRIG_MODE = old_trig
     torch.cuda.synchronize()
     worst = 0.0
     for n, p in Gd.siren.named_parameters():
