@@ -114,6 +114,8 @@ SIGNATURES = {
     "cips_gemm_bf16x3_set_wide": (None, [i32]),
     "cips_gemm_bf16x3_km": (i32, [C.POINTER(GemmX3Desc), vp]),
     "cips_gemm_bf16x3_km_grouped": (i32, [C.POINTER(GemmX3Desc), i32, vp]),
+    "cips_lrelu_bwd_bias_slices": (i32, [i32]),
+    "cips_lrelu_bwd_bias": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, vp]),
     "cips_conv1x1_smallk": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_conv1x1_smallk_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_conv1x1_smallk_bwd_weight_splits": (i32, [i32, i32]),

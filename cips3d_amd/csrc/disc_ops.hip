@@ -717,6 +717,44 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
   return CIPS_CHECK_LAUNCH();
 }
 
+// Backward of FusedLeakyReLU on a (B, C, H, W) activation with the bias gradient in the same pass (fused_act.py:26-44:
+// grad_input = fused_bias_act(grad_output, empty, out, 3, 1, slope, scale); grad_bias = grad_input.sum(0, 2, 3)):
+//   gin = (ref > 0 ? g : g * alpha) * scale,   part[plane][slice] = sum of gin over the slice of plane (b, c).
+// The caller adds part over images and slices (B * C * slices floats) instead of re-reading the whole gradient.
+__global__ __launch_bounds__(256) void lrelu_bwd_bias_kernel(const float* __restrict__ g, const float* __restrict__ ref,
+                                                             float* __restrict__ gin, float* __restrict__ part, int hw, int per,
+                                                             float alpha, float scale) {
+  __shared__ float red[4];
+  const long long base = (long long)blockIdx.x * hw;
+  const int lo = blockIdx.y * per, hi = min(hw, lo + per);
+  float acc = 0.f;
+  if ((hw & 3) == 0 && (per & 3) == 0) {
+    const float4* g4 = reinterpret_cast<const float4*>(g + base);
+    const float4* r4 = reinterpret_cast<const float4*>(ref + base);
+    float4* o4 = reinterpret_cast<float4*>(gin + base);
+    for (int i = lo / 4 + (int)threadIdx.x; i < hi / 4; i += 256) {
+      const float4 v = g4[i], r = r4[i];
+      float4 o;
+      o.x = (r.x > 0.f ? v.x : v.x * alpha) * scale; o.y = (r.y > 0.f ? v.y : v.y * alpha) * scale;
+      o.z = (r.z > 0.f ? v.z : v.z * alpha) * scale; o.w = (r.w > 0.f ? v.w : v.w * alpha) * scale;
+      o4[i] = o;
+      acc += (o.x + o.y) + (o.z + o.w);
+    }
+  } else {
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) {
+      const float v = g[base + i], r = ref[base + i];
+      const float o = (r > 0.f ? v : v * alpha) * scale;
+      gin[base + i] = o;
+      acc += o;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(long long)blockIdx.x * gridDim.y + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // Weight gradient of the same layer: dw[o][c] = sum_{b,p} dy[b][o][p] x[b][c][p] — O*C dot products over B*HW pixels.
 // As a GEMM this is one 128-row tile per image with a contraction of 65 536 (r256): four workgroups on the whole chip,
 // 4.6 ms.  Here a workgroup owns one output channel and one slice of the pixel range of every image (16-byte loads, the
@@ -756,6 +794,23 @@ __global__ __launch_bounds__(256) void conv1x1_smallk_bwd_weight_kernel(const fl
     const int c = threadIdx.x;
     part[((long long)s * O + o) * C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
   }
+}
+
+extern "C" int cips_lrelu_bwd_bias_slices(int HW) {
+  if (HW <= 0) return 0;
+  int S = HW / 4096;                          // >= 4096 elements (16 per thread) per slice
+  return S < 1 ? 1 : (S > 64 ? 64 : S);
+}
+
+extern "C" int cips_lrelu_bwd_bias(const float* grad, const float* refer, float* grad_in, float* part, long long planes, int HW,
+                                   float alpha, float scale, cips_stream_t stream) {
+  if (!grad || !refer || !grad_in || !part || planes <= 0 || planes > 0x7fffffffLL || HW <= 0) return (int)hipErrorInvalidValue;
+  const int S = cips_lrelu_bwd_bias_slices(HW);
+  int per = (HW + S - 1) / S;
+  per = (per + 3) & ~3;
+  hipLaunchKernelGGL(lrelu_bwd_bias_kernel, dim3((unsigned)planes, S), dim3(256), 0, (hipStream_t)stream, grad, refer, grad_in,
+                     part, HW, per, alpha, scale);
+  return CIPS_CHECK_LAUNCH();
 }
 
 extern "C" int cips_conv1x1_smallk(const float* x, const float* w, float* y, int B, int C, int O, int HW,

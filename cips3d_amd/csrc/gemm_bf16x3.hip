@@ -699,6 +699,7 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict
   __shared__ __attribute__((aligned(16))) u16 sh[64][72], sl[64][72];      // [n local][c local], 144-byte rows
   const int b = blockIdx.z, c0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const int t = threadIdx.x;
+  const bool vec = (n & 3) == 0;
   const float* xb = x + (long long)b * C * n;
   {
     const int col4 = t & 15, r_ = t >> 4;                // 16 float4 per 64-float row, 16 rows per pass
@@ -706,7 +707,16 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict
     for (int k = 0; k < 4; ++k) {
       const int cl = r_ + 16 * k, c = c0 + cl, nn = n0 + 4 * col4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < C && nn < n) v = *reinterpret_cast<const float4*>(xb + (long long)c * n + nn);      // n % 4 == 0
+      if (c < C && nn < n) {
+        const float* q = xb + (long long)c * n + nn;
+        if (vec) v = *reinterpret_cast<const float4*>(q);                   // n % 4 == 0: rows are 16-byte aligned
+        else {                                                              // odd planes (65 x 65 blur outputs ...)
+          v.x = q[0];
+          if (nn + 1 < n) v.y = q[1];
+          if (nn + 2 < n) v.z = q[2];
+          if (nn + 3 < n) v.w = q[3];
+        }
+      }
       u16 h, l;
       split2(v.x, h, l); sh[4 * col4 + 0][cl] = h; sl[4 * col4 + 0][cl] = l;
       split2(v.y, h, l); sh[4 * col4 + 1][cl] = h; sl[4 * col4 + 1][cl] = l;
@@ -866,7 +876,7 @@ extern "C" int cips_split_planes(const float* x, void* p_hi, void* p_lo, void* t
 }
 
 extern "C" int cips_split_planes_nhwc(const float* x, void* t_hi, void* t_lo, int B, int C, int n, cips_stream_t stream) {
-  if (!x || !t_hi || !t_lo || B <= 0 || C <= 0 || n <= 0 || (C & 7) || (n & 3)) return (int)hipErrorInvalidValue;
+  if (!x || !t_hi || !t_lo || B <= 0 || C <= 0 || n <= 0 || (C & 7)) return (int)hipErrorInvalidValue;
   dim3 grid((n + 63) / 64, (C + 63) / 64, B);
   hipLaunchKernelGGL(split_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (u16*)t_hi, (u16*)t_lo, C, n, B);
   return CIPS_CHECK_LAUNCH();

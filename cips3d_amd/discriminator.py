@@ -51,11 +51,17 @@ class gate_debug:
         GATE_PIN, GATE_REC = self.old
 
 
+_ACT_BWD_FUSED = __import__("os").environ.get("CIPS_D_ACT_BWD_FUSED", "1") != "0"
+
+
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, out, negative_slope, scale):
         ctx.save_for_backward(out)
         ctx.negative_slope, ctx.scale = negative_slope, scale
+        if (_ACT_BWD_FUSED and grad_output.dim() == 4 and grad_output.dtype == torch.float32 and out.dtype == torch.float32
+                and grad_output.is_cuda and grad_output.is_contiguous() and out.is_contiguous()):
+            return ops.lrelu_bwd_bias(grad_output, out, negative_slope, scale)     # one pass: gated gradient + bias sums
         empty = grad_output.new_empty(0)
         grad_input = ops.fused_bias_act(grad_output, empty, out, 3, 1, negative_slope, scale)
         dim = [0] + list(range(2, grad_input.ndim))

@@ -966,7 +966,7 @@ def split_planes_nhwc(x):
     n = H * W
     hi = torch.empty(B * n + 1, C, device=x.device, dtype=BF)
     lo = torch.empty(B * n + 1, C, device=x.device, dtype=BF)
-    if C % 8 == 0 and n % 4 == 0 and x.dtype == torch.float32 and x.is_contiguous():
+    if C % 8 == 0 and x.dtype == torch.float32 and x.is_contiguous():
         check(lib.cips_split_planes_nhwc(_p(x), _p(hi), _p(lo), B, C, n, _stream()), "cips_split_planes_nhwc")
         return Planes(hi, lo)
     hi[B * n:].zero_(); lo[B * n:].zero_()
@@ -1330,6 +1330,21 @@ def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
         check(lib.cips_fused_bias_act(_p(x), _p(b), _p(r), _p(y), x.numel(), size_b, step_b, act, grad, float(alpha),
                                       float(scale), _stream()), "cips_fused_bias_act")
     return y if input.dtype == torch.float32 else y.to(input.dtype)
+
+
+def lrelu_bwd_bias(grad, refer, alpha, scale):
+    """grad, refer (B, C, H, W) fp32 contiguous -> (grad_input, grad_bias (C)): FusedLeakyReLU's backward with the bias
+    gradient accumulated in the same pass"""
+    lib = _lib.load()
+    B, C = grad.shape[0], grad.shape[1]
+    hw = grad.numel() // (B * C)
+    S = lib.cips_lrelu_bwd_bias_slices(hw)
+    gin = torch.empty_like(grad)
+    part = torch.empty(B, C, S, device=grad.device)
+    with torch.cuda.device(grad.device):
+        check(lib.cips_lrelu_bwd_bias(_p(grad), _p(refer), _p(gin), _p(part), B * C, hw, float(alpha), float(scale), _stream()),
+              "cips_lrelu_bwd_bias")
+    return gin, part.sum((0, 2))
 
 
 def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):

@@ -324,7 +324,8 @@ int cips_conv2d_x3_wgrad(const cips_conv_wgrad_desc* d, cips_stream_t stream);
 int cips_conv_wgrad_finish(const float* part, float* dw, int nchunks, int taps, int O, int C, float scale,
                            cips_stream_t stream);
 /* Activation operand of cips_conv2d_x3 / cips_conv2d_x3_wgrad: x (B, C, n = H*W) fp32 NCHW -> NHWC split planes
- * t_hi, t_lo (B*n + 1, C) bf16, the last row zero (read wherever a tap falls into the padding).  C % 8 == 0, n % 4 == 0. */
+ * t_hi, t_lo (B*n + 1, C) bf16, the last row zero (read wherever a tap falls into the padding).  C % 8 == 0 (n % 4 == 0 takes
+ * 16-byte loads, any other n scalar loads). */
 int cips_split_planes_nhwc(const float* x, void* t_hi, void* t_lo, int B, int C, int n, cips_stream_t stream);
 
 /* fp32 (rows, cols) [ldx] -> split bf16 planes row-major [rows][ldp] and/or transposed [cols][ldt]. */
@@ -458,6 +459,14 @@ int cips_axpby(const float* x, const float* y, float* out, float a, float b, lon
  * * 255, + 0.5, clamp to [0, 255], truncate.  Bit-exact on identical float inputs. */
 int cips_image_to_u8(const float* x, unsigned char* out, int B, int C, int H, int W, float lo, float hi,
                      cips_stream_t stream);
+
+/* Backward of FusedLeakyReLU on a (B, C, H, W) activation (exp/comm/op/fused_act.py:26-44) with the bias gradient in the
+ * same pass: grad_in = (refer > 0 ? grad : grad * alpha) * scale — cips_fused_bias_act(act 3, grad 1) — and
+ * part[plane][slice] = sum of grad_in over slice `slice` of plane (b, c); planes = B * C, slices =
+ * cips_lrelu_bwd_bias_slices(HW); the caller adds part over images and slices to get grad_bias (C). */
+int cips_lrelu_bwd_bias_slices(int HW);
+int cips_lrelu_bwd_bias(const float* grad, const float* refer, float* grad_in, float* part, long long planes, int HW,
+                        float alpha, float scale, cips_stream_t stream);
 
 /* 1x1 convolution with C <= 4 input channels (EqualConv2d of the RGB input layers, discriminator.py:457-459):
  * y (B, O, HW) = w (O, C) . x (B, C, HW); HW % 4 == 0.  Streaming kernel, no GEMM. */

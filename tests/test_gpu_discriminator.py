@@ -299,3 +299,19 @@ def test_diffaug_sums_at_256_match_torch():
         finally:
             dm.DIFFAUG_HIP = old
     assert max_rel(outs[0], outs[1]) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (3, 5, 65, 65), (1, 4, 256, 256), (2, 3, 7, 5), (4, 512, 4, 4)])
+def test_lrelu_backward_with_bias_gradient_in_one_pass(shape):
+    """cips_lrelu_bwd_bias against the two-step form it replaces (cips_fused_bias_act act 3 grad 1, then a torch
+    reduction): the gated gradient bit for bit, the bias gradient to summation order"""
+    from cips3d_amd import ops
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(shape))
+    grad = torch.randn(*shape, generator=g).to(d)
+    out = torch.randn(*shape, generator=g).to(d)
+    gin, gb = ops.lrelu_bwd_bias(grad, out, 0.2, 2 ** 0.5)
+    ref = ops.fused_bias_act(grad, grad.new_empty(0), out, 3, 1, 0.2, 2 ** 0.5)
+    assert torch.equal(gin, ref)
+    want = ref.double().sum((0, 2, 3))
+    assert gb.shape == (shape[1],) and float((gb.double() - want).abs().max()) <= 1e-5 * float(ref.abs().sum((0, 2, 3)).max())
