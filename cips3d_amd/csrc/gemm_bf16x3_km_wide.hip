@@ -39,7 +39,7 @@ constexpr int MAXG = 4;
 struct KConv {
   int C, H, W, kw, stride, pad, Ho, Wo, ntap;
   long long zero_row;          // row index of the zero row
-  long long kchunk;            // pixels per chunk
+  int ktiles, nchunks;         // the pixel range is ktiles 32-row k-tiles; chunk c takes k-tiles [c*ktiles/nchunks, (c+1)*ktiles/nchunks)
 };
 struct KArgs {
   cips_gemm_x3_desc d;               // shape, leading dimensions, strides (common to the group)
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_km_wide_kernel(KArgs g) {
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = uw, wm = wave >> 1, wn = wave & 1;       // 4 x 2 waves, 64 x 128 outputs each
   const int M = d.M, N = d.N;
-  const int nk = d.K / BK;
+  const int nk_all = d.K / BK;
   const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
   for (int tseq = blockIdx.x; tseq < g.total; tseq += gridDim.x) {
@@ -79,8 +79,11 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_km_wide_kernel(KArgs g) {
     const int gi = bid / (g.tiles_n * g.tiles_m * d.batch);       // problem of the group (uniform); CONV: the tap
     const int m0 = tm * BM, n0 = tn * BN;
     const int gp = CONV ? 0 : gi;
-    const u16* Ahi = (const u16*)g.A_hi[gp] + (long long)bz * d.strideA;
-    const u16* Alo = (const u16*)g.A_lo[gp] + (long long)bz * d.strideA;
+    // CONV: ragged chunks of the pixel range (any chunk count fills the chip: powers of two left 144 of 256 CUs busy)
+    const long long kt0 = CONV ? (long long)bz * g.cv.ktiles / g.cv.nchunks : 0;
+    const int nk = CONV ? (int)((long long)(bz + 1) * g.cv.ktiles / g.cv.nchunks - kt0) : nk_all;
+    const u16* Ahi = (const u16*)g.A_hi[gp] + (CONV ? kt0 * BK * d.lda : (long long)bz * d.strideA);
+    const u16* Alo = (const u16*)g.A_lo[gp] + (CONV ? kt0 * BK * d.lda : (long long)bz * d.strideA);
     const u16* Bhi = (const u16*)g.B_hi[gp] + (CONV ? 0 : (long long)bz * d.strideB);
     const u16* Blo = (const u16*)g.B_lo[gp] + (CONV ? 0 : (long long)bz * d.strideB);
     float* Cg = g.C[gp] + (CONV ? (long long)gi * d.M * d.ldc : 0);       // CONV: strideC spans all taps of a chunk
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_km_wide_kernel(KArgs g) {
     unsigned cvoff[2] = {0, 0};            // offsets of the two B pieces (idx = uw, uw + 8) of the k-tile being issued
     auto conv_prep = [&](int k0) {
       if constexpr (CONV) {
-        const long long qb = (long long)bz * g.cv.kchunk + k0 + lh;
+        const long long qb = kt0 * BK + k0 + lh;
         cvoff[0] = conv_row_off(qb + 2 * uw, uw & 1);
         cvoff[1] = conv_row_off(qb + 2 * (uw + 8), uw & 1);      // (uw + 8) & 1 == uw & 1
       }
@@ -295,18 +298,17 @@ extern "C" int cips_conv2d_x3_wgrad(const cips_conv_wgrad_desc* c, cips_stream_t
   const int Ho = (c->H + 2 * c->pad - c->kh) / c->stride + 1, Wo = (c->W + 2 * c->pad - c->kw) / c->stride + 1;
   if (Ho <= 0 || Wo <= 0) return (int)hipErrorInvalidValue;
   const long long Kall = (long long)c->B * Ho * Wo;
-  if ((c->C & 7) || (c->O & 7) || Kall % ((long long)c->nchunks * 32)) return (int)hipErrorNotSupported;
+  if ((c->C & 7) || (c->O & 7) || (Kall & 31) || c->nchunks > Kall / 32) return (int)hipErrorNotSupported;
   const long long rows_x = (long long)c->B * c->H * c->W + 1;
   if (rows_x * c->C * 2 >= 0xffffffffLL || Kall * c->O * 2 >= 0x7fffffffffffLL) return (int)hipErrorNotSupported;
   KArgs g = {};
   cips_gemm_x3_desc& d = g.d;
-  const long long kchunk = Kall / c->nchunks;
-  d.M = c->O; d.N = c->C; d.K = (int)kchunk; d.lda = c->O; d.ldb = c->C; d.batch = c->nchunks;
-  d.strideA = kchunk * c->O; d.strideB = 0;
+  d.M = c->O; d.N = c->C; d.K = (int)(Kall / c->nchunks); d.lda = c->O; d.ldb = c->C; d.batch = c->nchunks;
+  d.strideA = 0; d.strideB = 0;                 // chunk starts come from (ktiles, nchunks) in the kernel
   d.ldc = c->C; d.strideC = (long long)c->kh * c->kw * c->O * c->C;
   g.A_hi[0] = c->dy_hi; g.A_lo[0] = c->dy_lo; g.B_hi[0] = c->x_hi; g.B_lo[0] = c->x_lo; g.C[0] = c->part;
   g.cv.C = c->C; g.cv.H = c->H; g.cv.W = c->W; g.cv.kw = c->kw; g.cv.stride = c->stride; g.cv.pad = c->pad;
-  g.cv.Ho = Ho; g.cv.Wo = Wo; g.cv.ntap = c->kh * c->kw; g.cv.zero_row = rows_x - 1; g.cv.kchunk = kchunk;
+  g.cv.Ho = Ho; g.cv.Wo = Wo; g.cv.ntap = c->kh * c->kw; g.cv.zero_row = rows_x - 1; g.cv.ktiles = (int)(Kall / 32); g.cv.nchunks = c->nchunks;
   g.tiles_m = (d.M + BM - 1) / BM;
   g.tiles_n = (d.N + BN - 1) / BN;
   g.ngroups = g.cv.ntap;

@@ -989,7 +989,7 @@ def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad):
     return y
 
 
-def conv2d_x3_wgrad(dyP, xP, B, C, H, W, O, kh, kw, stride, pad, scale=1.0):
+def conv2d_x3_wgrad(dyP, xP, B, C, H, W, O, kh, kw, stride, pad, scale=1.0, nch=None):
     """Weight gradient of conv2d_x3: dyP, xP NHWC Planes from split_planes_nhwc -> dW (O, C, kh, kw) fp32, or None when
     the pixel count does not split into 32-row k-tiles.  The pixel range is cut into chunks so that a 512x512 filter bank
     still fills the chip (4 tiles per tap and chunk); cips_conv_wgrad_finish adds the partial sums, applies `scale` and
@@ -1000,16 +1000,21 @@ def conv2d_x3_wgrad(dyP, xP, B, C, H, W, O, kh, kw, stride, pad, scale=1.0):
     K = B * Ho * Wo
     if K % 32:
         return None
-    # chunks of the pixel range: the persistent grid runs ceil(tiles*nch / 256) rounds of K/nch rows each (+ an
-    # epilogue worth ~512 rows); 36 tiles x 8 chunks = 288 would leave the second round 7/8 empty
+    # chunks of the pixel range: the persistent grid runs ceil(tiles*nch / 256) rounds of ~K/nch rows each (+ an
+    # epilogue worth ~512 rows); 36 tiles x 7 chunks = 252 of 256 CUs in one round (powers of two: 144, or 288 in two)
     tiles = ((O + 255) // 256) * ((C + 255) // 256) * kh * kw
-    nch, best = 1, None
-    for cand in (1, 2, 4, 8, 16, 32, 64):
-        if K % (32 * cand) or (cand > 1 and K // cand < 256):
-            continue
-        cost = -(-tiles * cand // 256) * (K // cand + 512)
+    T = K // 32
+    best = None
+    forced = nch
+    nch = 1
+    for cand in range(1, 33):                   # any count: the kernel cuts the range at k-tile granularity
+        if cand > 1 and T // cand < 8:
+            break
+        cost = -(-tiles * cand // 256) * (-(-T // cand) * 32 + 512)
         if best is None or cost < best:
             nch, best = cand, cost
+    if forced is not None:
+        nch = forced
     part = torch.empty(nch, kh * kw, O, C, device=xP.hi.device)
     d = ConvWgradDesc()
     d.dy_hi, d.dy_lo, d.x_hi, d.x_lo, d.part = _p(dyP.hi), _p(dyP.lo), _p(xP.hi), _p(xP.lo), _p(part)

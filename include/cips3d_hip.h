@@ -311,7 +311,9 @@ int cips_conv2d_x3(const cips_conv_x3_desc* d, cips_stream_t stream);
  * `nchunks` ranges whose partial sums the caller adds):
  *   part[chunk][ky*kw+kx][o][c] = sum_{q in chunk} dy[q][o] * x[pixel(q)*stride - pad + (ky,kx)][c]
  * dy: NHWC split planes [B*Ho*Wo][O]; x: NHWC split planes [B*H*W + 1][C] with a ZERO LAST ROW; part: fp32
- * (nchunks, kh*kw, O, C).  O, C multiples of 8, B*Ho*Wo % (32*nchunks) == 0; else hipErrorNotSupported. */
+ * (nchunks, kh*kw, O, C).  The pixel range is cut at 32-row granularity into nchunks nearly equal ranges (chunk c takes
+ * k-tiles [c*T/nchunks, (c+1)*T/nchunks), T = B*Ho*Wo/32).  O, C multiples of 8, B*Ho*Wo % 32 == 0, nchunks <= T; else
+ * hipErrorNotSupported. */
 typedef struct cips_conv_wgrad_desc {
   const void* dy_hi; const void* dy_lo;
   const void* x_hi; const void* x_lo;
