@@ -79,7 +79,7 @@ class GemmX3Desc(C.Structure):
 class ConvX3Desc(C.Structure):
     _fields_ = [("w_hi", vp), ("w_lo", vp), ("x_hi", vp), ("x_lo", vp), ("y", vp),
                 ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("O", i32), ("kh", i32), ("kw", i32),
-                ("stride", i32), ("pad", i32)]
+                ("stride", i32), ("pad", i32), ("ksplit", i32), ("part", vp)]
 
 
 class ConvWgradDesc(C.Structure):
@@ -124,6 +124,7 @@ SIGNATURES = {
     "cips_conv2d_x3_wgrad": (i32, [C.POINTER(ConvWgradDesc), vp]),
     "cips_split_planes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
     "cips_split_planes_nhwc": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "cips_conv2d_x3_ksplit": (i32, [i32, i32, i32, i32]),
     "cips_conv_wgrad_finish": (i32, [vp, vp, i32, i32, i32, i32, f32, vp]),
     "cips_modfc_prep_x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cips_torgb_fwd_x3": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),

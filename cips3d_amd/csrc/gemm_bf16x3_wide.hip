@@ -61,6 +61,8 @@ struct ConvGeom {
 struct WArgs {
   cips_gemm_x3_desc d;
   int tiles_m, tiles_n, total, dbg;
+  int ksplit;                  // > 1: the contraction is cut into ksplit ranges of k-tiles (chunk c takes k-tiles
+                               // [c*T/ksplit, (c+1)*T/ksplit)); chunk c of batch entry b writes C + (c*batch + b)*strideC
   ConvGeom cv;
 };
 
@@ -82,12 +84,13 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = uw, wm = wave >> 1, wn = wave & 1;       // 4 x 2 waves
   const int M = d.M, N = d.N, K = d.K;
-  const int nk = (g.dbg & 4) ? 0 : K / BK;
+  const int nk_all = (g.dbg & 4) ? 0 : K / BK;
+  const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
   const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
 #define LDS_B128(a) (*((__attribute__((address_space(3))) const bf16x8*)(uintptr_t)(a)))
 
   // tile coordinates of sequence number t (XCD-contiguous tile ranges, see gemm_bf16x3.hip)
-  auto decode = [&](int t, int& tm, int& tn, int& bz) {
+  auto decode = [&](int t, int& tm, int& tn, int& bz, int& kc) {
     const int nx = 8;
     int q = g.total / nx, r = g.total % nx;
     int xcd = t % nx, idx = t / nx;
@@ -95,24 +98,28 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
     const int bid = base + idx;
     tn = bid % g.tiles_n;
     tm = (bid / g.tiles_n) % g.tiles_m;
-    bz = bid / (g.tiles_n * g.tiles_m);
+    const int bk = bid / (g.tiles_n * g.tiles_m);
+    kc = bk % ksplit;
+    bz = bk / ksplit;
   };
+  auto chunk_kt0 = [&](int kc) -> int { return (int)((long long)kc * nk_all / ksplit); };
   // LDS-DMA of one k-tile: a wave instruction moves 16 rows x 64 B of one plane; lane L = (row L>>2, slot L&3) fetches
   // the global 16-byte chunk slot ^ ((row>>2)&3) — the swizzle lives in the source address.  Addresses are a uniform
   // plane pointer (advanced by k0 on the scalar side) plus one 32-bit byte offset per piece and lane; rows past
   // M / N are clamped (their products are never stored).
-  struct Src { const u16 *Ahi, *Alo, *Bhi, *Blo; unsigned offA[2], offB[2]; int iy0[2], ix0[2]; unsigned chunk[2], zero_rel; };
-  auto make_src = [&](int tm, int tn, int bz, int lane, Src& sr) {
+  struct Src { const u16 *Ahi, *Alo, *Bhi, *Blo; unsigned offA[2], offB[2]; int iy0[2], ix0[2]; unsigned chunk[2], zero_rel; int kbase; };
+  auto make_src = [&](int tm, int tn, int bz, int kc, int lane, Src& sr) {
     const int m0 = tm * BM, n0 = tn * BN;
-    sr.Ahi = (const u16*)d.A_hi + (long long)bz * d.strideA + (long long)m0 * d.lda;
-    sr.Alo = (const u16*)d.A_lo + (long long)bz * d.strideA + (long long)m0 * d.lda;
+    sr.kbase = chunk_kt0(kc) * BK;                         // first contraction index of this tile's chunk
+    sr.Ahi = (const u16*)d.A_hi + (long long)bz * d.strideA + (long long)m0 * d.lda + sr.kbase;
+    sr.Alo = (const u16*)d.A_lo + (long long)bz * d.strideA + (long long)m0 * d.lda + sr.kbase;
     if constexpr (CONV) {
       sr.Bhi = (const u16*)d.B_hi + (long long)bz * g.cv.img_stride;
       sr.Blo = (const u16*)d.B_lo + (long long)bz * g.cv.img_stride;
       sr.zero_rel = (unsigned)((g.cv.zero_elem - (long long)bz * g.cv.img_stride) * 2);
     } else {
-      sr.Bhi = (const u16*)d.B_hi + (long long)bz * d.strideB + (long long)n0 * d.ldb;
-      sr.Blo = (const u16*)d.B_lo + (long long)bz * d.strideB + (long long)n0 * d.ldb;
+      sr.Bhi = (const u16*)d.B_hi + (long long)bz * d.strideB + (long long)n0 * d.ldb + sr.kbase;
+      sr.Blo = (const u16*)d.B_lo + (long long)bz * d.strideB + (long long)n0 * d.ldb + sr.kbase;
     }
     const int drow = lane >> 2, dslot = lane & 3;
 #pragma unroll
@@ -135,7 +142,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
   // convolution it refreshes the two per-lane byte offsets instead (tap = k0 / C, 32 channels from k0 % C)
   auto prep_b = [&](Src& sr, int k0) -> int {
     if constexpr (CONV) {
-      const int tap = k0 / g.cv.C, c0 = k0 - tap * g.cv.C;
+      const int kk = k0 + sr.kbase;
+      const int tap = kk / g.cv.C, c0 = kk - tap * g.cv.C;
       const int ky = tap / g.cv.kw, kx = tap - ky * g.cv.kw;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
@@ -174,11 +182,12 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int l31 = lane & 31, hf = lane >> 5;
-    int tm, tn, bz;
-    decode(tseq, tm, tn, bz);
+    int tm, tn, bz, kc;
+    decode(tseq, tm, tn, bz, kc);
     const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = chunk_kt0(kc + 1) - chunk_kt0(kc);      // k-tiles of this tile's chunk (all of them when ksplit == 1)
     Src src;
-    make_src(tm, tn, bz, lane, src);
+    make_src(tm, tn, bz, kc, lane, src);
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
     };
 
     // ---------------- epilogue plumbing (declared first: the first sub-tiles' inputs are requested around the last k-tile)
-    const long long cb = (long long)bz * d.strideC, pb = (long long)bz * d.strideP;
+    const long long cb = ((long long)kc * d.batch + bz) * d.strideC, pb = (long long)bz * d.strideP;
     u16* Phi = (u16*)d.P_hi; u16* Plo = (u16*)d.P_lo;
     float* sc_f = reinterpret_cast<float*>(smem + STAGE + wave * SCR_WAVE);      // inside stage 1
     // sub-tile st = 4*i + jj: rows wm*64 + 32 i .., columns wn*128 + 32 jj ..   (one MFMA tile).  Row-contiguous form:
@@ -302,10 +311,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
     // ---------------- the next output tile's first k-tile streams into stage 0 while this tile's epilogue runs
     first_issued = false;
     if (nk > 0 && (nk & 1) == 0 && tseq + (int)gridDim.x < g.total && !(g.dbg & 2)) {
-      int tm2, tn2, bz2;
-      decode(tseq + gridDim.x, tm2, tn2, bz2);
+      int tm2, tn2, bz2, kc2;
+      decode(tseq + gridDim.x, tm2, tn2, bz2, kc2);
       Src nsrc;
-      make_src(tm2, tn2, bz2, lane, nsrc);
+      make_src(tm2, tn2, bz2, kc2, lane, nsrc);
       const int kbn0 = prep_b(nsrc, 0);
 #pragma unroll
       for (int pc = 0; pc < 8; ++pc) dma_piece(nsrc, pc, 0, kbn0, smem);
@@ -459,6 +468,19 @@ static int wide_grid(int total) {
   return total < ncu ? total : ncu;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void sum_chunks_kernel(const float4* __restrict__ part, float4* __restrict__ y, int nch, long long n4) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += gridDim.x * 256LL) {
+    float4 v = part[i];
+    for (int c = 1; c < nch; ++c) {
+      const float4 u = part[c * n4 + i];
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    y[i] = v;
+  }
+}
+}  // namespace
+
 // Implicit-GEMM convolution (see include/cips3d_hip.h): y[b] (O, Ho*Wo) = Wp (O, kh*kw*C) . gather(x[b])^T
 extern "C" int cips_conv2d_x3(const cips_conv_x3_desc* c, cips_stream_t stream) {
   if (!c || c->B <= 0 || c->C <= 0 || c->O <= 0 || c->H <= 0 || c->W <= 0 || c->kh <= 0 || c->kw <= 0 || c->stride <= 0 || c->pad < 0)
@@ -478,12 +500,37 @@ extern "C" int cips_conv2d_x3(const cips_conv_x3_desc* c, cips_stream_t stream) 
   g.cv.img_stride = img; g.cv.zero_elem = img * c->B;
   g.tiles_m = (d.M + BM - 1) / BM;
   g.tiles_n = (d.N + BN - 1) / BN;
-  const long long total = (long long)g.tiles_m * g.tiles_n * d.batch;
+  const int ks = c->ksplit > 1 ? c->ksplit : 1;
+  if (ks > 1 && (!c->part || ks > (int)(K / 32))) return (int)hipErrorInvalidValue;
+  if (ks > 1) d.C = c->part;                    // chunk c of image b -> part[c][b]; summed into y below
+  g.ksplit = ks;
+  const long long total = (long long)g.tiles_m * g.tiles_n * d.batch * ks;
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
   g.dbg = 0;
   launch_wide<false, false, false, true>(g, wide_grid(g.total), (hipStream_t)stream);
+  if (ks > 1) {
+    const long long n4 = (long long)c->B * c->O * N / 4;        // N % 8 == 0
+    const long long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(c->part), reinterpret_cast<float4*>(c->y), ks, n4);
+  }
   return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_conv2d_x3_ksplit(int B, int O, int N, int K) {
+  // chunks of the contraction that fill the chip when the output has few 256 x 256 tiles (16 x 16 planes: 64 of 256 CUs)
+  const long long tiles = (long long)((O + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
+  const int T = K / 32;
+  int best = 1;
+  long long best_cost = -1;
+  for (int c = 1; c <= 8; ++c) {
+    if (c > 1 && T / c < 8) break;
+    const long long rounds = (tiles * c + 255) / 256;
+    const long long cost = rounds * ((T + c - 1) / c * 32 + 256) + (c > 1 ? 64 * c : 0);     // + the partial-sum pass
+    if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
+  }
+  return best;
 }
 
 extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream) {
@@ -493,8 +540,9 @@ extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t s
   const bool a = d->add != nullptr, m = d->mask != nullptr, r = d->res_hi != nullptr;
   if ((a && !m) || (r && (a || m))) return (int)hipErrorNotSupported;
   if (d->gate_bits && ((d->N & 31) || (d->ldp & 31) || (d->strideP & 31))) return (int)hipErrorInvalidValue;
-  WArgs g;
+  WArgs g = {};
   g.d = *d;
+  g.ksplit = 1;
   g.tiles_m = (d->M + BM - 1) / BM;
   g.tiles_n = (d->N + BN - 1) / BN;
   long long total = (long long)g.tiles_m * g.tiles_n * d->batch;

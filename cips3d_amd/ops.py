@@ -975,7 +975,7 @@ def split_planes_nhwc(x):
     return Planes(hi, lo)
 
 
-def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad):
+def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad, ksplit=None):
     """Implicit-GEMM convolution: wP Planes (O, kh*kw*C) with contraction index (tap, channel), xP NHWC Planes from
     split_planes_nhwc -> y (B, O, Ho, Wo) fp32."""
     lib = _lib.load()
@@ -985,6 +985,13 @@ def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad):
     d = ConvX3Desc()
     d.w_hi, d.w_lo, d.x_hi, d.x_lo, d.y = _p(wP.hi), _p(wP.lo), _p(xP.hi), _p(xP.lo), _p(y)
     d.B, d.C, d.H, d.W, d.O, d.kh, d.kw, d.stride, d.pad = B, C, H, W, O, kh, kw, stride, pad
+    ks = lib.cips_conv2d_x3_ksplit(B, O, Ho * Wo, kh * kw * C) if ksplit is None else ksplit
+    part = None
+    if ks > 1:                                   # few output tiles: split the contraction over the idle CUs
+        part = torch.empty(ks, B, O, Ho, Wo, device=xP.hi.device)
+        d.ksplit, d.part = ks, _p(part)
+    else:
+        d.ksplit, d.part = 1, None
     check(lib.cips_conv2d_x3(_ct.byref(d), _stream()), "cips_conv2d_x3")
     return y
 

@@ -305,8 +305,12 @@ typedef struct cips_conv_x3_desc {
   const void* x_hi; const void* x_lo;
   float* y;
   int B, C, H, W, O, kh, kw, stride, pad;
+  int ksplit;      /* <= 1: off.  > 1: the contraction (kh*kw*C) is cut into ksplit ranges computed by different workgroups */
+  float* part;     /* (small output planes leave most CUs idle otherwise); part: ksplit * B*O*Ho*Wo floats of scratch, */
+                   /* summed into y by the call.  cips_conv2d_x3_ksplit proposes a count for (B, O, N = Ho*Wo, K).   */
 } cips_conv_x3_desc;
 int cips_conv2d_x3(const cips_conv_x3_desc* d, cips_stream_t stream);
+int cips_conv2d_x3_ksplit(int B, int O, int N, int K);
 /* Weight gradient of the same convolution on the K-major kernel (contraction over all B*Ho*Wo output pixels, split in
  * `nchunks` ranges whose partial sums the caller adds):
  *   part[chunk][ky*kw+kx][o][c] = sum_{q in chunk} dy[q][o] * x[pixel(q)*stride - pad + (ky,kx)][c]

@@ -336,3 +336,24 @@ def test_conv_weight_gradient_ragged_chunks(cfg):
     dw = ops.conv2d_x3_wgrad(ops.split_planes_nhwc(dy.float().to(d)), ops.split_planes_nhwc(x.float().to(d)), B, C, H, H, O, k, k,
                              stride, pad, scale=0.5, nch=nch)
     assert dw is not None and rel_err(dw, 0.5 * w.grad) < 3e-5, (cfg, float(rel_err(dw, 0.5 * w.grad)))
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 96, 16, 3, 1, 1, 4), (3, 32, 32, 16, 3, 1, 1, 3), (2, 64, 64, 17, 3, 2, 0, 5),
+                                 (2, 96, 32, 16, 1, 1, 0, 3), (1, 32, 64, 24, 3, 1, 1, 7)])
+def test_implicit_conv_split_contraction(cfg):
+    """cips_conv2d_x3 with ksplit > 1 (the contraction cut into ragged k-tile ranges computed by different workgroups,
+    partial planes summed into y): same result as the unsplit launch to fp32 summation order, and as torch in fp64"""
+    from cips3d_amd import ops
+    B, C, O, H, k, stride, pad, ks = cfg
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17 + ks)
+    x = torch.randn(B, C, H, H, generator=g, dtype=torch.float64)
+    w = torch.randn(O, C, k, k, generator=g, dtype=torch.float64) / (C * k * k) ** 0.5
+    y = torch.nn.functional.conv2d(x, w, stride=stride, padding=pad)
+    wP, _ = ops.split_planes(w.float().to(d).permute(0, 2, 3, 1).reshape(1, O, k * k * C).contiguous(), want_p=True, want_t=False)
+    xP = ops.split_planes_nhwc(x.float().to(d))
+    y1 = ops.conv2d_x3(wP, xP, B, C, H, H, O, k, k, stride, pad, ksplit=1)
+    y2 = ops.conv2d_x3(wP, xP, B, C, H, H, O, k, k, stride, pad, ksplit=ks)
+    y3 = ops.conv2d_x3(wP, xP, B, C, H, H, O, k, k, stride, pad)                 # the launcher's own choice
+    assert rel_err(y1, y) < 3e-5 and rel_err(y2, y) < 3e-5 and rel_err(y3, y) < 3e-5
+    assert rel_err(y2, y1) < 2e-6
