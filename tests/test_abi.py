@@ -100,6 +100,27 @@ def test_entry_points_validate_arguments_before_touching_the_device():
     buf = (ctypes.c_float * 4)()
     w.part = ctypes.cast(buf, ctypes.c_void_p)
     assert lib.cips_conv2d_x3_wgrad(ctypes.byref(w), None) == UNSUPPORTED   # 450 pixels: no 32-row k-tiles
+    # round-2 entry points: host-side helpers and argument validation (no launches)
+    w.H = w.W = 16                                                          # 2 * 256 pixels = 16 k-tiles
+    w.nchunks = 17
+    assert lib.cips_conv2d_x3_wgrad(ctypes.byref(w), None) == UNSUPPORTED   # more chunks than k-tiles
+    c.stride, c.ksplit, c.part = 1, 3, None
+    assert lib.cips_conv2d_x3(ctypes.byref(c), None) == INVALID             # split contraction without its scratch
+    for (B, O, N, K) in [(32, 512, 256, 4608), (32, 256, 4096, 2304), (4, 64, 65536, 576), (1, 32, 256, 288), (32, 512, 1024, 512)]:
+        ks = lib.cips_conv2d_x3_ksplit(B, O, N, K)
+        tiles = -(-O // 256) * -(-N // 256) * B
+        assert 1 <= ks <= 8 and (ks == 1 or (K // 32) // ks >= 8)
+        assert ks == 1 or tiles < 256                                       # a full chip is never split
+    assert lib.cips_conv2d_x3_ksplit(32, 512, 256, 4608) == 4               # 64 tiles -> 256
+    assert lib.cips_conv1x1_smallk_bwd_weight(None, None, None, 2, 3, 8, 64, None) == INVALID
+    assert lib.cips_conv1x1_smallk_bwd_weight_splits(64, 65536) == 32 and lib.cips_conv1x1_smallk_bwd_weight_splits(512, 16) == 1
+    assert lib.cips_conv1x1_smallk_bwd_weight_splits(8, 30) == 0            # pixels not a multiple of 4
+    assert lib.cips_lrelu_bwd_bias(None, None, None, None, 4, 64, 0.2, 1.0, None) == INVALID
+    assert lib.cips_lrelu_bwd_bias_slices(64) == 1 and lib.cips_lrelu_bwd_bias_slices(65536) == 16 and lib.cips_lrelu_bwd_bias_slices(1 << 20) == 64
+    assert lib.cips_split_planes_nhwc(None, None, None, 2, 64, 16, None) == INVALID
+    assert lib.cips_split_planes_nhwc(buf, buf, buf, 2, 60, 16, None) == INVALID        # channels not a multiple of 8
+    assert lib.cips_conv_wgrad_finish(None, None, 1, 9, 8, 8, 1.0, None) == INVALID
+    assert lib.cips_col2im(None, None, 0, 3, 8, 8, 3, 3, 2, 0, None) == INVALID
     assert lib.cips_conv1x1_smallk(None, None, None, 2, 5, 8, 64, None) == INVALID      # more than 4 input channels
     assert lib.cips_conv1x1_smallk(None, None, None, 2, 3, 8, 30, None) == INVALID      # pixels not a multiple of 4
     assert lib.cips_upfirdn2d(None, None, None, 1, 8, 8, 1, 9, 9, 1, 1, 1, 1, 0, 0, 0, 0, None) == INVALID   # > 64 taps
