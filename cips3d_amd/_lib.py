@@ -79,7 +79,8 @@ class GemmX3Desc(C.Structure):
 class ConvX3Desc(C.Structure):
     _fields_ = [("w_hi", vp), ("w_lo", vp), ("x_hi", vp), ("x_lo", vp), ("y", vp),
                 ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("O", i32), ("kh", i32), ("kw", i32),
-                ("stride", i32), ("pad", i32), ("ksplit", i32), ("part", vp)]
+                ("stride", i32), ("pad", i32), ("ksplit", i32), ("part", vp), ("bias", vp), ("act", i32), ("slope", f32),
+                ("act_scale", f32)]
 
 
 class ConvWgradDesc(C.Structure):

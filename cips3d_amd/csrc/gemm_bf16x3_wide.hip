@@ -57,6 +57,9 @@ struct ConvGeom {
   int C, H, W, kw, stride, pad, Wo;
   long long img_stride;        // H*W*C elements
   long long zero_elem;         // element offset of the zero row from the start of the planes
+  const float* bias;           // optional per-output-channel bias (row of the GEMM), added before the activation
+  int act;                     // 1: y = leaky_relu(y + bias, slope) * act_scale   (FusedLeakyReLU, fused_act.py:47-86)
+  float slope, act_scale;
 };
 struct WArgs {
   cips_gemm_x3_desc d;
@@ -347,6 +350,20 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(w[e] << 16); x[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
     };
+    // conv bias of this lane's four output rows: requested here, first used after the first sub-tile's scratch round trip
+    // (loaded at the point of use, every sub-tile waited for an L2 round trip: +3.5 ms per GAN step)
+    float cbias[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if constexpr (CONV) {
+      if (g.cv.bias) {
+#pragma unroll
+        for (int si = 0; si < 2; ++si)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int row = m0 + wm * 64 + si * 32 + h_rr + 16 * c;
+            cbias[si][c] = g.cv.bias[row < M ? row : M - 1];
+          }
+      }
+    }
     static_for(std::make_integer_sequence<int, 8>{}, [&](auto ST) {
       constexpr int st = decltype(ST)::value, si = st >> 2, jj = st & 3;
       const int row0 = m0 + wm * 64 + si * 32, col0 = n0 + wn * 128 + jj * 32;
@@ -419,6 +436,17 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) y[e] += rh[e] + rl[e];
         }
+        if constexpr (CONV) {                                // EqualConv2d + FusedLeakyReLU in one pass (unsplit launches only)
+          if (g.cv.bias) {
+            const float bv = cbias[si][c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] += bv;
+          }
+          if (g.cv.act) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = lrelu(y[e], g.cv.slope) * g.cv.act_scale;
+          }
+        }
         if (d.C && ok) {
           float* q = d.C + cb + (long long)row * d.ldc + col;
           *reinterpret_cast<float4*>(q) = make_float4(y[0], y[1], y[2], y[3]);
@@ -469,12 +497,22 @@ static int wide_grid(int total) {
 }
 
 namespace {
-__global__ __launch_bounds__(256) void sum_chunks_kernel(const float4* __restrict__ part, float4* __restrict__ y, int nch, long long n4) {
+__global__ __launch_bounds__(256) void sum_chunks_kernel(const float4* __restrict__ part, float4* __restrict__ y, int nch, long long n4,
+                                                         const float* __restrict__ bias, int act, float slope, float act_scale,
+                                                         int row_len4, int rows) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += gridDim.x * 256LL) {
     float4 v = part[i];
     for (int c = 1; c < nch; ++c) {
       const float4 u = part[c * n4 + i];
       v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (bias) {                                              // element i: row (i / row_len4) % rows of its image
+      const float bv = bias[(int)((i / row_len4) % rows)];
+      v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+    }
+    if (act) {
+      v.x = lrelu(v.x, slope) * act_scale; v.y = lrelu(v.y, slope) * act_scale;
+      v.z = lrelu(v.z, slope) * act_scale; v.w = lrelu(v.w, slope) * act_scale;
     }
     y[i] = v;
   }
@@ -504,6 +542,10 @@ extern "C" int cips_conv2d_x3(const cips_conv_x3_desc* c, cips_stream_t stream) 
   if (ks > 1 && (!c->part || ks > (int)(K / 32))) return (int)hipErrorInvalidValue;
   if (ks > 1) d.C = c->part;                    // chunk c of image b -> part[c][b]; summed into y below
   g.ksplit = ks;
+  const bool act = c->act == 1;
+  if (c->act != 0 && c->act != 1) return (int)hipErrorInvalidValue;
+  g.cv.bias = ks > 1 ? nullptr : c->bias; g.cv.act = (ks > 1 || !act) ? 0 : 1;
+  g.cv.slope = c->slope; g.cv.act_scale = c->act_scale;
   const long long total = (long long)g.tiles_m * g.tiles_n * d.batch * ks;
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
@@ -513,7 +555,8 @@ extern "C" int cips_conv2d_x3(const cips_conv_x3_desc* c, cips_stream_t stream) 
     const long long n4 = (long long)c->B * c->O * N / 4;        // N % 8 == 0
     const long long blocks = (n4 + 255) / 256;
     hipLaunchKernelGGL(sum_chunks_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(c->part), reinterpret_cast<float4*>(c->y), ks, n4);
+                       reinterpret_cast<const float4*>(c->part), reinterpret_cast<float4*>(c->y), ks, n4, c->bias, act ? 1 : 0,
+                       c->slope, c->act_scale, (int)(N / 4), c->O);
   }
   return CIPS_CHECK_LAUNCH();
 }

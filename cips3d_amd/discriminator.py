@@ -500,6 +500,57 @@ class Conv2dFunction(Function):
         return dx, dw, None, None, None
 
 
+class ConvBiasActFunction(Function):
+    """out = leaky_relu(conv(x, w * scale) + bias, slope) * act_scale in ONE kernel (bias and activation in the epilogue
+    of the implicit-GEMM convolution): EqualConv2d followed by FusedLeakyReLU (discriminator.py:205-215).  The backward is
+    the composition of the two layers' own backward Functions, so every higher-order path (R1) is theirs."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, scale, slope, act_scale):
+        B, C, H, W = x.shape
+        O, _, kh, kw = w.shape
+        x = x.contiguous()
+        with _share_planes():
+            out = ops.conv2d_x3(_w_planes(w, scale), _nhwc(x), B, C, H, W, O, kh, kw, stride, pad, bias=bias.detach().contiguous(),
+                                act=True, slope=slope, act_scale=act_scale)
+            ctx.xP = _shared.get(_key(x)) if ctx.needs_input_grad[1] else None
+        ctx.save_for_backward(x, w, out)
+        ctx.cfg = (stride, pad, scale, slope, act_scale)
+        ctx.w_obj = w if isinstance(w, nn.Parameter) else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, out = ctx.saved_tensors
+        w = ctx.w_obj if ctx.w_obj is not None else w
+        stride, pad, scale, slope, act_scale = ctx.cfg
+        dpre, dbias = FusedLeakyReLUFunctionBackward.apply(dout.contiguous(), out, slope, act_scale)
+        dx = dw = None
+        with _share_planes((x, ctx.xP)):
+            if ctx.needs_input_grad[0]:
+                dx = Conv2dBwdDataFunction.apply(dpre, w, x.shape, stride, pad, scale)
+            if ctx.needs_input_grad[1]:
+                dw = Conv2dBwdWeightFunction.apply(dpre, x, w.shape, stride, pad, scale)
+        ctx.xP = None
+        return dx, dw, (dbias if ctx.needs_input_grad[2] else None), None, None, None, None, None
+
+
+_CONV_ACT_FUSED = _os.environ.get("CIPS_D_CONV_ACT_FUSED", "1") != "0"
+
+
+def _conv_act_fusable(x, conv, act):
+    """EqualConv2d (no bias of its own) + FusedLeakyReLU on a GPU batch whose conv takes the implicit-GEMM path"""
+    if not (_CONV_ACT_FUSED and x.is_cuda and x.dtype == torch.float32 and conv.bias is None and isinstance(act, FusedLeakyReLU)):
+        return False
+    if GATE_PIN is not None or GATE_REC is not None:        # gate instrumentation works on the separate activation op
+        return False
+    B, C, H, W = x.shape
+    O, _, kh, kw = conv.weight.shape
+    Ho, Wo = (H + 2 * conv.padding - kh) // conv.stride + 1, (W + 2 * conv.padding - kw) // conv.stride + 1
+    rgb = kh == 1 and kw == 1 and C <= 4
+    return (not rgb) and Ho > 0 and Wo > 0 and _implicit_ok(C, Ho * Wo, O)
+
+
 class Conv2dBwdDataFunction(Function):
     @staticmethod
     def forward(ctx, dy, w, in_shape, stride, pad, scale=1.0):
@@ -639,6 +690,13 @@ class ConvLayer(nn.Sequential):
                 if name not in ("down_blur", "equal_conv"):
                     x = m(x)
             return x
+        act = getattr(self, "flrelu", None)
+        if act is not None and input.is_cuda:
+            x = blur(input) if blur is not None else input
+            if _conv_act_fusable(x, conv, act):
+                return ConvBiasActFunction.apply(x, conv.weight, act.bias, conv.stride, conv.padding, conv.scale,
+                                                 act.negative_slope, act.scale)
+            return act(conv(x))
         return super().forward(input)
 
 

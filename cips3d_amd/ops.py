@@ -975,7 +975,7 @@ def split_planes_nhwc(x):
     return Planes(hi, lo)
 
 
-def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad, ksplit=None):
+def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad, ksplit=None, bias=None, act=False, slope=0.2, act_scale=1.0):
     """Implicit-GEMM convolution: wP Planes (O, kh*kw*C) with contraction index (tap, channel), xP NHWC Planes from
     split_planes_nhwc -> y (B, O, Ho, Wo) fp32."""
     lib = _lib.load()
@@ -992,6 +992,8 @@ def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad, ksplit=None):
         d.ksplit, d.part = ks, _p(part)
     else:
         d.ksplit, d.part = 1, None
+    d.bias = _p(bias) if bias is not None else None            # EqualConv2d + FusedLeakyReLU in the epilogue
+    d.act, d.slope, d.act_scale = (1 if act else 0), float(slope), float(act_scale)
     check(lib.cips_conv2d_x3(_ct.byref(d), _stream()), "cips_conv2d_x3")
     return y
 

@@ -308,6 +308,9 @@ typedef struct cips_conv_x3_desc {
   int ksplit;      /* <= 1: off.  > 1: the contraction (kh*kw*C) is cut into ksplit ranges computed by different workgroups */
   float* part;     /* (small output planes leave most CUs idle otherwise); part: ksplit * B*O*Ho*Wo floats of scratch, */
                    /* summed into y by the call.  cips_conv2d_x3_ksplit proposes a count for (B, O, N = Ho*Wo, K).   */
+  const float* bias;  /* optional (O): added to every pixel of channel o                                                  */
+  int act;            /* 0: none; 1: y = leaky_relu(y + bias, slope) * act_scale — EqualConv2d followed by FusedLeakyReLU */
+  float slope, act_scale;   /* (discriminator.py:205-215, fused_act.py:47-86) in the GEMM epilogue                       */
 } cips_conv_x3_desc;
 int cips_conv2d_x3(const cips_conv_x3_desc* d, cips_stream_t stream);
 int cips_conv2d_x3_ksplit(int B, int O, int N, int K);

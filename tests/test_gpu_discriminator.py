@@ -357,3 +357,32 @@ def test_implicit_conv_split_contraction(cfg):
     y3 = ops.conv2d_x3(wP, xP, B, C, H, H, O, k, k, stride, pad)                 # the launcher's own choice
     assert rel_err(y1, y) < 3e-5 and rel_err(y2, y) < 3e-5 and rel_err(y3, y) < 3e-5
     assert rel_err(y2, y1) < 2e-6
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 32, False), (2, 32, 96, 32, True), (3, 64, 32, 16, False), (2, 32, 64, 64, True),
+                                 (2, 32, 32, 8, False)])
+def test_conv_layer_with_activation_in_the_gemm_epilogue(cfg, monkeypatch):
+    """ConvLayer = [Blur,] EqualConv2d, FusedLeakyReLU (discriminator.py:134-222) with bias + LeakyReLU * sqrt(2) applied in
+    the implicit-GEMM epilogue (also through the split-contraction launch: 16 x 16 planes) against the three separate
+    kernels: output, input gradient, and the R1-style double backward into input, weight and bias"""
+    from cips3d_amd import discriminator as dm
+    B, C, O, H, down = cfg
+    d = torch.device("cuda:0")
+    torch.manual_seed(5)
+    layer = dm.ConvLayer(C, O, 3, downsample=down).to(d)
+    with torch.no_grad():
+        layer.flrelu.bias.copy_(torch.randn(O, device=d) * 0.3)
+    x0 = torch.randn(B, C, H, H, device=d)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(dm, "_CONV_ACT_FUSED", fused)
+        layer.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        y = layer(x)
+        up = torch.randn(y.shape, device=d, generator=torch.Generator(device=d).manual_seed(1))
+        gx, = torch.autograd.grad((y * up).sum(), x, create_graph=True)
+        ((gx ** 2).sum() + (y ** 2).sum()).backward()
+        res[fused] = (y.detach(), gx.detach(), x.grad.clone(), layer.equal_conv.weight.grad.clone(), layer.flrelu.bias.grad.clone())
+    for a, b, what in zip(res[True], res[False], ("y", "dx", "x.grad", "w.grad", "bias.grad")):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-5, (what, float(rel_err(a, b)))
+    assert H < 16 or float((res[True][0] - res[False][0]).abs().max()) <= 1e-6 * float(res[False][0].abs().max())
