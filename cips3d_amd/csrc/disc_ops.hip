@@ -2,6 +2,7 @@
 // ships as CUDA extensions, with identical contracts, plus the im2col / col2im pair that
 // feeds EqualConv2d to the fp32 MFMA GEMM.  All HBM-bandwidth bound streaming kernels.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/cips3d_hip.h"
 
 // A readable zero outside any tensor: out-of-range taps of the register-tiled upfirdn2d kernels are redirected here by
@@ -95,19 +96,22 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirArgs a) {
 // compute per plane: 125 us on the 8192 64 x 64 planes whose bytes need 45, 117 us on down-2 calls that need 30.  Same
 // taps in the same order (kernel rows outer, columns inner, one fma chain per output), so the results are bit-identical
 // to the generic kernel's.
-template <int DOWN>
+// Thread tile TW x TH outputs.  4 x 4 minimises loads per output (3.1) but neighbouring lanes then read addresses 16 B apart:
+// every wave load touches 1 KiB for 256 useful bytes and the texture path moves 12.5 x the output bytes.  1 x 16 (lanes
+// along x) needs 4.75 loads per output, each fully coalesced: 4.75 x.
+template <int DOWN, int TW, int TH>
 __global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(UpfirArgs a, int bw, int bh) {
-  constexpr int R = 4, NX = 3 * DOWN + 4, NR = (R - 1) * DOWN + 4;
+  constexpr int NX = (TW - 1) * DOWN + 4, NR = (TH - 1) * DOWN + 4;
   float ck[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) ck[i] = a.k[15 - i];                   // flipped 4 x 4 kernel (uniform: scalar loads)
   const long long per_plane = (long long)bh * bw, nblk = a.major * per_plane;
-  const bool vec = (a.out_w & 3) == 0;
+  const bool vec = TW == 4 && (a.out_w & 3) == 0;
   const float* zp = cips_zero_word;
   for (long long t = blockIdx.x * 256LL + threadIdx.x; t < nblk; t += gridDim.x * 256LL) {
     const long long mj = t / per_plane;
     const int rem = (int)(t - mj * per_plane), by = rem / bw, bx = rem - by * bw;
-    const int oy0 = by * R, ox0 = bx * 4;
+    const int oy0 = by * TH, ox0 = bx * TW;
     const int iyb = oy0 * DOWN - a.pad_y0, ixb = ox0 * DOWN - a.pad_x0;
     const float* src = a.in + mj * (long long)a.in_h * a.in_w;
     int colx[NX];
@@ -118,11 +122,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(UpfirArgs a, int 
       cok[i] = (unsigned)ix < (unsigned)a.in_w;
       colx[i] = min(max(ix, 0), a.in_w - 1);
     }
-    float v[R][4];
+    float v[TH][TW];
 #pragma unroll
-    for (int ry = 0; ry < R; ++ry)
+    for (int ry = 0; ry < TH; ++ry)
 #pragma unroll
-      for (int o = 0; o < 4; ++o) v[ry][o] = 0.f;
+      for (int o = 0; o < TW; ++o) v[ry][o] = 0.f;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int iy = iyb + r;
@@ -132,75 +136,70 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(UpfirArgs a, int 
 #pragma unroll
       for (int i = 0; i < NX; ++i) x[i] = *((rok && cok[i]) ? rowp + colx[i] : zp);
 #pragma unroll
-      for (int ry = 0; ry < R; ++ry) {
+      for (int ry = 0; ry < TH; ++ry) {
         const int ky = r - ry * DOWN;
         if (ky >= 0 && ky < 4) {
 #pragma unroll
           for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
-            for (int o = 0; o < 4; ++o) v[ry][o] = fmaf(x[o * DOWN + kx], ck[ky * 4 + kx], v[ry][o]);
+            for (int o = 0; o < TW; ++o) v[ry][o] = fmaf(x[o * DOWN + kx], ck[ky * 4 + kx], v[ry][o]);
         }
       }
     }
 #pragma unroll
-    for (int ry = 0; ry < R; ++ry) {
+    for (int ry = 0; ry < TH; ++ry) {
       const int oy = oy0 + ry;
       if (oy < a.out_h) {
         float* q = a.out + (mj * a.out_h + oy) * (long long)a.out_w + ox0;
-        if (vec) {
-          *reinterpret_cast<float4*>(q) = make_float4(v[ry][0], v[ry][1], v[ry][2], v[ry][3]);
-        } else {
-#pragma unroll
-          for (int o = 0; o < 4; ++o)
-            if (ox0 + o < a.out_w) q[o] = v[ry][o];
+        if constexpr (TW == 4) {
+          if (vec) {
+            *reinterpret_cast<float4*>(q) = make_float4(v[ry][0], v[ry][1], v[ry][2], v[ry][3]);
+            continue;
+          }
         }
+#pragma unroll
+        for (int o = 0; o < TW; ++o)
+          if (ox0 + o < a.out_w) q[o] = v[ry][o];
       }
     }
   }
 }
 
-// up 2, down 1, 4 x 4 kernel (the backward of the down-2 blur of the skip branch): each output has 2 x 2 taps.  A
-// thread produces four neighbouring outputs of one row; the quarter-size input stays in L1 / L2.  Same polyphase
-// arithmetic and tap order as the generic kernel.
-__global__ __launch_bounds__(256) void upfirdn2d_up2_kernel(UpfirArgs a, int bw) {
+// up 2, down 1, 4 x 4 kernel (the backward of the down-2 blur of the skip branch): each output has 2 x 2 taps; the
+// quarter-size input stays in L1 / L2.  Same polyphase arithmetic and tap order as the generic kernel.
+template <int TH>
+__global__ __launch_bounds__(256) void upfirdn2d_up2_kernel(UpfirArgs a, int bh) {
+  // thread = one output column x TH output rows, lanes along x (pairs of lanes share their input addresses: coalesced)
   __shared__ float sk[16];
   if (threadIdx.x < 16) sk[threadIdx.x] = a.k[15 - threadIdx.x];
   __syncthreads();
-  const long long per_plane = (long long)a.out_h * bw, nblk = a.major * per_plane;
-  const bool vec = (a.out_w & 3) == 0;
+  const long long per_plane = (long long)bh * a.out_w, nblk = a.major * per_plane;
   const float* zp = cips_zero_word;
   for (long long t = blockIdx.x * 256LL + threadIdx.x; t < nblk; t += gridDim.x * 256LL) {
     const long long mj = t / per_plane;
-    const int rem = (int)(t - mj * per_plane), oy = rem / bw, bx = rem - oy * bw, ox0 = bx * 4;
+    const int rem = (int)(t - mj * per_plane), by = rem / a.out_w, ox = rem - by * a.out_w;
     const float* src = a.in + mj * (long long)a.in_h * a.in_w;
-    const int mid_y = oy + 1 - a.pad_y0, in_y0 = floor_div(mid_y, 2), ky0 = (in_y0 + 1) * 2 - mid_y - 1;
-    float v[4];
+    const int mid_x = ox + 1 - a.pad_x0, in_x0 = floor_div(mid_x, 2), kx0 = (in_x0 + 1) * 2 - mid_x - 1;
+    const bool xok0 = (unsigned)in_x0 < (unsigned)a.in_w, xok1 = (unsigned)(in_x0 + 1) < (unsigned)a.in_w;
+    const int xc0 = min(max(in_x0, 0), a.in_w - 1), xc1 = min(max(in_x0 + 1, 0), a.in_w - 1);
+    float* dst = a.out + mj * (long long)a.out_h * a.out_w + ox;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int mid_x = ox0 + o + 1 - a.pad_x0, in_x0 = floor_div(mid_x, 2), kx0 = (in_x0 + 1) * 2 - mid_x - 1;
-      float acc = 0.f;
+    for (int j = 0; j < TH; ++j) {
+      const int oy = by * TH + j;
+      if (oy < a.out_h) {
+        const int mid_y = oy + 1 - a.pad_y0, in_y0 = floor_div(mid_y, 2), ky0 = (in_y0 + 1) * 2 - mid_y - 1;
+        float acc = 0.f;
 #pragma unroll
-      for (int yy = 0; yy < 2; ++yy) {
-        const int iy = in_y0 + yy, ky = ky0 + 2 * yy;
-        const bool rok = (unsigned)iy < (unsigned)a.in_h;
-        const float* rowp = src + (long long)min(max(iy, 0), a.in_h - 1) * a.in_w;
-#pragma unroll
-        for (int xx = 0; xx < 2; ++xx) {
-          const int ix = in_x0 + xx, kx = kx0 + 2 * xx;
-          const bool ok = rok && (unsigned)ix < (unsigned)a.in_w;
-          const float q = *(ok ? rowp + min(max(ix, 0), a.in_w - 1) : zp);
-          acc = fmaf(q, sk[ky * 4 + kx], acc);
+        for (int yy = 0; yy < 2; ++yy) {
+          const int iy = in_y0 + yy, ky = ky0 + 2 * yy;
+          const bool rok = (unsigned)iy < (unsigned)a.in_h;
+          const float* rowp = src + (long long)min(max(iy, 0), a.in_h - 1) * a.in_w;
+          const float q0 = *((rok && xok0) ? rowp + xc0 : zp), q1 = *((rok && xok1) ? rowp + xc1 : zp);
+          acc = fmaf(q0, sk[ky * 4 + kx0], acc);
+          acc = fmaf(q1, sk[ky * 4 + kx0 + 2], acc);
         }
+        dst[(long long)oy * a.out_w] = acc;
       }
-      v[o] = acc;
-    }
-    float* q = a.out + (mj * a.out_h + oy) * (long long)a.out_w + ox0;
-    if (vec) {
-      *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-        if (ox0 + o < a.out_w) q[o] = v[o];
     }
   }
 }
@@ -676,18 +675,24 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
   if (minor == 1 && kernel_h == 4 && kernel_w == 4 && up_x == up_y && down_x == down_y) {
     hipStream_t st = (hipStream_t)stream;
     if (up_x == 1 && (down_x == 1 || down_x == 2)) {
-      const int bw = (a.out_w + 3) / 4, bh = (a.out_h + 3) / 4;
+      static int tile = -1;                      // CIPS_BLUR_TILE: 0 = 4 x 4 outputs per thread, 1 = 1 x 16, 2 = 1 x 8
+      if (tile < 0) { const char* e = getenv("CIPS_BLUR_TILE"); tile = e ? atoi(e) : 1; }
+      const int eff = (tile == 1 && a.out_h < 48) ? 2 : tile;          // short planes: 1 x 8 wastes fewer rows of the last block
+      const int tw = eff == 0 ? 4 : 1, th = eff == 0 ? 4 : (eff == 2 ? 8 : 16);
+      const int bw = (a.out_w + tw - 1) / tw, bh = (a.out_h + th - 1) / th;
       const long long nthreads = (long long)major * bw * bh;
       const unsigned grid = (unsigned)((nthreads + 255) / 256 < 131072 ? (nthreads + 255) / 256 : 131072);
-      if (down_x == 1) hipLaunchKernelGGL(upfirdn2d_direct_kernel<1>, dim3(grid), dim3(256), 0, st, a, bw, bh);
-      else hipLaunchKernelGGL(upfirdn2d_direct_kernel<2>, dim3(grid), dim3(256), 0, st, a, bw, bh);
+#define CIPS_UF(D, TW_, TH_) hipLaunchKernelGGL((upfirdn2d_direct_kernel<D, TW_, TH_>), dim3(grid), dim3(256), 0, st, a, bw, bh)
+      if (down_x == 1) { if (eff == 0) CIPS_UF(1, 4, 4); else if (eff == 2) CIPS_UF(1, 1, 8); else CIPS_UF(1, 1, 16); }
+      else { if (eff == 0) CIPS_UF(2, 4, 4); else if (eff == 2) CIPS_UF(2, 1, 8); else CIPS_UF(2, 1, 16); }
+#undef CIPS_UF
       return CIPS_CHECK_LAUNCH();
     }
     if (up_x == 2 && down_x == 1) {
-      const int bw = (a.out_w + 3) / 4;
-      const long long nthreads = (long long)major * a.out_h * bw;
+      const int bh = (a.out_h + 3) / 4;
+      const long long nthreads = (long long)major * a.out_w * bh;
       const unsigned grid = (unsigned)((nthreads + 255) / 256 < 131072 ? (nthreads + 255) / 256 : 131072);
-      hipLaunchKernelGGL(upfirdn2d_up2_kernel, dim3(grid), dim3(256), 0, st, a, bw);
+      hipLaunchKernelGGL(upfirdn2d_up2_kernel<4>, dim3(grid), dim3(256), 0, st, a, bh);
       return CIPS_CHECK_LAUNCH();
     }
   }
