@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
     ap.add_argument("--inr-mode", default=None, choices=["bf16x3", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph of the step")
+    ap.add_argument("--overlap-reduce", action="store_true",
+                    help="N > 1: issue each gradient bucket's all-reduce from autograd hooks while backward is still running "
+                         "(implies --no-graph; validated over gloo only: not the default)")
     return ap.parse_args()
 
 
@@ -232,7 +235,10 @@ def main():
     b, img = a.batch, a.img_size
     G0 = torch.randn(b, 3, img, img, device=dev) / (b * 3 * img * img)
     params = list(G.parameters())
-    reduce_grads = GradAllReducer(params)
+    overlap = bool(a.overlap_reduce and world > 1)
+    if overlap:
+        a.no_graph = True                      # hooks run in eager autograd only
+    reduce_grads = GradAllReducer(params, bucket_mb=8.0 if overlap else 64.0, overlap=overlap)
 
     def fwd_bwd():
         zs = G.get_zs(b)
@@ -322,7 +328,9 @@ def main():
                                f"batch {b}/GPU, G fwd+bwd, all 9 CIPS blocks" + (", NeRF frozen" if a.freeze else ""),
                    "global_batch": world * b, "parallelism": f"dp{world}", "rccl_ranks": world if backend == "nccl" else 0,
                    "inr_gemm_mode": mode,
-                   "launch": "hipGraph replay" if use_graph[0] else "eager"},
+                   "launch": "hipGraph replay" if use_graph[0] else "eager",
+                   "grad_reduce": ("bucketed all-reduce issued from autograd hooks during backward" if overlap else
+                                   "flat-bucket all-reduce after backward") if world > 1 else "none"},
         **({"backend_note": f"{backend} functional check, not a measurement"} if backend != "nccl" and world > 1 else {}),
     }
     if exact:

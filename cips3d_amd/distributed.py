@@ -12,8 +12,12 @@ does per step) and reused while this rank's own presence pattern stays the same,
 step issues, per bucket, one concatenation, one all-reduce and one multi-tensor copy-back — no
 host synchronisation and no per-parameter launches (the G step is ~21 ms on an MI355X; 170
 per-tensor copies plus a `.tolist()` would cost > 5 % of it)."""
+import contextlib
+
 import torch
 import torch.distributed as dist
+
+_null = contextlib.nullcontext
 
 
 class GradAllReducer:
@@ -32,12 +36,34 @@ class GradAllReducer:
     Parameters are NOT filtered by `requires_grad` (train.py:335-336, 441-442 toggle it on G and D
     every step): what takes part is decided per call by which gradients exist."""
 
-    def __init__(self, params, bucket_mb=64.0, group=None):
+    def __init__(self, params, bucket_mb=64.0, group=None, overlap=False):
+        """overlap=True: once a plan exists, a bucket's all-reduce is issued from a post-accumulate-grad hook as soon as
+        the last of its locally expected gradients has arrived (buckets are formed in REVERSE parameter order — roughly
+        the order in which backward produces gradients — and issued strictly in bucket order, like DDP's reducer, so
+        every rank issues the same sequence of collectives); on a GPU the concatenation, the collective and the copy-back
+        run on a side stream that the caller's stream joins in __call__.  __call__ then issues whatever has not been
+        issued, waits, and handles a changed presence pattern.  One backward per __call__ (no gradient accumulation
+        across several backward passes), eager autograd only (hooks do not run inside a replayed hipGraph)."""
         self.params = list(params)
         if not self.params:
             raise ValueError("GradAllReducer: empty parameter list")
         self.group = group
         self.limit = int(bucket_mb * 1024 * 1024)
+        self.overlap = bool(overlap)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._bucket_of = {}     # id(param) -> bucket index of the cached plan
+        self._expected = []      # per bucket: how many of its parameters THIS rank produces a gradient for
+        self._arrived = []       # per bucket: how many of those have arrived in the current backward
+        self._next = 0           # next bucket to issue (buckets are issued in order)
+        self._inflight = []      # (flat, work, grads, sig_view) of issued buckets
+        self._dirty = False      # a gradient arrived that the plan does not expect: the pattern changed
+        self._side = None        # side stream (GPU)
+        self._seen = set()       # indices of the parameters whose gradient arrived in the current backward (hooks)
+        self._early = 0          # buckets issued from hooks during the current backward
+        self.last_launched_early = 0   # ... during the backward that the last __call__ closed (statistics / tests)
+        if self.overlap:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
         self._local = None       # this rank's presence pattern the cached plan was built for
         self._union = None       # the agreed pattern (union over ranks): what `.grad is not None` looks like after a call
         self._buckets = None     # list of lists of parameters (the union over ranks, bucketed)
@@ -50,6 +76,8 @@ class GradAllReducer:
         dist.all_reduce(present, op=dist.ReduceOp.MAX, group=self.group)
         flags = [f > 0 for f in present.tolist()]
         used = [p for p, f in zip(self.params, flags) if f]
+        if self.overlap:
+            used = used[::-1]                    # backward produces the last layers' gradients first
         buckets, cur, size = [], [], 0
         for p in used:
             cur.append(p)
@@ -60,8 +88,87 @@ class GradAllReducer:
         if cur:
             buckets.append(cur)
         self._local, self._union, self._buckets = local, tuple(flags), buckets
+        self._bucket_of = {id(p): b for b, bucket in enumerate(buckets) for p in bucket}
+        self._expected = [sum(1 for p in bucket if local[self._index[id(p)]]) for bucket in buckets]
+        self._reset_step()
         # plan checksum: exactly representable in fp32 so that the mean over identical ranks is exact
         self._sig = float(sum((i + 1) * 7 for i, f in enumerate(flags) if f) % 65521)
+
+    def _reset_step(self):
+        self._arrived = [0] * len(self._buckets or [])
+        self._next = 0
+        self._inflight = []
+        self._dirty = False
+        self._seen = set()
+        self._early = 0
+
+    def _on_grad(self, p):
+        """post-accumulate-grad hook (overlap mode): count the gradient in; issue every bucket that is complete"""
+        i = self._index[id(p)]
+        if i in self._seen:                  # a second backward before __call__: not supported in overlap mode
+            self._dirty = True
+        self._seen.add(i)
+        if self._buckets is None or self._dirty or not dist.is_initialized():
+            return
+        b = self._bucket_of.get(id(p))
+        if b is None or not self._local[i]:
+            self._dirty = True               # a gradient the plan does not expect from this rank: handled in __call__
+            return
+        self._arrived[b] += 1
+        before = self._next
+        self._issue_ready()
+        self._early += self._next - before
+
+    def _issue_ready(self, force=False):
+        nb = len(self._buckets)
+        while self._next < nb and (force or self._arrived[self._next] >= self._expected[self._next]):
+            self._issue(self._next)
+            self._next += 1
+
+    def _issue(self, b):
+        bucket = self._buckets[b]
+        for p in bucket:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        grads = [p.grad for p in bucket]
+        dev = grads[0].device
+        if dev.type == "cuda":
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)        # the gradients of this bucket are complete on the producing stream
+                sig = torch.full((1,), self._sig, device=dev, dtype=grads[0].dtype)
+                flat = torch.cat([g.reshape(-1) for g in grads] + [sig])
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            sig = torch.full((1,), self._sig, device=dev, dtype=grads[0].dtype)
+            flat = torch.cat([g.reshape(-1) for g in grads] + [sig])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight.append((flat, work, grads))
+
+    def _drain(self, world):
+        """wait for the issued buckets, divide, copy back; returns (bytes, checksum views)"""
+        nbytes, sigs = 0, []
+        dev = self.params[0].device
+        ctx = torch.cuda.stream(self._side) if (dev.type == "cuda" and self._side is not None) else _null()
+        with ctx:
+            for flat, work, grads in self._inflight:
+                work.wait()
+                flat.div_(world)
+                views, off = [], 0
+                for g in grads:
+                    n = g.numel()
+                    views.append(flat[off:off + n].view_as(g))
+                    off += n
+                torch._foreach_copy_(grads, views)
+                sigs.append(flat[off:off + 1])
+                nbytes += (flat.numel() - 1) * flat.element_size()
+        if dev.type == "cuda" and self._side is not None:
+            torch.cuda.current_stream(dev).wait_stream(self._side)
+        self._inflight = []
+        return nbytes, sigs
 
     def _check_pending(self, block=False):
         if self._pending is None:
@@ -83,6 +190,8 @@ class GradAllReducer:
         if world == 1:
             return 0
         self._check_pending()
+        if self.overlap and self._buckets is not None:
+            return self._finish_overlapped(world)
         local = tuple(p.grad is not None for p in self.params)
         # a change of the local pattern (another loss, a frozen sub-net) re-plans; see the contract above.  A caller
         # that did not reset the gradients to None (zero_grad(set_to_none=False), gradient accumulation) shows the
@@ -109,16 +218,57 @@ class GradAllReducer:
                 off += n
             torch._foreach_copy_(grads, views)
             sigs.append(flat[off:off + 1])
-        if sigs:
-            got = torch.cat(sigs).float()
-            if got.is_cuda:
-                host = torch.empty(got.shape, dtype=torch.float32).pin_memory()
-                host.copy_(got, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                self._pending = (ev, host, self._sig)
-            else:
-                self._pending = (None, got, self._sig)
+        self._record_sigs(sigs, self._sig)
+        if self.overlap:
+            self._reset_step()
+        return nbytes
+
+    def _record_sigs(self, sigs, want):
+        if not sigs:
+            return
+        got = torch.cat(sigs).float()
+        if got.is_cuda:
+            host = torch.empty(got.shape, dtype=torch.float32).pin_memory()
+            host.copy_(got, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (ev, host, want)
+        else:
+            self._pending = (None, got.clone(), want)
+
+    def _finish_overlapped(self, world):
+        """overlap mode, plan present: issue what the hooks did not, wait, copy back; then deal with a changed pattern"""
+        old_union, old_sig = self._union, self._sig
+        # the presence pattern of THIS backward = the gradients whose hooks fired (buckets issued early have already filled
+        # the gradients this rank does not produce with zeros, so `.grad is not None` no longer tells)
+        local = tuple(i in self._seen for i in range(len(self.params)))
+        self.last_launched_early = self._early
+        self._issue_ready(force=True)             # same bucket order on every rank, whatever arrived
+        nbytes, sigs = self._drain(world)
+        self._record_sigs(sigs, old_sig)
+        changed = local != self._local
+        if changed:
+            # (contract: every rank sees a change in the same step)  Parameters of the old plan are reduced; agree on the
+            # new union and reduce the parameters that were not part of the old one
+            self._check_pending(block=True)
+            self._plan(local)
+            extra = [p for p, was, now in zip(self.params, old_union, self._union) if now and not was]
+            if extra:
+                for p in extra:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                grads = [p.grad for p in extra]
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                flat.div_(world)
+                views, off = [], 0
+                for g in grads:
+                    n = g.numel()
+                    views.append(flat[off:off + n].view_as(g))
+                    off += n
+                torch._foreach_copy_(grads, views)
+                nbytes += flat.numel() * flat.element_size()
+        self._reset_step()
         return nbytes
 
 

@@ -125,3 +125,105 @@ def test_allreduce_grads_world2_gloo():
                 assert st[2] is None and st[3] is None
             else:
                 assert torch.allclose(st[2], torch.full((3,), 3.0)) and torch.allclose(st[3], torch.full((4,), 4.0))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# overlap mode: buckets issued from post-accumulate-grad hooks during backward
+# ------------------------------------------------------------------------------------------------------------------
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(16, 64)
+        self.b = torch.nn.Linear(64, 64)
+        self.c = torch.nn.Linear(64, 8)
+        self.side = torch.nn.Linear(16, 8)       # used on some steps / ranks only
+        self.never = torch.nn.Linear(4, 4)       # weight: never used; bias: used on rank 0 only
+
+    def forward(self, x, use_side):
+        y = self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
+        return y + self.side(x) if use_side else y
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cips3d_amd.distributed import GradAllReducer
+    out = {}
+    for mode in ("classic", "overlap"):
+        torch.manual_seed(0)
+        net = _Net()
+        params = list(net.parameters())
+        red = GradAllReducer(params, bucket_mb=0.002, overlap=(mode == "overlap"))   # ~0.5k floats per bucket: several buckets
+        steps = []
+        for step in range(5):
+            for p in params:
+                p.grad = None
+            x = torch.randn(32, 16, generator=torch.Generator().manual_seed(1000 + 10 * step + rank))
+            # steps 0-1: side unused everywhere; steps 2-4: side used on EVERY rank from the same step on (the contract) ...
+            use_side = step >= 2
+            loss = net(x, use_side).square().mean()
+            if rank == 0:                            # a parameter only rank 0 produces a gradient for (union != local on rank 1)
+                loss = loss + net.never.bias.sum()
+            loss.backward()
+            red()
+            red._check_pending(block=True)
+            steps.append(([None if p.grad is None else p.grad.clone().numpy() for p in params], red.last_launched_early,
+                          len(red._buckets)))
+        out[mode] = steps
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_overlap(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r, out = q.get(timeout=180)
+            res[r] = out
+        for p in procs:
+            p.join(timeout=60)
+            if p.exitcode != 0:
+                return None
+    except Exception:
+        res = None
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    return res
+
+
+def test_overlapped_bucket_allreduce_equals_classic_world2_gloo():
+    """overlap=True must give the gradients of the classic reduce on every step — including the first (planning) step,
+    the step at which the presence pattern changes on all ranks, and parameters that never get a gradient — and must
+    actually issue buckets from the hooks (before __call__) once a plan exists"""
+    world = 2
+    res = None
+    for _attempt in range(3):
+        res = _run_overlap(world)
+        if res is not None and len(res) == world:
+            break
+    assert res is not None and len(res) == world
+    for r in range(world):
+        classic, over = res[r]["classic"], res[r]["overlap"]
+        for step, ((gc, _, _), (go, early, nb)) in enumerate(zip(classic, over)):
+            for a, b in zip(gc, go):
+                assert (a is None) == (b is None), (r, step)
+                if a is not None:
+                    assert torch.allclose(torch.from_numpy(a), torch.from_numpy(b), atol=1e-7), (r, step)
+            if step in (1, 4):                       # steady state: a plan exists and the pattern did not change
+                assert nb >= 3 and early >= nb - 1, (r, step, early, nb)     # at most the last bucket waits for __call__
+    # both ranks hold identical (averaged) gradients
+    for step in range(5):
+        for a, b in zip(res[0]["overlap"][step][0], res[1]["overlap"][step][0]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(torch.from_numpy(a), torch.from_numpy(b))
