@@ -146,3 +146,74 @@ def _free_port_shared():
     if not _PORT:
         _PORT.append(_free_port())
     return _PORT[0]
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from cips3d_amd.distributed import GradAllReducer
+    out = {}
+    for mode in ("classic", "overlap"):
+        G, _ = _build(dev)
+        params = list(G.parameters())
+        red = GradAllReducer(params, bucket_mb=2.0, overlap=(mode == "overlap"))
+        steps = []
+        for step in range(3):
+            torch.manual_seed(500 + 10 * step + rank)
+            for p in params:
+                p.grad = None
+            imgs, _ = G(G.get_zs(B), img_size=IMG, nerf_noise=0.0, return_aux_img=(step == 2), forward_points=None,
+                        grad_points=None, **G_KW)               # step 2: the aux branch adds parameters on every rank
+            imgs.square().mean().backward()
+            red()
+            torch.cuda.synchronize()
+            red._check_pending(block=True)
+            steps.append(([None if p.grad is None else p.grad.detach().cpu().numpy() for p in params],
+                          red.last_launched_early, len(red._buckets)))
+        out[mode] = steps
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_buckets_on_gpu_equal_classic():
+    """GradAllReducer(overlap=True) on GPU tensors (two ranks share cuda:0, gloo): buckets issued from autograd hooks on a
+    side stream while the generator's backward is still running must leave the same averaged gradients as the classic
+    after-backward reduce, on the planning step, in steady state and when the presence pattern changes"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r, out = q.get(timeout=180)
+            res[r] = out
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    import numpy as np
+    for r in range(world):
+        for step in range(3):
+            gc, _, _ = res[r]["classic"][step]
+            go, early, nb = res[r]["overlap"][step]
+            for a, b in zip(gc, go):
+                assert (a is None) == (b is None), (r, step)
+                if a is not None:
+                    assert np.array_equal(a, b), (r, step, float(abs(a - b).max()))
+            if step == 1:
+                assert nb >= 3 and early >= nb - 1, (early, nb)
+        for a, b in zip(res[0]["overlap"][step][0], res[1]["overlap"][step][0]):
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
