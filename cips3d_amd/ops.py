@@ -948,7 +948,9 @@ def conv1x1_smallk_bwd_data(dy, w, C):
 
 
 def conv1x1_smallk_bwd_weight(dy, x):
-    """dy (B, O, H, W), x (B, C<=4, H, W) -> dw (O, C) = sum over images and pixels of dy x^T"""
+    """dy (B, O, H, W), x (B, C<=4, H, W) -> dw (O, C) = sum over images and pixels of dy x^T: the weight gradient of the
+    RGB input convs (autograd of F.conv2d in EqualConv2d.forward, exp/cips3d/models/discriminator.py:40-48, for the 1x1
+    layers of :457-459)"""
     lib = _lib.load()
     B, O, H, W = dy.shape
     C = x.shape[1]
@@ -1347,8 +1349,9 @@ def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
 
 
 def lrelu_bwd_bias(grad, refer, alpha, scale):
-    """grad, refer (B, C, H, W) fp32 contiguous -> (grad_input, grad_bias (C)): FusedLeakyReLU's backward with the bias
-    gradient accumulated in the same pass"""
+    """grad, refer (B, C, H, W) fp32 contiguous -> (grad_input, grad_bias (C)): FusedLeakyReLUFunctionBackward.forward
+    (exp/comm/op/fused_act.py:26-44: fused_bias_act(grad, empty, out, 3, 1, slope, scale) then grad_input.sum(0, 2, 3)) with
+    the bias gradient accumulated in the same pass"""
     lib = _lib.load()
     B, C = grad.shape[0], grad.shape[1]
     hw = grad.numel() // (B * C)
