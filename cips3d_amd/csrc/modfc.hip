@@ -7,6 +7,7 @@
 // LeakyReLU / skip epilogue fused.  ToRGB (generator.py:983-1006) is a 512 -> 3 projection:
 // pure HBM streaming, one wave per pixel row.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/cips3d_hip.h"
 
 namespace {
@@ -540,6 +541,63 @@ __global__ __launch_bounds__(256) void modfc_planes_batch_kernel(PrepJobs J, int
   }
 }
 
+// The same planes in 64 x 64 tiles: float4 reads of W along n, 8-byte plane stores along n straight from registers,
+// 16-byte stores of the transposed planes along k through LDS (the 32 x 32 form above writes 64-byte segments of 2-byte
+// elements: 3.4 TB/s on the 1.2 GB of per-sample weight planes of a C2 step).  Needs out_dim % 4 == 0, in_dim % 8 == 0.
+__global__ __launch_bounds__(256) void modfc_planes_batch64_kernel(PrepJobs J, int B) {
+  __shared__ __attribute__((aligned(16))) unsigned short th[64][72], tl[64][72];      // [n local][k local]
+  const int job = blockIdx.z / B, b = blockIdx.z % B;
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  if (n0 >= out_dim || k0 >= in_dim) return;
+  const float* __restrict__ W = J.W[job];
+  const float* __restrict__ s = J.s[job];
+  const float* __restrict__ demod = J.demod[job];
+  unsigned short *wbh = J.wbh[job], *wbl = J.wbl[job], *wth = J.wth[job], *wtl = J.wtl[job];
+  const int t = threadIdx.x;
+  const long long base = (long long)b * in_dim * out_dim;
+  {
+    const int col4 = t & 15, r_ = t >> 4;
+    const int n = n0 + 4 * col4;
+    const bool nok = n < out_dim;
+    float4 dm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nok) dm = *reinterpret_cast<const float4*>(demod + (long long)b * out_dim + n);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int kl = r_ + 16 * p, k = k0 + kl;
+      unsigned short h[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
+      if (nok && k < in_dim) {
+        const float4 w = *reinterpret_cast<const float4*>(W + (long long)k * out_dim + n);
+        const float sc = s[(long long)b * in_dim + k] + 1.f;
+        const float v[4] = {w.x * sc * dm.x, w.y * sc * dm.y, w.z * sc * dm.z, w.w * sc * dm.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          h[j] = f2bf_rne(v[j]);
+          l[j] = f2bf_rne(v[j] - __uint_as_float(((unsigned)h[j]) << 16));
+        }
+        const long long o = base + (long long)k * out_dim + n;
+        *reinterpret_cast<uint2*>(wbh + o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        *reinterpret_cast<uint2*>(wbl + o) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { th[4 * col4 + j][kl] = h[j]; tl[4 * col4 + j][kl] = l[j]; }
+    }
+  }
+  __syncthreads();
+  {
+    const int c8 = t & 7, r_ = t >> 3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int nl = r_ + 32 * p, n = n0 + nl, k = k0 + 8 * c8;
+      if (n < out_dim && k < in_dim) {
+        const long long o = base + (long long)n * in_dim + k;
+        *reinterpret_cast<uint4*>(wth + o) = *reinterpret_cast<const uint4*>(&th[nl][8 * c8]);
+        *reinterpret_cast<uint4*>(wtl + o) = *reinterpret_cast<const uint4*>(&tl[nl][8 * c8]);
+      }
+    }
+  }
+}
+
 struct BwdJobs {
   const float* W[MAXJOBS]; const float* s[MAXJOBS]; const float* demod[MAXJOBS]; const float* G[MAXJOBS];
   float *cbuf[MAXJOBS], *dW[MAXJOBS], *ds[MAXJOBS];
@@ -736,7 +794,14 @@ extern "C" int cips_modfc_prep_x3_batch(const cips_modfc_prep_job* jobs, int njo
   }
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(modfc_demod_batch_kernel, dim3((max_out + 31) / 32, B, njobs), dim3(256), 0, st, J, B, eps);
-  hipLaunchKernelGGL(modfc_planes_batch_kernel, dim3((max_out + 31) / 32, (max_in + 31) / 32, B * njobs), dim3(256), 0, st, J, B);
+  bool wide = true;                              // 64 x 64 tiles with vector accesses when every job's shape allows
+  for (int i = 0; i < njobs; ++i) wide = wide && (jobs[i].out_dim % 4 == 0) && (jobs[i].in_dim % 8 == 0);
+  static int planes64 = -1;
+  if (planes64 < 0) { const char* e = getenv("CIPS_MODFC_PLANES64"); planes64 = (e && atoi(e) == 0) ? 0 : 1; }
+  if (wide && planes64)
+    hipLaunchKernelGGL(modfc_planes_batch64_kernel, dim3((max_out + 63) / 64, (max_in + 63) / 64, B * njobs), dim3(256), 0, st, J, B);
+  else
+    hipLaunchKernelGGL(modfc_planes_batch_kernel, dim3((max_out + 31) / 32, (max_in + 31) / 32, B * njobs), dim3(256), 0, st, J, B);
   return CIPS_CHECK_LAUNCH();
 }
 
