@@ -20,6 +20,17 @@ def _unwrap(obj):
     return obj.module if isinstance(obj, torch.nn.parallel.DistributedDataParallel) else obj
 
 
+def _to_cpu(obj):
+    """tensors anywhere inside nested dicts / lists / tuples (an optimiser's state -> idx -> exp_avg ...) -> CPU copies"""
+    if torch.is_tensor(obj):
+        return obj.detach().cpu()
+    if isinstance(obj, dict):
+        return type(obj)((k, _to_cpu(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_cpu(v) for v in obj)
+    return obj
+
+
 def save_models(save_dir, model_dict, info_msg=None):
     """<save_dir>/<name>.pth for every entry: modules / optimisers / EMA helpers -> their state_dict(), plain dicts
     (the 'state_dict' entry: step, FID bookkeeping) as they are.  Tensors are moved to the CPU first."""
@@ -27,9 +38,7 @@ def save_models(save_dir, model_dict, info_msg=None):
     for name, obj in model_dict.items():
         obj = _unwrap(obj)
         sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
-        if isinstance(sd, dict):
-            sd = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in sd.items()}
-        torch.save(sd, os.path.join(save_dir, f"{name}.pth"))
+        torch.save(_to_cpu(sd), os.path.join(save_dir, f"{name}.pth"))
     if info_msg is not None:
         with open(os.path.join(save_dir, "0info.txt"), "w") as f:
             f.write(f"{info_msg}\n")
@@ -48,6 +57,8 @@ def load_models(save_dir, model_dict, strict=True, rank=0, verbose=False):
         loaded = torch.load(path, map_location="cpu", weights_only=False)
         if isinstance(obj, torch.nn.Module):
             res = obj.load_state_dict(loaded, strict=strict)
+            from .discriminator import invalidate_weight_cache
+            invalidate_weight_cache(obj)
             if verbose and rank == 0:
                 print(f"{name}: {res}")
         elif hasattr(obj, "load_state_dict"):
@@ -67,7 +78,16 @@ class Checkpointer:
 
     def load_state_dict_from_file(self, path, rank=0, strict=True):
         sd = torch.load(path, map_location="cpu", weights_only=False)
-        return self.model.load_state_dict(sd, strict=strict)
+        # a file written as {'model': state_dict} / {'state_dict': state_dict} (common wrappers) loads too
+        if isinstance(sd, dict) and sd and not any(torch.is_tensor(v) for v in sd.values()):
+            for key in ("model", "state_dict", "G_ema", "generator"):
+                if isinstance(sd.get(key), dict):
+                    sd = sd[key]
+                    break
+        res = self.model.load_state_dict(sd, strict=strict)
+        from .discriminator import invalidate_weight_cache
+        invalidate_weight_cache(self.model)
+        return res
 
     def save_state_dict_to_file(self, path):
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)

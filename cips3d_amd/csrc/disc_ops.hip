@@ -514,7 +514,12 @@ __global__ __launch_bounds__(256) void diffaug_fwd_kernel(DiffAugArgs a) {
     const int b = (int)(t / HW), p = (int)(t - (long long)b * HW), i = p / a.W, j = p - i * a.W;
     const int si = i + (int)a.tx[b], sj = j + (int)a.ty[b];
     const bool zero = da_masked(a, b, i, j) || si < 0 || si >= a.H || sj < 0 || sj >= a.W;
-    const float off = a.affine ? a.rb[b] - 0.5f : 0.f;
+    if (a.affine & 2) {                          // policy without the colour stage: shift and hole only, values untouched
+      for (int c = 0; c < a.C; ++c)
+        a.y[((long long)b * a.C + c) * HW + p] = zero ? 0.f : a.x[((long long)b * a.C + c) * HW + si * a.W + sj];
+      continue;
+    }
+    const float off = (a.affine & 1) ? a.rb[b] - 0.5f : 0.f;
     const float s2 = a.rs[b] * 2.f, k = a.rc[b] + 0.5f;
     const float m2 = a.sums[b] / (float)(a.C * HW) + off;
     float x1[4], m1 = 0.f;
@@ -539,6 +544,11 @@ __global__ __launch_bounds__(256) void diffaug_adj_kernel(DiffAugArgs a) {
     const int b = (int)(t / HW), p = (int)(t - (long long)b * HW), si = p / a.W, sj = p - si * a.W;
     const int i = si - (int)a.tx[b], j = sj - (int)a.ty[b];          // where this source pixel went
     const bool none = i < 0 || i >= a.H || j < 0 || j >= a.W || da_masked(a, b, i, j);
+    if (a.affine & 2) {
+      for (int c = 0; c < a.C; ++c)
+        a.y[((long long)b * a.C + c) * HW + p] = none ? 0.f : a.x[((long long)b * a.C + c) * HW + i * a.W + j];
+      continue;
+    }
     const float s2 = a.rs[b] * 2.f, k = a.rc[b] + 0.5f;
     const float spread = (1.f - k) * a.sums[b] / (float)(a.C * HW);
     float g2[4], mg = 0.f;

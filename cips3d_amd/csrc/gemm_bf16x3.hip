@@ -760,7 +760,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float* __r
 }  // namespace
 
 extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream);   // gemm_bf16x3_wide.hip
-static int g_wide = -1;   // -1: from env CIPS_X3_WIDE (default 1); 0 never; 1 for large problems; 2 whenever supported
+extern "C" int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t stream);     // gemm_bf16x3_v3.hip
+static int g_wide = -1;   // -1: from env CIPS_X3_WIDE (default 1); 0 never; 1 for large problems; 2 whenever supported;
+                          // 3: like 2 but never the v3 kernel (tests of the wide kernel proper)
+static int g_v3 = -1;     // env CIPS_X3_V3 (default 1): 256x256 tiles of interior shapes on gemm_bf16x3_v3.hip
 extern "C" void cips_gemm_bf16x3_set_wide(int mode) { g_wide = mode; }
 
 extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream) {
@@ -772,7 +775,12 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   // CIPS_X3_WIDE=0 keeps everything on the 256x128 kernel below
   if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }
   const bool big = d->N >= 256 && d->M >= 256 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 256;
-  if (g_wide == 2 || (g_wide == 1 && big)) {
+  if (g_v3 < 0) { const char* e = getenv("CIPS_X3_V3"); g_v3 = e ? atoi(e) : 1; }
+  if (g_wide >= 2 || (g_wide == 1 && big)) {
+    if (g_v3 && g_wide != 3) {
+      const int rc3 = cips_gemm_bf16x3_v3(d, stream);
+      if (rc3 != (int)hipErrorNotSupported) return rc3;
+    }
     const int rc = cips_gemm_bf16x3_wide(d, stream);
     if (rc != (int)hipErrorNotSupported) return rc;
   }
@@ -831,7 +839,7 @@ extern "C" int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t str
   // square-ish outputs filling the chip with 256x256 tiles: the wide kernel (a single problem is a group of one)
   if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }
   if (g_wide >= 1 && d->M >= 256 && d->N >= 256 &&
-      ((long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 192 || g_wide == 2)) {
+      ((long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 192 || g_wide >= 2)) {
     const int rc = cips_gemm_bf16x3_km_grouped(d, 1, stream);
     if (rc != (int)hipErrorNotSupported) return rc;
   }

@@ -309,14 +309,33 @@ def _nhwc(t):
 # counter (bumped by every in-place update: torch.optim, load_state_dict, and cips3d_amd.optim.FusedClipAdamEMA, which
 # writes through raw pointers and therefore bumps it explicitly).  Transient weights (the double-backward's `ggw`) are
 # never cached.  CIPS_D_WCACHE=0 disables the cache.
+# A write that bypasses the version counter (`p.data.copy_()`, `p.data.mul_()` — the reference's own EMA helper writes
+# through .data —, an optimiser step replayed from a hipGraph, a raw-pointer kernel) leaves stale planes in use: such
+# writers call invalidate_weight_cache(module_or_parameters) afterwards.  The cache lives in a WeakKeyDictionary beside
+# the parameters, not in Parameter.__dict__: pickling / deepcopying a module does not carry GPU planes along.
 _WCACHE_ON = _os.environ.get("CIPS_D_WCACHE", "1") != "0"
+import weakref as _weakref
+_WCACHE = _weakref.WeakKeyDictionary()                     # Parameter -> {(kind, scale): (version, data_ptr, operand)}
+
+
+def invalidate_weight_cache(what=None):
+    """Drop the cached operand planes of a module's parameters (or of an iterable of parameters; None: of everything).
+    Needed after any weight write that does not bump Tensor._version (see above); cheap to call when nothing is cached."""
+    if what is None:
+        _WCACHE.clear()
+        return
+    params = what.parameters() if isinstance(what, nn.Module) else what
+    for p in params:
+        _WCACHE.pop(p, None)
 
 
 def _cached(w, scale, kind, build):
     """build(w_eff) -> operand for `kind`, memoised on (parameter, version, scale)"""
     if not (_WCACHE_ON and isinstance(w, nn.Parameter)):
         return build(w if scale == 1.0 else w * scale)
-    ent = w.__dict__.setdefault("_cips_planes", {})        # lives and dies with the Parameter object
+    ent = _WCACHE.get(w)                                   # entries die with the Parameter object
+    if ent is None:
+        ent = _WCACHE[w] = {}
     key = (kind, float(scale))
     hit = ent.get(key)
     if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
@@ -750,7 +769,7 @@ class _DiffAugFunction(Function):
     def forward(ctx, x, draws, adjoint, affine):
         import ctypes as C
         from . import _lib
-        rb, rs, rc, tx, ty, ox, oy = draws
+        rb, rs, rc, tx, ty, ox, oy, (cut_h, cut_w, color) = draws
         x = x.contiguous().float()
         B, Cc, H, W = x.shape
         y = torch.empty_like(x)
@@ -759,7 +778,7 @@ class _DiffAugFunction(Function):
         P = lambda t: C.c_void_p(t.data_ptr())
         with torch.cuda.device(x.device):
             _lib.check(lib.cips_diffaug(P(x), P(y), P(rb), P(rs), P(rc), P(tx), P(ty), P(ox), P(oy), P(sums), B, Cc, H, W,
-                                        int(H * 0.2 + 0.5), int(W * 0.2 + 0.5), 1 if adjoint else 0, 1 if affine else 0,
+                                        cut_h, cut_w, 1 if adjoint else 0, (1 if affine else 0) | (0 if color else 2),
                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "cips_diffaug")
         ctx.draws, ctx.adjoint = draws, adjoint
         return y
@@ -769,88 +788,56 @@ class _DiffAugFunction(Function):
         return _DiffAugFunction.apply(g, ctx.draws, not ctx.adjoint, False), None, None, None
 
 
-def _diffaug_hip(x):
-    """policy 'color,translation,cutout' on a GPU batch: the reference's seven draws, in its order and with its calls
-    (diffaug.py:32, 38, 44, 50-51, 66-67), then one fused operator"""
+_POLICY_ORDER = ("color", "translation", "cutout")
+
+
+def _diffaug_hip(x, parts):
+    """`parts`: the policy's stages, a subsequence of (color, translation, cutout).  The reference's draws for the stages
+    that are present, in its order and with its calls (diffaug.py:32, 38, 44, 50-51, 66-67), then one fused operator;
+    an absent stage is the operator's identity setting (no colour arithmetic, zero shift, empty hole)."""
     b, _, h, w = x.shape
     dev = x.device
-    rb = torch.rand(b, 1, 1, 1, dtype=x.dtype, device=dev)
-    rs = torch.rand(b, 1, 1, 1, dtype=x.dtype, device=dev)
-    rc = torch.rand(b, 1, 1, 1, dtype=x.dtype, device=dev)
-    sx, sy = int(h * 0.125 + 0.5), int(w * 0.125 + 0.5)
-    tx = torch.randint(-sx, sx + 1, size=[b, 1, 1], device=dev)
-    ty = torch.randint(-sy, sy + 1, size=[b, 1, 1], device=dev)
-    ch, cw = int(h * 0.2 + 0.5), int(w * 0.2 + 0.5)
-    ox = torch.randint(0, h + (1 - ch % 2), size=[b, 1, 1], device=dev)
-    oy = torch.randint(0, w + (1 - cw % 2), size=[b, 1, 1], device=dev)
+    if "color" in parts:
+        rb = torch.rand(b, 1, 1, 1, dtype=x.dtype, device=dev)
+        rs = torch.rand(b, 1, 1, 1, dtype=x.dtype, device=dev)
+        rc = torch.rand(b, 1, 1, 1, dtype=x.dtype, device=dev)
+    else:
+        rb = rs = rc = torch.full((b,), 0.5, device=dev)
+    if "translation" in parts:
+        sx, sy = int(h * 0.125 + 0.5), int(w * 0.125 + 0.5)
+        tx = torch.randint(-sx, sx + 1, size=[b, 1, 1], device=dev)
+        ty = torch.randint(-sy, sy + 1, size=[b, 1, 1], device=dev)
+    else:
+        tx = ty = torch.zeros(b, dtype=torch.long, device=dev)
+    ch, cw = (int(h * 0.2 + 0.5), int(w * 0.2 + 0.5)) if "cutout" in parts else (0, 0)
+    if "cutout" in parts:
+        ox = torch.randint(0, h + (1 - ch % 2), size=[b, 1, 1], device=dev)
+        oy = torch.randint(0, w + (1 - cw % 2), size=[b, 1, 1], device=dev)
+    else:
+        ox = oy = torch.zeros(b, dtype=torch.long, device=dev)
     draws = tuple(t.reshape(b).contiguous() for t in (rb.float(), rs.float(), rc.float(), tx.long(), ty.long(), ox.long(), oy.long()))
-    return _DiffAugFunction.apply(x, draws, False, True)
-
-
-DIFFAUG_HIP = _os.environ.get("CIPS_DIFFAUG_HIP", "1") != "0"
+    return _DiffAugFunction.apply(x, draws + ((ch, cw, "color" in parts),), False, True)
 
 
 def DiffAugment(x, policy='', channels_first=True):
-    """exp/cips3d/models/diffaug.py:9-85 (color, translation, cutout).  The discriminator's policy on a GPU batch runs as
-    one fused HIP operator with its adjoint (cips_diffaug); other policies / CPU tensors take the op-by-op torch
-    restatement below (same draws, same order)."""
+    """exp/cips3d/models/diffaug.py:9-85 (color, translation, cutout) as one fused HIP operator with its adjoint
+    (cips_diffaug).  Policies are the reference's stage names in the reference's order (any subsequence of
+    color,translation,cutout: what its configs use); the product has no CPU path."""
     if not policy:
         return x
-    if DIFFAUG_HIP and policy == 'color,translation,cutout' and channels_first and x.is_cuda and x.dim() == 4 and x.shape[1] <= 4:
-        return _diffaug_hip(x)
+    parts = tuple(policy.split(','))
+    if any(p not in _POLICY_ORDER for p in parts) or list(parts) != [p for p in _POLICY_ORDER if p in parts]:
+        raise ValueError(f"DiffAugment policy {policy!r}: stages must be a subsequence of {','.join(_POLICY_ORDER)}")
+    if not x.is_cuda or x.dim() != 4:
+        raise RuntimeError("DiffAugment runs on the HIP operator only: a 4-d GPU batch is required")
     if not channels_first:
         x = x.permute(0, 3, 1, 2)
-    for p in policy.split(','):
-        for f in _AUGMENT_FNS[p]:
-            x = f(x)
+    if x.shape[1] > 4:
+        raise RuntimeError("DiffAugment: at most 4 channels (images)")
+    y = _diffaug_hip(x, parts)
     if not channels_first:
-        x = x.permute(0, 2, 3, 1)
-    return x.contiguous()
-
-
-def _rand_brightness(x):
-    return x + (torch.rand(x.size(0), 1, 1, 1, dtype=x.dtype, device=x.device) - 0.5)
-
-
-def _rand_saturation(x):
-    m = x.mean(dim=1, keepdim=True)
-    return (x - m) * (torch.rand(x.size(0), 1, 1, 1, dtype=x.dtype, device=x.device) * 2) + m
-
-
-def _rand_contrast(x):
-    m = x.mean(dim=[1, 2, 3], keepdim=True)
-    return (x - m) * (torch.rand(x.size(0), 1, 1, 1, dtype=x.dtype, device=x.device) + 0.5) + m
-
-
-def _rand_translation(x, ratio=0.125):
-    sx, sy = int(x.size(2) * ratio + 0.5), int(x.size(3) * ratio + 0.5)
-    tx = torch.randint(-sx, sx + 1, size=[x.size(0), 1, 1], device=x.device)
-    ty = torch.randint(-sy, sy + 1, size=[x.size(0), 1, 1], device=x.device)
-    gb, gx, gy = torch.meshgrid(torch.arange(x.size(0), dtype=torch.long, device=x.device),
-                                torch.arange(x.size(2), dtype=torch.long, device=x.device),
-                                torch.arange(x.size(3), dtype=torch.long, device=x.device), indexing="ij")
-    gx = torch.clamp(gx + tx + 1, 0, x.size(2) + 1)
-    gy = torch.clamp(gy + ty + 1, 0, x.size(3) + 1)
-    xp = F.pad(x, [1, 1, 1, 1, 0, 0, 0, 0])
-    return xp.permute(0, 2, 3, 1).contiguous()[gb, gx, gy].permute(0, 3, 1, 2)
-
-
-def _rand_cutout(x, ratio=0.2):      # the reference's default (diffaug.py:64), not the DiffAugment paper's 0.5
-    cs = int(x.size(2) * ratio + 0.5), int(x.size(3) * ratio + 0.5)
-    ox = torch.randint(0, x.size(2) + (1 - cs[0] % 2), size=[x.size(0), 1, 1], device=x.device)
-    oy = torch.randint(0, x.size(3) + (1 - cs[1] % 2), size=[x.size(0), 1, 1], device=x.device)
-    gb, gx, gy = torch.meshgrid(torch.arange(x.size(0), dtype=torch.long, device=x.device),
-                                torch.arange(cs[0], dtype=torch.long, device=x.device),
-                                torch.arange(cs[1], dtype=torch.long, device=x.device), indexing="ij")
-    gx = torch.clamp(gx + ox - cs[0] // 2, min=0, max=x.size(2) - 1)
-    gy = torch.clamp(gy + oy - cs[1] // 2, min=0, max=x.size(3) - 1)
-    mask = torch.ones(x.size(0), x.size(2), x.size(3), dtype=x.dtype, device=x.device)
-    mask[gb, gx, gy] = 0
-    return x * mask.unsqueeze(1)
-
-
-_AUGMENT_FNS = {'color': [_rand_brightness, _rand_saturation, _rand_contrast],
-                'translation': [_rand_translation], 'cutout': [_rand_cutout]}
+        y = y.permute(0, 2, 3, 1)
+    return y.contiguous()
 
 
 def _hip_unary(name, *args):

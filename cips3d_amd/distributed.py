@@ -13,6 +13,7 @@ step issues, per bucket, one concatenation, one all-reduce and one multi-tensor 
 host synchronisation and no per-parameter launches (the G step is ~21 ms on an MI355X; 170
 per-tensor copies plus a `.tolist()` would cost > 5 % of it)."""
 import contextlib
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -62,8 +63,18 @@ class GradAllReducer:
         self._early = 0          # buckets issued from hooks during the current backward
         self.last_launched_early = 0   # ... during the backward that the last __call__ closed (statistics / tests)
         if self.overlap:
+            # torch refuses a hook on a tensor that does not require a gradient, and train.py toggles requires_grad on
+            # G and D every step (a reducer may be built while a sub-net is frozen, or for a frozen-NeRF generator):
+            # register with the flag raised for the moment; a parameter that stays frozen simply never fires its hook
+            # (its bucket is issued by __call__'s forced pass)
             for p in self.params:
+                frozen = not p.requires_grad
+                if frozen:
+                    p.requires_grad_(True)
                 p.register_post_accumulate_grad_hook(self._on_grad)
+                if frozen:
+                    p.requires_grad_(False)
+        self._grad_refs = None   # weak references to the gradient tensors left behind by the last call (see __call__)
         self._local = None       # this rank's presence pattern the cached plan was built for
         self._union = None       # the agreed pattern (union over ranks): what `.grad is not None` looks like after a call
         self._buckets = None     # list of lists of parameters (the union over ranks, bucketed)
@@ -93,6 +104,16 @@ class GradAllReducer:
         self._reset_step()
         # plan checksum: exactly representable in fp32 so that the mean over identical ranks is exact
         self._sig = float(sum((i + 1) * 7 for i, f in enumerate(flags) if f) % 65521)
+
+    def _sig_for(self, dtype):
+        """the checksum as carried inside a bucket of `dtype`: half-precision buckets (fp16 / bf16 gradients) hold integers
+        exactly only up to 2048 / 256, so the value is folded below that; fp32 / fp64 carry it as is"""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if dtype == torch.float16:
+            return float(int(self._sig) % max(1, 2048 // world))       # every partial sum over the ranks stays an exact integer
+        if dtype == torch.bfloat16:
+            return float(int(self._sig) % max(1, 256 // world))
+        return self._sig
 
     def _reset_step(self):
         self._arrived = [0] * len(self._buckets or [])
@@ -139,18 +160,18 @@ class GradAllReducer:
             ev.record(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)        # the gradients of this bucket are complete on the producing stream
-                sig = torch.full((1,), self._sig, device=dev, dtype=grads[0].dtype)
+                sig = torch.full((1,), self._sig_for(grads[0].dtype), device=dev, dtype=grads[0].dtype)
                 flat = torch.cat([g.reshape(-1) for g in grads] + [sig])
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            sig = torch.full((1,), self._sig, device=dev, dtype=grads[0].dtype)
+            sig = torch.full((1,), self._sig_for(grads[0].dtype), device=dev, dtype=grads[0].dtype)
             flat = torch.cat([g.reshape(-1) for g in grads] + [sig])
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._inflight.append((flat, work, grads))
 
     def _drain(self, world):
-        """wait for the issued buckets, divide, copy back; returns (bytes, checksum views)"""
-        nbytes, sigs = 0, []
+        """wait for the issued buckets, divide, copy back; returns (bytes, checksum views, expected checksums)"""
+        nbytes, sigs, wants = 0, [], []
         dev = self.params[0].device
         ctx = torch.cuda.stream(self._side) if (dev.type == "cuda" and self._side is not None) else _null()
         with ctx:
@@ -164,11 +185,12 @@ class GradAllReducer:
                     off += n
                 torch._foreach_copy_(grads, views)
                 sigs.append(flat[off:off + 1])
+                wants.append(self._sig_for(flat.dtype))
                 nbytes += (flat.numel() - 1) * flat.element_size()
         if dev.type == "cuda" and self._side is not None:
             torch.cuda.current_stream(dev).wait_stream(self._side)
         self._inflight = []
-        return nbytes, sigs
+        return nbytes, sigs, wants
 
     def _check_pending(self, block=False):
         if self._pending is None:
@@ -179,7 +201,7 @@ class GradAllReducer:
                 return
             ev.synchronize()
         self._pending = None
-        if any(abs(float(v) - want) > 1e-3 for v in host.tolist()):
+        if any(abs(float(v) - w) > 1e-3 for v, w in zip(host.tolist(), want)):
             raise RuntimeError("GradAllReducer: ranks reduced with different bucket plans — the set of parameters with "
                                "a gradient changed on some ranks only (see the class contract)")
 
@@ -195,18 +217,23 @@ class GradAllReducer:
         local = tuple(p.grad is not None for p in self.params)
         # a change of the local pattern (another loss, a frozen sub-net) re-plans; see the contract above.  A caller
         # that did not reset the gradients to None (zero_grad(set_to_none=False), gradient accumulation) shows the
-        # agreed union pattern on every rank: same plan, no re-plan.
-        if local != self._local and local != self._union:
+        # agreed union pattern on every rank: same plan, no re-plan.  That shortcut is taken only when the gradient
+        # tensors ARE the ones the last call left behind (then every rank sees the union, so the decision is the same
+        # everywhere); a rank whose freshly produced pattern merely happens to equal the old union re-plans like its
+        # peers whose pattern changed — the re-plan is a collective, all ranks or none must enter it.
+        kept = self._grad_refs is not None and local == self._union and all(
+            (not f) or (r is not None and r() is p.grad) for p, f, r in zip(self.params, self._union, self._grad_refs))
+        if local != self._local and not kept:
             self._check_pending(block=True)
             self._plan(local)
         nbytes = 0
-        sigs = []
+        sigs, wants = [], []
         for bucket in self._buckets:
             for p in bucket:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
             grads = [p.grad for p in bucket]
-            sig = torch.full((1,), self._sig, device=grads[0].device, dtype=grads[0].dtype)
+            sig = torch.full((1,), self._sig_for(grads[0].dtype), device=grads[0].device, dtype=grads[0].dtype)
             flat = torch.cat([g.reshape(-1) for g in grads] + [sig])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             flat.div_(world)
@@ -218,12 +245,15 @@ class GradAllReducer:
                 off += n
             torch._foreach_copy_(grads, views)
             sigs.append(flat[off:off + 1])
-        self._record_sigs(sigs, self._sig)
+            wants.append(self._sig_for(flat.dtype))
+        self._record_sigs(sigs, wants)
+        self._grad_refs = [None if p.grad is None else weakref.ref(p.grad) for p in self.params]
         if self.overlap:
             self._reset_step()
         return nbytes
 
     def _record_sigs(self, sigs, want):
+        """sigs: one reduced checksum element per bucket; want: the value each must hold"""
         if not sigs:
             return
         got = torch.cat(sigs).float()
@@ -238,14 +268,14 @@ class GradAllReducer:
 
     def _finish_overlapped(self, world):
         """overlap mode, plan present: issue what the hooks did not, wait, copy back; then deal with a changed pattern"""
-        old_union, old_sig = self._union, self._sig
+        old_union = self._union
         # the presence pattern of THIS backward = the gradients whose hooks fired (buckets issued early have already filled
         # the gradients this rank does not produce with zeros, so `.grad is not None` no longer tells)
         local = tuple(i in self._seen for i in range(len(self.params)))
         self.last_launched_early = self._early
         self._issue_ready(force=True)             # same bucket order on every rank, whatever arrived
-        nbytes, sigs = self._drain(world)
-        self._record_sigs(sigs, old_sig)
+        nbytes, sigs, wants = self._drain(world)
+        self._record_sigs(sigs, wants)
         changed = local != self._local
         if changed:
             # (contract: every rank sees a change in the same step)  Parameters of the old plan are reduced; agree on the

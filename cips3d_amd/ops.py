@@ -1126,6 +1126,57 @@ def torgb_bwd_w_x3(xp, drgb2d):
 INR_GATE_BITS = _os.environ.get("CIPS_INR_GATE_BITS", "1") != "0"
 
 
+# The head is independent per image (per-image modulated weights): it can run as several CHAINS of launches, one per
+# contiguous range of images, on different streams.  Every launch of a chain is a persistent grid that owns whole CUs
+# (160 KiB of LDS), so the chains do not share CUs — they fill each other's tails: while the last workgroups of a
+# GEMM of chain A are still in their store-bound epilogue, chain B's next GEMM already streams operands on the CUs that
+# are free, and the HBM write bursts of the epilogues (every CU reaches its epilogue at the same moment within ONE
+# launch: 4 TB/s of writes and an idle matrix pipe) are spread over the other chain's main loops.
+# CIPS_INR_CHUNKS=1: one chain (the round-2 behaviour).
+INR_CHUNKS = int(_os.environ.get("CIPS_INR_CHUNKS", "1"))
+_SIDE_STREAMS = {}
+
+
+def _bsl(t, b0, b1):
+    """images b0..b1 of a (B, ...) tensor / Planes (a contiguous view)"""
+    if t is None:
+        return None
+    if isinstance(t, Planes):
+        return Planes(t.hi[b0:b1], t.lo[b0:b1])
+    return t[b0:b1]
+
+
+def _chunk_ranges(B):
+    nch = INR_CHUNKS if (INR_CHUNKS > 1 and B % INR_CHUNKS == 0 and B // INR_CHUNKS >= 8) else 1
+    step = B // nch
+    return [(i * step, (i + 1) * step) for i in range(nch)]
+
+
+def _run_chunks(ranges, fn, dev):
+    """fn(b0, b1) for every range: the first on the current stream, the others on side streams forked from it and
+    joined back (capturable: the side streams enter a hipGraph capture through the event wait)"""
+    if len(ranges) == 1:
+        fn(*ranges[0])
+        return
+    main = torch.cuda.current_stream(dev)
+    fork = torch.cuda.Event()
+    fork.record(main)
+    done = []
+    for i, r in enumerate(ranges[1:]):
+        side = _SIDE_STREAMS.get((dev.index, i))
+        if side is None:
+            side = _SIDE_STREAMS[(dev.index, i)] = torch.cuda.Stream(device=dev)
+        side.wait_event(fork)
+        with torch.cuda.stream(side):
+            fn(*r)
+            e = torch.cuda.Event()
+            e.record(side)
+            done.append(e)
+    fn(*ranges[0])
+    for e in done:
+        main.wait_event(e)
+
+
 class InrHeadX3Function(torch.autograd.Function):
     """Same contract as InrHeadFunction, on the bf16x3 GEMM.  Every activation / gradient lives in HBM
     as bf16 hi/lo planes in both orientations (row-major for the forward / dX operand, transposed for
@@ -1146,63 +1197,88 @@ class InrHeadX3Function(torch.autograd.Function):
         _chk(x0, *[t for blk in blocks for t in blk], *rgbp)
         train = grad_mode and any(ctx.needs_input_grad)       # no-grad / inference: no transposed planes, nothing kept
         want_t = train and not INR_W_KMAJOR     # K-major dW form reads the row-major planes: no transposed copies
-        xP, xT = split_planes(x0, want_t=want_t)
+        x0P, x0T = split_planes(x0, want_t=want_t)
         rgb = torch.empty(B, n, 3, device=dev)
-        first_rgb = True
-        saved = []
         # modulate / demodulate / split every layer's weights up front, in one batch
         prepped = modfc_prep_x3_batch([(W, s_) for (W1, s1, W2, s2) in blocks for (W, s_) in ((W1, s1), (W2, s2))])
+        dbg = GATE_PIN is not None or GATE_REC is not None          # gate instrumentation (tests): bit planes always
+        # every full-batch buffer is allocated here, on the caller's stream, before the chains fork
+        plan = []
         for k, (W1, s1, W2, s2) in enumerate(blocks):
             cin, cout = W1.shape
-            wb1, wbt1, d1 = prepped[2 * k]
-            a1P = Planes.empty(B, n, cout, device=dev)
-            a1T = Planes.empty(B, cout, n, device=dev) if want_t else None
-            dbg = GATE_PIN is not None or GATE_REC is not None          # gate instrumentation (tests): bit planes always
             bits = (train or dbg) and (INR_GATE_BITS or dbg) and cout % 32 == 0
             pin1 = _next_pin(B, n, cout, dev)
             pin2 = _next_pin(B, n, cout, dev)
             if (pin1 is not None or GATE_REC is not None) and not bits:
                 raise RuntimeError("gate instrumentation needs layer widths that are multiples of 32")
-            a1g = pin1 if pin1 is not None else (torch.empty(B, n, cout // 8, device=dev, dtype=torch.uint8) if bits else None)
-            if pin1 is not None:
-                # pinned: `gate ? 1 : slope` from the supplied plane in place of the LeakyReLU on the computed sign
-                gemm_x3(xP, wbt1, n, cout, cin, cin, cin, B, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
-                        mask=pin1, gate_bits=1)
-            else:
-                gemm_x3(xP, wbt1, n, cout, cin, cin, cin, B, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
-                        act=1, mask_out=a1g, gate_bits=2 if bits else 0)
-            wb2, wbt2, d2 = prepped[2 * k + 1]
             skip = (k >= 4) and (cin == cout)
-            oP = Planes.empty(B, n, cout, device=dev)
-            oT = Planes.empty(B, cout, n, device=dev) if want_t else None
+            e = dict(cin=cin, cout=cout, bits=bits, pin1=pin1, pin2=pin2, skip=skip)
+            e["a1P"] = Planes.empty(B, n, cout, device=dev)
+            e["a1T"] = Planes.empty(B, cout, n, device=dev) if want_t else None
+            e["a1g"] = pin1 if pin1 is not None else (torch.empty(B, n, cout // 8, device=dev, dtype=torch.uint8) if bits else None)
+            e["oP"] = Planes.empty(B, n, cout, device=dev)
+            e["oT"] = Planes.empty(B, cout, n, device=dev) if want_t else None
             if pin2 is not None:
-                m2 = pin2
-                gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
-                        strideT=cout * n, res=xP if skip else None, mask=pin2, gate_bits=1)
+                e["m2"] = pin2
             elif bits:
-                m2 = torch.empty(B, n, cout // 8, device=dev, dtype=torch.uint8)
-                gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
-                        strideT=cout * n, act=1, res=xP if skip else None, mask_out=m2, gate_bits=2)
+                e["m2"] = torch.empty(B, n, cout // 8, device=dev, dtype=torch.uint8)
             elif skip:
-                m2 = torch.empty(B, n, cout, device=dev, dtype=BF) if train else None
-                gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
-                        strideT=cout * n, act=1, res=xP, mask_out=m2)
+                e["m2"] = torch.empty(B, n, cout, device=dev, dtype=BF) if train else None
             else:
-                m2 = oP.hi
-                gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, B, n * cout, cout * cout, P=oP, T=oT, ldt=n,
-                        strideT=cout * n, act=1)
+                e["m2"] = e["oP"].hi
+            plan.append(e)
+        any_rgb = nblocks > 3
+
+        def run(b0, b1):
+            nb = b1 - b0
+            xP = _bsl(x0P, b0, b1)
+            first_rgb = True
+            for k, e in enumerate(plan):
+                cin, cout, bits, skip = e["cin"], e["cout"], e["bits"], e["skip"]
+                wb1, wbt1, d1 = prepped[2 * k]
+                wb2, wbt2, d2 = prepped[2 * k + 1]
+                wbt1, wbt2 = _bsl(wbt1, b0, b1), _bsl(wbt2, b0, b1)
+                a1P, a1T, a1g = _bsl(e["a1P"], b0, b1), _bsl(e["a1T"], b0, b1), _bsl(e["a1g"], b0, b1)
+                oP, oT, m2 = _bsl(e["oP"], b0, b1), _bsl(e["oT"], b0, b1), _bsl(e["m2"], b0, b1)
+                if e["pin1"] is not None:
+                    # pinned: `gate ? 1 : slope` from the supplied plane in place of the LeakyReLU on the computed sign
+                    gemm_x3(xP, wbt1, n, cout, cin, cin, cin, nb, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
+                            mask=a1g, gate_bits=1)
+                else:
+                    gemm_x3(xP, wbt1, n, cout, cin, cin, cin, nb, n * cin, cout * cin, P=a1P, T=a1T, ldt=n, strideT=cout * n,
+                            act=1, mask_out=a1g, gate_bits=2 if bits else 0)
+                if e["pin2"] is not None:
+                    gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, nb, n * cout, cout * cout, P=oP, T=oT, ldt=n,
+                            strideT=cout * n, res=xP if skip else None, mask=m2, gate_bits=1)
+                elif bits:
+                    gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, nb, n * cout, cout * cout, P=oP, T=oT, ldt=n,
+                            strideT=cout * n, act=1, res=xP if skip else None, mask_out=m2, gate_bits=2)
+                elif skip:
+                    gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, nb, n * cout, cout * cout, P=oP, T=oT, ldt=n,
+                            strideT=cout * n, act=1, res=xP, mask_out=m2)
+                else:
+                    gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, nb, n * cout, cout * cout, P=oP, T=oT, ldt=n,
+                            strideT=cout * n, act=1)
+                if k >= 3:
+                    torgb_fwd_x3(oP, rgbp[2 * (k - 3)], rgbp[2 * (k - 3) + 1], rgb[b0:b1].view(nb * n, 3), accumulate=not first_rgb)
+                    first_rgb = False
+                xP = oP
+
+        _run_chunks(_chunk_ranges(B), run, dev)
+        saved = []
+        xP, xT = x0P, x0T
+        for k, e in enumerate(plan):
             if GATE_REC is not None:
-                GATE_REC.append(a1g)
-                GATE_REC.append(m2)
-            if k >= 3:
-                torgb_fwd_x3(oP, rgbp[2 * (k - 3)], rgbp[2 * (k - 3) + 1], rgb.view(B * n, 3), accumulate=not first_rgb)
-                first_rgb = False
+                GATE_REC.append(e["a1g"])
+                GATE_REC.append(e["m2"])
             if train:
                 # keep for backward: xT (dW1), a1 gate + a1T (dW2), out planes (ToRGB grad), m2 gate, weights
-                saved.append(dict(xT=xT, xP=xP, a1P=a1P, a1m=a1g if bits else a1P.hi, a1T=a1T, oP=oP, m2=m2, wb1=wb1, d1=d1,
-                                  wb2=wb2, d2=d2, skip=skip, bits=bits))
-            xP, xT = oP, oT
-        if first_rgb:
+                wb1, _, d1 = prepped[2 * k]
+                wb2, _, d2 = prepped[2 * k + 1]
+                saved.append(dict(xT=xT, xP=xP, a1P=e["a1P"], a1m=e["a1g"] if e["bits"] else e["a1P"].hi, a1T=e["a1T"], oP=e["oP"],
+                                  m2=e["m2"], wb1=wb1, d1=d1, wb2=wb2, d2=d2, skip=e["skip"], bits=e["bits"]))
+            xP, xT = e["oP"], e["oT"]
+        if not any_rgb:
             rgb.zero_()
         ctx.nblocks, ctx.blocks, ctx.rgbp, ctx.saved = nblocks, blocks, rgbp, saved
         ctx.dims = (B, n)
@@ -1215,82 +1291,106 @@ class InrHeadX3Function(torch.autograd.Function):
         B, n = ctx.dims
         drgb = _c(drgb)
         dev = drgb.device
-        drgb2 = drgb.view(B * n, 3)
+        width = blocks[-1][2].shape[1]
+        km = ctx.kmajor
+        # full-batch outputs of the chains: per-image dL/dWb of every layer, dx0, and the ToRGB weight-gradient partials
+        gwb = []
+        for k in range(nblocks):
+            cin, cout = blocks[k][0].shape
+            gwb.append((torch.empty(B, cin, cout, device=dev), torch.empty(B, cout, cout, device=dev)))       # (gwb1, gwb2)
+        cin0 = blocks[0][0].shape[0]
+        dx0 = torch.empty(B, n, cin0, device=dev)
+        ranges = _chunk_ranges(B)
+        rgb_parts = [[None] * len(ranges) for _ in range(nblocks)]
+        tpad = None
+        if nblocks - 1 >= 3:
+            T = rgbp[2 * (nblocks - 1 - 3)]
+            tpad = torch.zeros(1, width, 32, device=dev); tpad[0, :, :3] = T.t()
+            tP, _ = split_planes(tpad, want_t=False)
+
+        def run(b0, b1):
+            nb = b1 - b0
+            ci = [r[0] for r in ranges].index(b0)
+            drgb_c = drgb[b0:b1]
+            drgb2 = drgb_c.reshape(nb * n, 3)
+            PT = (lambda c: None) if km else (lambda c: Planes.empty(nb, c, n, device=dev))
+            k = nblocks - 1
+            gP, gT = Planes.empty(nb, n, width, device=dev), PT(width)
+            Dout = None
+            if k >= 3:
+                # grad wrt out_k = drgb @ T_k as a K=32 zero-padded bf16x3 GEMM (gate of a2_k fused)
+                dpad = torch.zeros(nb, n, 32, device=dev); dpad[..., :3] = drgb_c
+                dP, _ = split_planes(dpad, want_t=False)
+                Dout = torch.empty(nb, n, width, device=dev) if saved[k]["skip"] else None
+                gemm_x3(dP, tP, n, width, 32, 32, 32, nb, n * 32, 0, P=gP, T=gT, ldt=n, strideT=width * n,
+                        C_unmasked=Dout, mask=_bsl(saved[k]["m2"], b0, b1), gate_bits=1 if saved[k]["bits"] else 0)
+            else:
+                gP.hi.zero_(); gP.lo.zero_()
+                if gT is not None:
+                    gT.hi.zero_(); gT.lo.zero_()
+                Dout = torch.zeros(nb, n, width, device=dev) if saved[k]["skip"] else None
+            for k in range(nblocks - 1, -1, -1):
+                sv = saved[k]
+                W1, s1, W2, s2 = blocks[k]
+                cin, cout = W1.shape
+                if k >= 3:
+                    rgb_parts[k][ci] = torgb_bwd_w_x3(_bsl(sv["oP"], b0, b1), drgb2)
+                # ---- mod2: gradient through the gate of a1 ----
+                g1P, g1T = Planes.empty(nb, n, cout, device=dev), PT(cout)
+                gemm_x3(gP, _bsl(sv["wb2"], b0, b1), n, cout, cout, cout, cout, nb, n * cout, cout * cout, P=g1P, T=g1T, ldt=n,
+                        strideT=cout * n, mask=_bsl(sv["a1m"], b0, b1), gate_bits=1 if sv["bits"] else 0)
+                # ---- weight gradients of both layers: dWb2 = a1^T g, dWb1 = x^T g1 ----
+                gwb1, gwb2 = gwb[k][0][b0:b1], gwb[k][1][b0:b1]
+                a1P, xP = _bsl(sv["a1P"], b0, b1), _bsl(sv["xP"], b0, b1)
+                if km:
+                    # dWb[b] = X[b]^T G[b] contracts over the n pixels of image b.  With few images per GPU a 512x512
+                    # output is too few tiles for the chip, so the pixel range is split in `ksp` parts — a pure view of
+                    # the row-major planes, (B, n, C) -> (B*ksp, n/ksp, C) — and the partial products are summed.
+                    ksp = 1
+                    while nb * ksp < 32 and n % (2 * ksp * 32) == 0 and n // (2 * ksp) >= 512:
+                        ksp *= 2
+                    nk_ = n // ksp
+                    part2 = gwb2 if ksp == 1 else torch.empty(nb * ksp, cout, cout, device=dev)
+                    part1 = gwb1 if ksp == 1 else torch.empty(nb * ksp, cin, cout, device=dev)
+                    if cin == cout:
+                        gemm_x3_km_grouped([(a1P, gP, part2), (xP, g1P, part1)], cout, cout, nk_, cout, cout,
+                                           nb * ksp, nk_ * cout, nk_ * cout)
+                    else:
+                        gemm_x3_km(a1P, gP, cout, cout, nk_, cout, cout, nb * ksp, nk_ * cout, nk_ * cout, part2)
+                        gemm_x3_km(xP, g1P, cin, cout, nk_, cin, cout, nb * ksp, nk_ * cin, nk_ * cout, part1)
+                    if ksp > 1:
+                        torch.sum(part2.view(nb, ksp, cout, cout), dim=1, out=gwb2)
+                        torch.sum(part1.view(nb, ksp, cin, cout), dim=1, out=gwb1)
+                else:
+                    gemm_x3(_bsl(sv["a1T"], b0, b1), gT, cout, cout, n, n, n, nb, cout * n, cout * n, C=gwb2)
+                    gemm_x3(_bsl(sv["xT"], b0, b1), g1T, cin, cout, n, n, n, nb, cin * n, cout * n, C=gwb1)
+                if k == 0:
+                    gemm_x3(g1P, _bsl(sv["wb1"], b0, b1), n, cin, cout, cout, cout, nb, n * cout, cin * cout, C=dx0[b0:b1])
+                else:
+                    pv = saved[k - 1]
+                    newD = torch.empty(nb, n, cin, device=dev) if pv["skip"] else None
+                    gP, gT = Planes.empty(nb, n, cin, device=dev), PT(cin)
+                    gemm_x3(g1P, _bsl(sv["wb1"], b0, b1), n, cin, cout, cout, cout, nb, n * cout, cin * cout, P=gP, T=gT, ldt=n,
+                            strideT=cin * n, add=Dout if sv["skip"] else None,
+                            rgb_g=drgb2 if k - 1 >= 3 else None, rgb_w=rgbp[2 * (k - 1 - 3)] if k - 1 >= 3 else None,
+                            C_unmasked=newD, mask=_bsl(pv["m2"], b0, b1), gate_bits=1 if pv["bits"] else 0)
+                    Dout = newD
+
+        _run_chunks(ranges, run, dev)
         grads_blocks = [None] * nblocks
         grads_rgb = [None] * len(rgbp)
-        width = blocks[-1][2].shape[1]
-        k = nblocks - 1
-        km = ctx.kmajor
-        PT = (lambda c: None) if km else (lambda c: Planes.empty(B, c, n, device=dev))
-        gP, gT = Planes.empty(B, n, width, device=dev), PT(width)
-        Dout = None
-        if k >= 3:
-            # grad wrt out_k = drgb @ T_k as a K=32 zero-padded bf16x3 GEMM (gate of a2_k fused)
-            T = rgbp[2 * (k - 3)]
-            dpad = torch.zeros(B, n, 32, device=dev); dpad[..., :3] = drgb
-            tpad = torch.zeros(1, width, 32, device=dev); tpad[0, :, :3] = T.t()
-            dP, _ = split_planes(dpad, want_t=False)
-            tP, _ = split_planes(tpad, want_t=False)
-            Dout = torch.empty(B, n, width, device=dev) if saved[k]["skip"] else None
-            gemm_x3(dP, tP, n, width, 32, 32, 32, B, n * 32, 0, P=gP, T=gT, ldt=n, strideT=width * n,
-                    C_unmasked=Dout, mask=saved[k]["m2"], gate_bits=1 if saved[k]["bits"] else 0)
-        else:
-            gP.hi.zero_(); gP.lo.zero_()
-            if gT is not None:
-                gT.hi.zero_(); gT.lo.zero_()
-            Dout = torch.zeros(B, n, width, device=dev) if saved[k]["skip"] else None
-        dx0 = None
-        pending = []      # (W, s, demod, dL/dWb) of every layer: their prep backward runs as one batch at the end
+        for k in range(3, nblocks):
+            parts = rgb_parts[k]
+            dT, dtau = parts[0]
+            for q in parts[1:]:
+                dT = dT + q[0]; dtau = dtau + q[1]
+            grads_rgb[2 * (k - 3)], grads_rgb[2 * (k - 3) + 1] = dT, dtau
+        pending = []      # (W, s, demod, dL/dWb) of every layer: their prep backward runs as one batch
         for k in range(nblocks - 1, -1, -1):
             sv = saved[k]
             W1, s1, W2, s2 = blocks[k]
-            cin, cout = W1.shape
-            if k >= 3:
-                dT, dtau = torgb_bwd_w_x3(sv["oP"], drgb2)
-                grads_rgb[2 * (k - 3)], grads_rgb[2 * (k - 3) + 1] = dT, dtau
-            # ---- mod2: gradient through the gate of a1 ----
-            g1P, g1T = Planes.empty(B, n, cout, device=dev), PT(cout)
-            gemm_x3(gP, sv["wb2"], n, cout, cout, cout, cout, B, n * cout, cout * cout, P=g1P, T=g1T, ldt=n,
-                    strideT=cout * n, mask=sv["a1m"], gate_bits=1 if sv["bits"] else 0)
-            # ---- weight gradients of both layers: dWb2 = a1^T g, dWb1 = x^T g1 ----
-            gwb2 = torch.empty(B, cout, cout, device=dev)
-            gwb1 = torch.empty(B, cin, cout, device=dev)
-            if km:
-                # dWb[b] = X[b]^T G[b] contracts over the n pixels of image b.  With few images per GPU a 512x512
-                # output is too few tiles for the chip, so the pixel range is split in `ksp` parts — a pure view of
-                # the row-major planes, (B, n, C) -> (B*ksp, n/ksp, C) — and the partial products are summed.
-                ksp = 1
-                while B * ksp < 32 and n % (2 * ksp * 32) == 0 and n // (2 * ksp) >= 512:
-                    ksp *= 2
-                nk_ = n // ksp
-                part2 = gwb2 if ksp == 1 else torch.empty(B * ksp, cout, cout, device=dev)
-                part1 = gwb1 if ksp == 1 else torch.empty(B * ksp, cin, cout, device=dev)
-                if cin == cout:
-                    gemm_x3_km_grouped([(sv["a1P"], gP, part2), (sv["xP"], g1P, part1)], cout, cout, nk_, cout, cout,
-                                       B * ksp, nk_ * cout, nk_ * cout)
-                else:
-                    gemm_x3_km(sv["a1P"], gP, cout, cout, nk_, cout, cout, B * ksp, nk_ * cout, nk_ * cout, part2)
-                    gemm_x3_km(sv["xP"], g1P, cin, cout, nk_, cin, cout, B * ksp, nk_ * cin, nk_ * cout, part1)
-                if ksp > 1:
-                    torch.sum(part2.view(B, ksp, cout, cout), dim=1, out=gwb2)
-                    torch.sum(part1.view(B, ksp, cin, cout), dim=1, out=gwb1)
-            else:
-                gemm_x3(sv["a1T"], gT, cout, cout, n, n, n, B, cout * n, cout * n, C=gwb2)
-                gemm_x3(sv["xT"], g1T, cin, cout, n, n, n, B, cin * n, cout * n, C=gwb1)
-            pending.append((W2, s2, sv["d2"], gwb2))
-            pending.append((W1, s1, sv["d1"], gwb1))
-            if k == 0:
-                dx0 = torch.empty(B, n, cin, device=dev)
-                gemm_x3(g1P, sv["wb1"], n, cin, cout, cout, cout, B, n * cout, cin * cout, C=dx0)
-            else:
-                pv = saved[k - 1]
-                newD = torch.empty(B, n, cin, device=dev) if pv["skip"] else None
-                gP, gT = Planes.empty(B, n, cin, device=dev), PT(cin)
-                gemm_x3(g1P, sv["wb1"], n, cin, cout, cout, cout, B, n * cout, cin * cout, P=gP, T=gT, ldt=n,
-                        strideT=cin * n, add=Dout if sv["skip"] else None,
-                        rgb_g=drgb2 if k - 1 >= 3 else None, rgb_w=rgbp[2 * (k - 1 - 3)] if k - 1 >= 3 else None,
-                        C_unmasked=newD, mask=pv["m2"], gate_bits=1 if pv["bits"] else 0)
-                Dout = newD
+            pending.append((W2, s2, sv["d2"], gwb[k][1]))
+            pending.append((W1, s1, sv["d1"], gwb[k][0]))
         res = modfc_prep_bwd_batch(pending)          # pending order: block nblocks-1 (mod2, mod1), ..., block 0
         for i, k in enumerate(range(nblocks - 1, -1, -1)):
             (dW2, ds2), (dW1, ds1) = res[2 * i], res[2 * i + 1]

@@ -70,6 +70,7 @@ class FusedClipAdamEMA:
         # has completed (its event), so a host that runs ahead of the stream cannot overwrite a table in flight
         self._ring = [[torch.empty(C.sizeof(self._table_host), dtype=torch.uint8).pin_memory(), None] for _ in range(4)]
         self._ring_pos = 0
+        self._captured = []          # pinned tables read by captured uploads (kept alive for the graphs' lifetime)
         self._uploaded = None        # bytes of the table the device currently holds
 
     @property
@@ -83,7 +84,12 @@ class FusedClipAdamEMA:
 
     @torch.no_grad()
     def step(self, itr=None):
-        """Returns the pre-clip total gradient norm as a 1-element device tensor (no host sync)."""
+        """Returns the pre-clip total gradient norm as a 1-element device tensor (no host sync).
+
+        The kernels write parameters and EMA copies through raw pointers; the eager call bumps their autograd version
+        counters so that operands memoised per parameter version (the discriminator's weight planes) are rebuilt.  A
+        REPLAY of a captured step runs no Python: call cips3d_amd.discriminator.invalidate_weight_cache(module) after
+        replaying a graph that contains this step."""
         lib = _lib.load()
         do_ema = self.ema is not None and (itr is None or itr >= self.ema_start_itr)
         for i, p in enumerate(self.params):
@@ -97,17 +103,27 @@ class FusedClipAdamEMA:
             t.n = p.numel()
             t.step = 0                       # unused: the step counts are device-side (steps_dev)
         raw = bytes(self._table_host)
-        if raw != self._uploaded:            # pointers change when autograd reallocates gradients; often they do not
-            slot = self._ring[self._ring_pos]
-            self._ring_pos = (self._ring_pos + 1) % len(self._ring)
-            if slot[1] is not None:
-                slot[1].synchronize()        # the copy that last read this slot (4 uploads ago) — long done
-            C.memmove(slot[0].data_ptr(), C.addressof(self._table_host), C.sizeof(self._table_host))
-            self._table_dev.copy_(slot[0], non_blocking=True)
-            if not torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if raw != self._uploaded or capturing:   # pointers change when autograd reallocates gradients; often they do not
+            if capturing:
+                # a captured upload is re-executed by every replay: it reads a pinned buffer of its own that nothing
+                # rewrites afterwards (a ring slot would be overwritten by later eager uploads, and a replay would then
+                # upload whatever pointers the slot holds at that time)
+                buf = torch.empty(C.sizeof(self._table_host), dtype=torch.uint8).pin_memory()
+                self._captured.append(buf)
+                C.memmove(buf.data_ptr(), C.addressof(self._table_host), C.sizeof(self._table_host))
+                self._table_dev.copy_(buf, non_blocking=True)
+                self._uploaded = None            # a replay may restore this table at any time: never skip an eager upload
+            else:
+                slot = self._ring[self._ring_pos]
+                self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+                if slot[1] is not None:
+                    slot[1].synchronize()        # the copy that last read this slot (4 uploads ago) — long done
+                C.memmove(slot[0].data_ptr(), C.addressof(self._table_host), C.sizeof(self._table_host))
+                self._table_dev.copy_(slot[0], non_blocking=True)
                 slot[1] = torch.cuda.Event()
                 slot[1].record()
-            self._uploaded = raw
+                self._uploaded = raw if not self._captured else None
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         check(lib.cips_opt_step(C.c_void_p(self._table_dev.data_ptr()), C.c_void_p(self._chunk_tensor.data_ptr()),
                                 C.c_void_p(self._chunk_off.data_ptr()), self.nchunks,

@@ -453,7 +453,9 @@ int cips_upfirdn2d(const float* input, const float* kernel, float* out,
  * centre, all made by the host with the reference's calls.  x, y (B, C <= 4, H, W); sums: 33 * B floats of scratch
  * (per-image sums, then 32 slices of partial sums per image).
  * adjoint 0: y = A x + c (affine != 0) or y = A x (affine == 0); adjoint 1: y = A^T x (the backward; its own backward
- * is the forward with affine == 0: the R1 double-backward of train.py:387-394).  cut_h / cut_w = int(size * 0.2 + 0.5). */
+ * is the forward with affine == 0: the R1 double-backward of train.py:387-394).  cut_h / cut_w = int(size * 0.2 + 0.5).
+ * Policies that leave stages out (diffaug.py:12-17 applies the listed ones): bit 1 of `affine` set = no colour stage
+ * (values pass through untouched), tx = ty = 0 = no translation, cut_h = cut_w = 0 = no cutout. */
 int cips_diffaug(const float* x, float* y, const float* rb, const float* rs, const float* rc, const long long* tx,
                  const long long* ty, const long long* ox, const long long* oy, float* sums, int B, int C, int H, int W,
                  int cut_h, int cut_w, int adjoint, int affine, cips_stream_t stream);

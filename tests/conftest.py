@@ -90,26 +90,6 @@ def max_rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def check_grad_digest(named_params, digest, tol, skip_none=True):
-    worst = 0.0
-    for name, p in named_params:
-        d = digest[name]
-        if d is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
-            continue
-        assert p.grad is not None, f"missing grad for {name}"
-        g = p.grad.detach().reshape(-1).double().cpu()
-        ref = d["sample"].double()
-        got = g[::d["stride"]] if d["stride"] > 1 else g
-        scale = max(d["norm"] / (d["n"] ** 0.5), 1e-30)     # rms of the reference gradient
-        err = float((got - ref).abs().max() / scale)
-        nerr = abs(float(g.norm()) - d["norm"]) / max(d["norm"], 1e-30)
-        worst = max(worst, err * 0 + nerr)
-        assert nerr <= tol, f"{name}: grad norm rel err {nerr:.3e}"
-        assert float((got - ref).norm() / ref.norm().clamp_min(1e-30)) <= tol * 5, f"{name}: grad sample mismatch"
-    return worst
-
-
 class ReplayDraws:
     """Make torch.rand / torch.randint return recorded tensors (in order, moved to the requested device): lets the
     product's DiffAugment consume exactly the draws the reference made when a golden fixture was minted."""

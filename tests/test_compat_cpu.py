@@ -147,3 +147,35 @@ def test_checkpoint_directory_round_trips_with_the_reference_classes(tmp_path):
     load_models(d2, {"discriminator": D}, strict=False)
     with pytest.raises(FileNotFoundError):
         load_models(d2, {"discriminator": D}, strict=True)
+
+
+def test_checkpoint_nested_optimizer_state_and_wrapped_payload(tmp_path):
+    """save_models maps tensors to the CPU through NESTED containers (an optimiser's state -> index -> exp_avg /
+    exp_avg_sq) and the round trip restores the optimiser; Checkpointer also reads a file whose state_dict sits under a
+    wrapper key ({'model': sd}) — round-2 advisor items on checkpoint.py."""
+    from cips3d_amd.checkpoint import save_models, load_models, Checkpointer, _to_cpu
+    torch.manual_seed(3)
+    net = torch.nn.Linear(5, 3)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.0, 0.999))
+    net(torch.randn(4, 5)).sum().backward()
+    opt.step()
+    d = str(tmp_path / "ckpt")
+    save_models(d, {"net": net, "opt": opt, "state_dict": {"step": 7}})
+    raw = torch.load(os.path.join(d, "opt.pth"), weights_only=False)
+    assert set(raw) == {"state", "param_groups"} and all(t.device.type == "cpu" for st in raw["state"].values()
+                                                          for t in st.values() if torch.is_tensor(t))
+    net2 = torch.nn.Linear(5, 3); opt2 = torch.optim.Adam(net2.parameters(), lr=5.0)
+    st = {}
+    load_models(d, {"net": net2, "opt": opt2, "state_dict": st})
+    assert st == {"step": 7} and opt2.param_groups[0]["lr"] == 1e-3
+    for a, b in zip(opt.state_dict()["state"].values(), opt2.state_dict()["state"].values()):
+        assert torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"])
+    # nested containers keep their types; non-tensors pass through
+    x = _to_cpu({"a": [torch.ones(2), (torch.zeros(1), 3)], "b": "s"})
+    assert isinstance(x["a"], list) and isinstance(x["a"][1], tuple) and x["a"][1][1] == 3 and x["b"] == "s"
+    # wrapped single-network file
+    p = str(tmp_path / "wrapped.pth")
+    torch.save({"model": net.state_dict(), "epoch": 3}, p)
+    net3 = torch.nn.Linear(5, 3)
+    Checkpointer(net3).load_state_dict_from_file(p)
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net3.state_dict().values()))

@@ -64,7 +64,44 @@ def _worker(rank, world, port, q):
     red2._check_pending(block=True)
     red._check_pending(block=True)
     frozen_built = [float(p.grad.reshape(-1)[0]) for p in params]
-    q.put((rank, out, nbytes, steady, leftover, frozen_built))
+    # (c) round-2 advisor scenario: gradients reset to None; rank 0's NEW pattern happens to equal the OLD union while
+    #     rank 1's pattern changes too.  Both must enter the re-plan collective (a rank-local "equals the union, skip it"
+    #     would issue a bucket SUM against the peer's presence MAX).
+    red3 = GradAllReducer(params, bucket_mb=0.5)
+    for p in params:
+        p.grad = None
+    params[0].grad = torch.full((7, 5), float(rank + 1))
+    if rank == 1:
+        params[2].grad = torch.full((3,), 5.0)               # union {0, 2}: rank 0 holds {0}, rank 1 {0, 2}
+    red3()
+    for p in params:
+        p.grad = None
+    params[0].grad = torch.full((7, 5), float(rank + 1))
+    params[2].grad = torch.full((3,), float(10 + rank))      # rank 0: {0, 2} == the old union; rank 1: {0, 2, 3}
+    if rank == 1:
+        params[3].grad = torch.full((4,), 7.0)
+    red3()
+    red3._check_pending(block=True)
+    union_case = [None if p.grad is None else float(p.grad.reshape(-1)[0]) for p in params]
+    # (d) overlap=True built while a sub-net is frozen (advisor: register_post_accumulate_grad_hook raises on a tensor that
+    #     does not require grad): construction works, frozen parameters never fire, the rest reduces
+    lin = torch.nn.Linear(4, 3); frozen = torch.nn.Linear(3, 3)
+    for p in frozen.parameters():
+        p.requires_grad_(False)
+    red4 = GradAllReducer(list(lin.parameters()) + list(frozen.parameters()), bucket_mb=0.5, overlap=True)
+    over_frozen = []
+    for step in range(3):
+        for p in list(lin.parameters()) + list(frozen.parameters()):
+            p.grad = None
+        if step == 2:                                        # ... and thawed later: its hooks exist and fire
+            for p in frozen.parameters():
+                p.requires_grad_(True)
+        xin = torch.full((2, 4), float(rank + 1))
+        frozen(lin(xin)).sum().backward()
+        red4()
+        red4._check_pending(block=True)
+        over_frozen.append([None if p.grad is None else p.grad.clone().numpy() for p in list(lin.parameters()) + list(frozen.parameters())])
+    q.put((rank, out, nbytes, steady, leftover, frozen_built, union_case, over_frozen))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,8 +116,8 @@ def _run_world(world):
     res = {}
     try:
         for _ in range(world):
-            r, out, nbytes, steady, leftover, frozen_built = q.get(timeout=180)
-            res[r] = (out, nbytes, steady, leftover, frozen_built)
+            r, out, nbytes, steady, leftover, frozen_built, union_case, over_frozen = q.get(timeout=180)
+            res[r] = (out, nbytes, steady, leftover, frozen_built, union_case, over_frozen)
         for p in procs:
             p.join(timeout=60)
             if p.exitcode != 0:
@@ -108,8 +145,17 @@ def test_allreduce_grads_world2_gloo():
     g1 = [torch.randn(300000, generator=g) for g in gens]
     g2 = torch.randn(3, generator=gens[0])
     for r in range(world):
-        out, nbytes, steady, leftover, frozen_built = res[r]
+        out, nbytes, steady, leftover, frozen_built, union_case, over_frozen = res[r]
         assert leftover == [0.5, 0.5, 0.5, 0.5] and frozen_built == [3.5, 3.5, 3.5, 3.5]
+        assert union_case == [1.5, None, 10.5, 3.5], union_case
+        # overlap reducer with a frozen sub-net: lin's gradients are the two-rank mean, the frozen layer has none until thawed
+        torch.manual_seed(0)      # (values below do not depend on the weights: d/dW of sum(frozen(lin(x))) is checked by rank symmetry)
+        for step in range(3):
+            gw, gb, fw, fb = over_frozen[step]
+            assert gw is not None and gb is not None
+            assert (fw is None) == (step < 2) and (fb is None) == (step < 2)
+            assert all(torch.equal(torch.from_numpy(a), torch.from_numpy(b)) for a, b in
+                       zip([t for t in over_frozen[step] if t is not None], [t for t in res[1 - r][6][step] if t is not None]))
         out = [None if o is None else torch.from_numpy(o) for o in out]
         steady = [[None if o is None else torch.from_numpy(o) for o in st] for st in steady]
         assert torch.allclose(out[0], (g0[0] + g0[1]) / 2, atol=1e-6)

@@ -160,145 +160,65 @@ def test_discriminator_matches_reference_golden(tag, conv_mode, monkeypatch):
     check(out, grad_real, loss, grads, o64.float(), g64.float(), grads64, "free-running (vs fp64 oracle at the product's gates)", False)
 
 
-def test_diffaugment_hip_operator_matches_reference_golden_and_torch():
+def test_diffaugment_hip_operator_matches_reference_golden():
     """The fused DiffAugment operator (cips_diffaug: forward, adjoint, and — the forward without its constant — the
-    adjoint's backward) against (1) the vectors minted from the reference with its recorded draws (output and input
-    gradient) and (2) the op-by-op torch restatement through a double-backward: an R1-style penalty on the input
-    gradient, differentiated w.r.t. a parameter that scales the input."""
+    adjoint's backward) against (1) the vectors minted from the reference with its recorded draws, every policy of the
+    fixture (all three stages, translation + cutout, colour only): output and input gradient; (2) the oracle's op-by-op
+    restatement through a double-backward: an R1-style penalty on the input gradient, differentiated w.r.t. a parameter
+    that scales the input."""
     from conftest import ReplayDraws
     from cips3d_amd import discriminator as dm
     d = torch.device("cuda:0")
+    for case in load_golden("diffaug_cases"):
+        x = case["x"].to(d).requires_grad_(True)
+        with ReplayDraws(case["draws"]):
+            y = dm.DiffAugment(x, policy=case["policy"])
+        assert y.shape == case["y"].shape and max_rel(y, case["y"]) < 1e-6, case["policy"]
+        if "color" not in case["policy"]:
+            assert torch.equal(y.cpu(), case["y"])                       # shift + hole only: values pass through untouched
+        gx, = torch.autograd.grad((y * case["g0"].to(d)).sum(), x)
+        assert max_rel(gx, case["gx"]) < 1e-6, case["policy"]
+
     case = [c for c in load_golden("diffaug_cases") if c["policy"] == "color,translation,cutout"][0]
-    x = case["x"].to(d).requires_grad_(True)
-    with ReplayDraws(case["draws"]):
-        y = dm.DiffAugment(x, policy=case["policy"])
-    assert y.shape == case["y"].shape and max_rel(y, case["y"]) < 1e-6
-    gx, = torch.autograd.grad((y * case["g0"].to(d)).sum(), x)
-    assert max_rel(gx, case["gx"]) < 1e-6
 
     def penalty(fused):
-        old = dm.DIFFAUG_HIP
-        dm.DIFFAUG_HIP = fused
-        try:
-            w = torch.tensor(0.7, device=d, requires_grad=True)
-            xi = case["x"].to(d).requires_grad_(True)
+        dev = d if fused else torch.device("cpu")
+        w = torch.tensor(0.7, device=dev, requires_grad=True)
+        xi = case["x"].to(dev).requires_grad_(True)
+        if fused:
             with ReplayDraws(case["draws"]):
                 yy = dm.DiffAugment(xi * w, policy=case["policy"])
-            out = (yy * yy * case["g0"].to(d)).sum()                 # nonlinear in y: the input gradient depends on w
-            g, = torch.autograd.grad(out, xi, create_graph=True)
-            pen = g.pow(2).sum()
-            gw, = torch.autograd.grad(pen, w)
-            return float(out), g.detach(), float(gw)
-        finally:
-            dm.DIFFAUG_HIP = old
+        else:
+            yy = orc.diff_augment(xi * w, iter(t for _, t in case["draws"]), case["policy"])
+        out = (yy * yy * case["g0"].to(dev)).sum()                       # nonlinear in y: the input gradient depends on w
+        g, = torch.autograd.grad(out, xi, create_graph=True)
+        pen = g.pow(2).sum()
+        gw, = torch.autograd.grad(pen, w)
+        return float(out), g.detach().cpu(), float(gw)
 
     o1, g1, w1 = penalty(True)
     o0, g0, w0 = penalty(False)
     assert abs(o1 - o0) <= 1e-5 * abs(o0) and max_rel(g1, g0) < 1e-5 and abs(w1 - w0) <= 1e-4 * abs(w0), (o1, o0, w1, w0)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (3, 3, 64, 32)])
-def test_fade_in_ops_match_torch(shape):
-    """the 2x2 mean standing in for F.interpolate(scale_factor=0.5, mode='bilinear') (discriminator.py:525), its
-    transpose, and the blend alpha * cur + (1 - alpha) * down — values and first / second derivatives"""
-    from cips3d_amd import discriminator as dm
-    d = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(shape[2])
-    x = torch.randn(*shape, generator=g)
-    ref = torch.nn.functional.interpolate(x, scale_factor=0.5, mode="bilinear")
-    xd = x.to(d).requires_grad_(True)
-    y = dm._AvgPool2Function.apply(xd, False)
-    assert max_rel(y, ref) < 1e-6           # (ATen's CPU kernel associates the four products differently: 1 ulp)
-    up = torch.randn(ref.shape, generator=g)
-    xr = x.clone().requires_grad_(True)
-    yr = torch.nn.functional.interpolate(xr, scale_factor=0.5, mode="bilinear")
-    gr, = torch.autograd.grad((yr * yr * up).sum(), xr, create_graph=True)
-    gr.pow(2).sum().backward()
-    gd, = torch.autograd.grad((y * y * up.to(d)).sum(), xd, create_graph=True)
-    gd.pow(2).sum().backward()
-    assert max_rel(gd, gr) < 1e-6 and max_rel(xd.grad, xr.grad) < 1e-6
-    a = torch.randn(*ref.shape, generator=g); b = torch.randn(*ref.shape, generator=g)
-    ad, bd = a.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
-    out = dm._BlendFunction.apply(ad, bd, 0.3, 0.7)
-    assert max_rel(out, 0.3 * a + 0.7 * b) < 1e-6
-    ga, gb = torch.autograd.grad((out * up.to(d)).sum(), (ad, bd))
-    assert max_rel(ga, 0.3 * up) < 1e-6 and max_rel(gb, 0.7 * up) < 1e-6
-
-
-@pytest.mark.parametrize("shape", [(2, 3, 16, 64, 64), (4, 3, 64, 256, 256), (3, 4, 24, 8, 12), (1, 1, 8, 4, 4)])
-def test_rgb_conv_weight_gradient_streaming_kernel(shape):
-    """dw[o][c] = sum_{b,p} dy[b][o][p] x[b][c][p] of the RGB input convs (cips_conv1x1_smallk_bwd_weight: one workgroup
-    per output channel and pixel slice, partial rows summed in slice order) against fp64, and through conv2d's autograd
-    including the R1-style double backward"""
-    from cips3d_amd import ops
-    from cips3d_amd.discriminator import conv2d
-    B, C, O, H, W = shape
-    d = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(5)
-    dy = torch.randn(B, O, H, W, generator=g).to(d)
-    x = torch.randn(B, C, H, W, generator=g).to(d)
-    dw = ops.conv1x1_smallk_bwd_weight(dy, x)
-    ref = torch.einsum("bohw,bchw->oc", dy.double(), x.double())
-    assert dw.shape == (O, C) and rel_err(dw, ref) < 2e-6
-    assert torch.equal(dw, ops.conv1x1_smallk_bwd_weight(dy, x))          # fixed summation order: run-to-run identical
-    if H * W <= 4096:
-        xr = x.double().cpu().requires_grad_(True)
-        wr = (torch.randn(O, C, 1, 1, generator=g, dtype=torch.float64) / C ** 0.5).requires_grad_(True)
-        y = torch.nn.functional.conv2d(xr, wr)
-        gx, = torch.autograd.grad((y * dy.double().cpu()).sum(), xr, create_graph=True)
-        ((gx ** 2).sum() + (y ** 2).sum()).backward()
-        xd = x.clone().requires_grad_(True); wd = wr.detach().float().to(d).requires_grad_(True)
-        yd = conv2d(xd, wd)
-        gxd, = torch.autograd.grad((yd * dy).sum(), xd, create_graph=True)
-        ((gxd ** 2).sum() + (yd ** 2).sum()).backward()
-        assert rel_err(yd, y) < 1e-5 and rel_err(gxd, gx) < 1e-5
-        assert rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(xd.grad, xr.grad) < 1e-5
-
-
-@pytest.mark.parametrize("cfg", [(2, 64, 96, 32), (2, 32, 64, 64), (3, 32, 32, 8)])
-def test_skip_branch_blur_down2_equals_blur_then_stride2(cfg, monkeypatch):
-    """ResBlock skip branch (discriminator.py:239-241): Blur + 1x1 stride-2 conv run as upfirdn2d(down = 2) + stride-1 conv
-    must give the unfused composition's output bit for bit in the blur and to GEMM rounding after the conv, and the same
-    input / weight gradients including the R1 double backward"""
-    from cips3d_amd import discriminator as dm
-    B, C, O, H = cfg
-    d = torch.device("cuda:0")
-    torch.manual_seed(3)
-    layer = dm.ConvLayer(C, O, 1, downsample=True, activate=False, bias=False).to(d)
-    x0 = torch.randn(B, C, H, H, device=d)
-    up = torch.randn(B, O, H // 2, H // 2, device=d)
-    res = {}
-    for fused in (True, False):
-        monkeypatch.setattr(dm, "_SKIP_DOWN2", fused)
-        layer.zero_grad()
-        x = x0.clone().requires_grad_(True)
-        y = layer(x)
-        gx, = torch.autograd.grad((y * up).sum(), x, create_graph=True)
-        ((gx ** 2).sum() + (y ** 2).sum()).backward()
-        res[fused] = (y.detach(), gx.detach(), x.grad.clone(), layer.equal_conv.weight.grad.clone())
-    blur = layer.down_blur
-    assert torch.equal(dm.upfirdn2d(x0, blur.kernel, down=2, pad=blur.pad), dm.upfirdn2d(x0, blur.kernel, pad=blur.pad)[:, :, ::2, ::2])
-    for a, b, what in zip(res[True], res[False], ("y", "dx", "x.grad", "w.grad")):
-        assert a.shape == b.shape and rel_err(a, b) < 2e-5, (what, float(rel_err(a, b)))
-
-
-def test_diffaug_sums_at_256_match_torch():
+def test_diffaug_sums_at_256_match_oracle():
     """the per-image sums of cips_diffaug are reduced in 32 slices per image: brightness / contrast means at 256 x 256
-    against the op-by-op torch restatement with the same device draws"""
+    against the oracle's op-by-op restatement (CPU) with the same draws"""
+    from conftest import ReplayDraws
     from cips3d_amd import discriminator as dm
     d = torch.device("cuda:0")
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(3, 3, 256, 256, generator=g).to(d)
-    outs = []
-    for fused in (True, False):
-        old = dm.DIFFAUG_HIP
-        dm.DIFFAUG_HIP = fused
-        try:
-            torch.manual_seed(11)
-            outs.append(dm.DiffAugment(x, policy="color,translation,cutout"))
-        finally:
-            dm.DIFFAUG_HIP = old
-    assert max_rel(outs[0], outs[1]) < 2e-6
+    b, h, w = 3, 256, 256
+    x = torch.randn(b, 3, h, w, generator=g)
+    sx, sy, ch, cw = int(h * 0.125 + 0.5), int(w * 0.125 + 0.5), int(h * 0.2 + 0.5), int(w * 0.2 + 0.5)
+    draws = [("rand", torch.rand(b, 1, 1, 1, generator=g)) for _ in range(3)]
+    draws += [("randint", torch.randint(-sx, sx + 1, [b, 1, 1], generator=g)), ("randint", torch.randint(-sy, sy + 1, [b, 1, 1], generator=g)),
+              ("randint", torch.randint(0, h + (1 - ch % 2), [b, 1, 1], generator=g)),
+              ("randint", torch.randint(0, w + (1 - cw % 2), [b, 1, 1], generator=g))]
+    with ReplayDraws(draws):
+        y = dm.DiffAugment(x.to(d), policy="color,translation,cutout")
+    ref = orc.diff_augment(x, iter(t for _, t in draws), "color,translation,cutout")
+    assert max_rel(y, ref) < 2e-6
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 16, 16), (3, 5, 65, 65), (1, 4, 256, 256), (2, 3, 7, 5), (4, 512, 4, 4)])

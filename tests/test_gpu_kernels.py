@@ -430,7 +430,8 @@ def _unpack_bits(u, N):
     return ((u.to(torch.int32).unsqueeze(-1) >> torch.arange(8)) & 1).reshape(*u.shape[:-1], N).bool()
 
 
-@pytest.mark.parametrize("tile_mode", [2, 0])       # 2: 256x256-tile kernel wherever supported; 0: 256x128 kernel only
+@pytest.mark.parametrize("tile_mode", [2, 3, 0])    # 2: 256x256-tile kernels wherever supported (v3 schedule for interior shapes,
+                                                    # else the wide kernel); 3: the wide kernel only; 0: 256x128 kernel only
 @pytest.mark.parametrize("M,N,K,batch", [(256, 256, 64, 1), (520, 264, 96, 2), (4096, 512, 512, 20), (1024, 768, 32, 3),
                                          (300, 96, 64, 2)])
 @pytest.mark.parametrize("flavour", ["plain", "res", "mask", "add"])

@@ -200,3 +200,140 @@ def test_discriminator_real_sizes_vs_oracle(size, b, alpha):
           f"loss {float(ld):.6f} vs {ref_loss:.6f}")
     assert e < TOL and eg < GRAD_TOL and abs(float(ld) - ref_loss) < TOL * max(1.0, abs(ref_loss))
     _grad_compare(list(Dd.named_parameters()), ref_grads, f"D {size}x{size} gradients (oracle's gates pinned)")
+
+
+def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed):
+    """forward + every parameter gradient of `(imgs * G0).sum()` against the oracle, the oracle's LeakyReLU gates pinned"""
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(seed)
+    zs, rand = _draws(g, b, img, S, hier)
+    nimg = 2 * b if aux else b
+    G0 = torch.randn(nimg, 3, img, img, generator=g) / (nimg * 3 * img * img)
+    Gc = seeded_generator(1234)
+    tape = orc.GateTape()
+    with orc.gate_tape(tape):
+        ref = orc.generator_forward(dict(Gc.named_parameters()), zs, rand, img, KW["fov"], KW["ray_start"], KW["ray_end"],
+                                    S, KW["h_stddev"], KW["v_stddev"], hier, nerf_noise=nerf_noise, return_aux_img=aux)
+    (ref["imgs"] * G0).sum().backward()
+    ref_grads = {k: p.grad for k, p in Gc.named_parameters() if p.grad is not None}
+    ref_imgs = ref["imgs"].detach()
+    pins = [pack_bitplane(t) for t in tape.rec]
+    del ref, tape
+    Gd = seeded_generator(1234, device=d)
+    imgs = _product_forward(Gd, zs, rand, d, img, S, hier, aux=aux, pin=pins, nerf_noise=nerf_noise)
+    e = max_rel(imgs, ref_imgs)
+    print(f"{what}: imgs max_rel {e:.3e}")
+    assert imgs.shape == (nimg, 3, img, img) and e < TOL
+    (imgs * G0.to(d)).sum().backward()
+    torch.cuda.synchronize()
+    _grad_compare(list(Gd.named_parameters()), ref_grads, f"{what} gradients (oracle's gates pinned)")
+    return len(ref_grads)
+
+
+def test_c2_headline_geometry_flat_march_forward_backward_vs_oracle():
+    """BASELINE configs[1] at the geometry bench.py times: r64, S = 24 FLAT sampling (the fused ray-march kernel and its
+    backward: cips_march_fwd_x3 -> cips_composite_bwd + cips_siren_bwd_x3_rays), aux image on (ffhq_exp.yaml:169), batch 4:
+    forward and all 130 parameter gradients (generator.py:1659-1762)."""
+    n = _g_forward_backward_vs_oracle("C2 geometry b=4 r64 S=24 flat, aux", 4, 64, 24, False, True, 0.2, 64)
+    assert n == 130, n
+
+
+def test_c3_r128_pair_forward_backward_vs_oracle():
+    """C3 geometry with gradients: r128, S = 12 + 12, aux image, an image pair (the weight-gradient GEMMs contract over
+    16 384 pixels per image)."""
+    _g_forward_backward_vs_oracle("C3 geometry b=2 r128 S=12+12, aux", 2, 128, 12, True, True, 0.1, 1283)
+
+
+def _aug_draws(g, nb, size):
+    """the seven DiffAugment draws of one Discriminator_MultiScale.forward on nb images (diffaug.py:32-67), as the
+    (kind, tensor) records ReplayDraws replays and orc.discriminator_forward consumes"""
+    sx = int(size * 0.125 + 0.5)
+    c = int(size * 0.2 + 0.5)
+    out = [("rand", torch.rand(nb, 1, 1, 1, generator=g)) for _ in range(3)]
+    out += [("randint", torch.randint(-sx, sx + 1, [nb, 1, 1], generator=g)) for _ in range(2)]
+    out += [("randint", torch.randint(0, size + (1 - c % 2), [nb, 1, 1], generator=g)) for _ in range(2)]
+    return out
+
+
+def test_c5_finetune_step_r256_aux_two_discriminators_vs_oracle():
+    """BASELINE configs[4] (finetune_afhq.yaml:38,70,89 with train_aux_img): r256, num_steps 12 + hierarchical (E = 24),
+    GeneratorNerfINR_freeze_NeRF, aux image, Discriminator_MultiScale_Aux with diffaug=True, the aux discriminator and a
+    fade-in alpha < 1 — the G step and the D step of train.py:334-466 on one image:
+      G step: imgs = G(z) (main + aux image), g_loss = softplus(-D(DiffAugment(imgs))).mean(): images, logits and every
+              generator gradient of the stage (through both discriminators, the augmentation and the fade-in);
+      D step: r_preds on real images (requires_grad), R1 penalty through the double-backward graph, g_preds on the
+              generated images: logits, R1 input gradient, loss and every parameter gradient of both discriminators."""
+    from conftest import ReplayDraws
+    from cips3d_amd import ops, discriminator as dmod
+    from cips3d_amd.discriminator import Discriminator_MultiScale_Aux
+    d = torch.device("cuda:0")
+    b, img, S, alpha = 1, 256, 12, 0.8
+    g = torch.Generator().manual_seed(555)
+    zs, rand = _draws(g, b, img, S, True)
+    real = torch.rand(2 * b, 3, img, img, generator=g) * 2 - 1          # train.py:376-377: real_imgs twice when aux_reg
+    aug_g, aug_r, aug_f = (_aug_draws(g, b, img) + _aug_draws(g, b, img) for _ in range(3))      # main + aux disc, per D forward
+    torch.manual_seed(4321)
+    D = Discriminator_MultiScale_Aux(**dict(D_CFG, diffaug=True))
+    sdD = dict(D.state_dict()); sdD.update(dict(D.named_parameters()))
+    Gc = seeded_generator(1234, freeze=True)
+    F = torch.nn.functional
+    # ---------------- oracle: G step
+    tape_g, tape_d = orc.GateTape(), orc.GateTape()
+    with orc.gate_tape(tape_g):
+        ref = orc.generator_forward(dict(Gc.named_parameters()), zs, rand, img, KW["fov"], KW["ray_start"], KW["ray_end"], S,
+                                    KW["h_stddev"], KW["v_stddev"], True, nerf_noise=0.0, return_aux_img=True, freeze_nerf=True)
+    with orc.gate_tape(tape_d):
+        gp = orc.discriminator_forward(sdD, ref["imgs"], alpha=alpha, use_aux_disc=True, draws=[t for _, t in aug_g])
+    F.softplus(-gp).mean().backward()
+    ref_g_grads = {k: p.grad for k, p in Gc.named_parameters() if p.grad is not None}
+    assert not any(k.startswith(("siren", "mapping_network_nerf", "aux_to_rbg")) for k in ref_g_grads)
+    ref_imgs, ref_gp = ref["imgs"].detach(), gp.detach()
+    pins_g, pins_dg = [pack_bitplane(t) for t in tape_g.rec], tape_d.rec
+    D.zero_grad(set_to_none=True)
+    del ref, gp, tape_g
+    # ---------------- oracle: D step (fake images = the oracle's, so that the D comparison stands on its own)
+    x = real.clone().requires_grad_(True)
+    tape_dd = orc.GateTape()
+    with orc.gate_tape(tape_dd):
+        rp = orc.discriminator_forward(sdD, x, alpha=alpha, use_aux_disc=True, draws=[t for _, t in aug_r])
+        gr, = torch.autograd.grad(rp.sum(), x, create_graph=True)
+        fp = orc.discriminator_forward(sdD, ref_imgs, alpha=alpha, use_aux_disc=True, draws=[t for _, t in aug_f])
+    pen = 0.5 * 10. * gr.flatten(1).square().sum(1, keepdim=True) * 1 + 0. * rp           # train.py:397-398
+    d_loss = (F.softplus(fp) + F.softplus(-rp) + pen).mean()
+    d_loss.backward()
+    ref_d_grads = {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None}
+    ref_rp, ref_gr, ref_fp, ref_dl = rp.detach(), gr.detach(), fp.detach(), float(d_loss)
+    D.zero_grad(set_to_none=True)
+    del rp, gr, fp, pen, d_loss
+    # ---------------- product: G step
+    Gd = seeded_generator(1234, freeze=True, device=d)
+    Dd = D.to(d)
+    for p in Dd.parameters():
+        p.requires_grad_(False)                               # train.py:441-442
+    imgs = _product_forward(Gd, zs, rand, d, img, S, True, aux=True, pin=pins_g)
+    with dmod.gate_debug(pin=pins_dg), ReplayDraws(aug_g):
+        gpd = Dd(imgs, alpha=alpha, use_aux_disc=True)[0]
+    F.softplus(-gpd).mean().backward()
+    torch.cuda.synchronize()
+    e_img, e_gp = max_rel(imgs, ref_imgs), max_rel(gpd, ref_gp)
+    print(f"C5 G step b=1 r256 S=12+12 frozen NeRF + aux image + aux D + DiffAugment, alpha={alpha}: imgs max_rel {e_img:.3e}, "
+          f"logits max_rel {e_gp:.3e}")
+    assert imgs.shape == (2 * b, 3, img, img) and e_img < TOL and e_gp < TOL
+    _grad_compare(list(Gd.named_parameters()), ref_g_grads, "C5 G-step generator gradients (oracle's gates pinned)")
+    del imgs, gpd
+    # ---------------- product: D step
+    for p in Dd.parameters():
+        p.requires_grad_(True)
+    xd = real.to(d).requires_grad_(True)
+    with dmod.gate_debug(pin=tape_dd.rec), ReplayDraws(aug_r + aug_f):
+        rpd = Dd(xd, alpha=alpha, use_aux_disc=True)[0]
+        grd, = torch.autograd.grad(rpd.sum(), xd, create_graph=True)
+        fpd = Dd(ref_imgs.to(d), alpha=alpha, use_aux_disc=True)[0]
+    pend = 0.5 * 10. * grd.flatten(1).square().sum(1, keepdim=True) * 1 + 0. * rpd
+    dl = (F.softplus(fpd) + F.softplus(-rpd) + pend).mean()
+    dl.backward()
+    torch.cuda.synchronize()
+    e_r, e_g, e_f = max_rel(rpd, ref_rp), max_rel(grd, ref_gr), max_rel(fpd, ref_fp)
+    print(f"C5 D step: real logits {e_r:.3e}, R1 input gradient {e_g:.3e}, fake logits {e_f:.3e}, d_loss {float(dl):.6f} vs {ref_dl:.6f}")
+    assert e_r < TOL and e_f < TOL and e_g < GRAD_TOL and abs(float(dl) - ref_dl) < TOL * max(1.0, abs(ref_dl))
+    _grad_compare(list(Dd.named_parameters()), ref_d_grads, "C5 D-step gradients, main + aux discriminator (oracle's gates pinned)")
