@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
+    ap.add_argument("--no-full-step", action="store_true",
+                    help="skip the secondary measurement: one full GAN step (D step with R1 + G step + fused clip/Adam/EMA)")
     ap.add_argument("--inr-mode", default=None, choices=["bf16x3", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph of the step")
     ap.add_argument("--overlap-reduce", action="store_true",
@@ -122,7 +124,7 @@ def gemm_roofline(dev, b, n, mode):
         tot_t += count * t
         tot_f += count * flops
     ach = tot_f / tot_t / 1e12
-    r = {"bound": "mfma", "kernel": "gemm_bf16x3_wide_kernel family (modfc 512x512 layer GEMMs of the CIPS head, 256x256 tiles): "
+    r = {"bound": "mfma", "kernel": "gemm_bf16x3_v3_kernel family (modfc 512x512 layer GEMMs of the CIPS head, 256x256 tiles): "
                                     "launch-count-weighted over the four epilogue flavours of the step",
          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
          "traffic": None, "launch_us": round(tot_t / sum(f[1] for f in flav) * 1e6, 1), "flops_per_launch": flops,
@@ -132,7 +134,7 @@ def gemm_roofline(dev, b, n, mode):
                  "algorithmic bytes / time / 8 TB/s"}
     # HBM bytes per launch of the forward flavour from the PMC counters, collected in their own rocprofv3 --pmc passes
     # (scripts/pmc_roofline.sh -> profiles/r2_roofline_pmc.json, r1 as fallback); null if absent
-    for f in ("r2_roofline_pmc.json", "r1_roofline_pmc.json"):
+    for f in ("r3_roofline_pmc.json", "r2_roofline_pmc.json", "r1_roofline_pmc.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", f)))
             if b == 32 and n == 4096:
@@ -175,6 +177,78 @@ def cpu_baseline(img_size, S, hier):
     return {"value": round(b / dt, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle G fwd+bwd, {img_size}x{img_size}, E={E} evals/ray, b={b}, median of {reps} timed iters "
                       f"after 1 warm-up (min {b / ts[-1]:.3f}, max {b / ts[0]:.3f} img/s)"}
+
+
+def full_gan_step(dev, b, img, S, steps=4, warmup=2, freeze=False, diffaug=False, aux=True, torch_optim=False):
+    """Secondary measurement: one full GAN training step as exp/cips3d/scripts/train.py:334-491 drives
+    it — D step (G under no_grad with the aux image, R1 double-backward on the reals, clip, Adam), G step through the
+    frozen D (clip, Adam, EMA) — on synthetic "real" images, with the fused step tail (FusedClipAdamEMA).  S coarse
+    samples + hierarchical resampling (the training configuration).  Returns ms per phase and images / s."""
+    import copy
+    import torch.nn.functional as F
+    from cips3d_amd.generator import GeneratorNerfINR, GeneratorNerfINR_freeze_NeRF
+    from cips3d_amd.discriminator import Discriminator_MultiScale_Aux
+    from cips3d_amd.optim import FusedClipAdamEMA
+    torch.manual_seed(1234)
+    G = (GeneratorNerfINR_freeze_NeRF if freeze else GeneratorNerfINR)(**G_CFG, device=dev).to(dev); G.device = dev
+    G_ema = copy.deepcopy(G)
+    D = Discriminator_MultiScale_Aux(diffaug=diffaug, max_size=1024, channel_multiplier=2, first_downsample=False,
+                                     stddev_group=0).to(dev)
+    kw = dict(G_KW); kw.update(num_steps=S, hierarchical_sample=True)
+    if torch_optim:
+        oG = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.0, 0.999)); oD = torch.optim.Adam(D.parameters(), lr=2e-3, betas=(0.0, 0.999))
+    else:
+        oG = FusedClipAdamEMA(G.parameters(), lr=2e-4, betas=(0.0, 0.999), max_norm=10.0, ema_params=G_ema.parameters())
+        oD = FusedClipAdamEMA(D.parameters(), lr=2e-3, betas=(0.0, 0.999), max_norm=10.0)
+    real = torch.rand(b, 3, img, img, device=dev) * 2 - 1
+
+    def d_step():
+        for p in G.parameters(): p.requires_grad_(False)
+        for p in D.parameters(): p.requires_grad_(True)
+        with torch.no_grad():
+            gen, _ = G(G.get_zs(b), img_size=img, nerf_noise=0.5, return_aux_img=aux, forward_points=None, grad_points=None, **kw)
+        real2 = (torch.cat([real, real]) if aux else real.clone()).requires_grad_(True)
+        r_preds, _, _ = D(real2, alpha=1.0, use_aux_disc=aux)
+        grad_real, = torch.autograd.grad(outputs=r_preds.sum(), inputs=real2, create_graph=True)       # d_reg_every: 1
+        pen = 0.5 * 10.0 * grad_real.flatten(1).square().sum(1, keepdim=True)
+        g_preds, _, _ = D(gen, alpha=1.0, use_aux_disc=aux)
+        loss = (F.softplus(g_preds) + F.softplus(-r_preds) + pen).mean()
+        for p in D.parameters(): p.grad = None
+        loss.backward()
+        if torch_optim:
+            torch.nn.utils.clip_grad_norm_(D.parameters(), 10.0)
+        oD.step()
+
+    def g_step():
+        for p in G.parameters(): p.requires_grad_(True)
+        for p in D.parameters(): p.requires_grad_(False)
+        imgs, _ = G(G.get_zs(b), img_size=img, nerf_noise=0.5, return_aux_img=aux, grad_points=None, forward_points=None, **kw)
+        preds, _, _ = D(imgs, alpha=1.0, use_aux_disc=aux)
+        loss = F.softplus(-preds).mean()
+        for p in G.parameters(): p.grad = None
+        loss.backward()
+        if torch_optim:
+            torch.nn.utils.clip_grad_norm_(G.parameters(), 10.0); oG.step()
+            with torch.no_grad():
+                for e, p in zip(G_ema.parameters(), G.parameters()): e.copy_(e * 0.999 + p * 0.001)
+        else:
+            oG.step()
+
+    for _ in range(warmup):
+        d_step(); g_step()
+    torch.cuda.synchronize()
+    tD = tG = 0.0
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for _ in range(steps):
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record(); d_step(); e1.record(); g_step(); e2.record()
+        torch.cuda.synchronize()
+        tD += e0.elapsed_time(e1); tG += e1.elapsed_time(e2)
+    return {"metric": "full GAN step (D step with R1 + G step + clip/Adam/EMA), synthetic reals, eager launches",
+            "img_size": img, "batch": b, "num_steps": S, "hierarchical": True, "aux": aux, "freeze_nerf": freeze,
+            "diffaug": diffaug, "optimizer": "torch" if torch_optim else "fused clip+Adam+EMA", "steps": steps,
+            "ms_D_step": round(tD / steps, 2), "ms_G_step": round(tG / steps, 2), "ms_step": round((tD + tG) / steps, 2),
+            "img_per_s": round(b * steps / ((tD + tG) * 1e-3), 1)}
 
 
 def _free_port():
@@ -271,13 +345,19 @@ def main():
             torch.cuda.synchronize()
     use_graph = [graph is not None]
 
+    ar_events, ar_bytes = [], [0]
+
     def step():
         if use_graph[0]:
             graph.replay()
         else:
             fwd_bwd()
         if world > 1:
-            reduce_grads()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ar_bytes[0] = reduce_grads() or ar_bytes[0]
+            e1.record()
+            ar_events.append((e0, e1))
 
     def fence():
         torch.cuda.synchronize()
@@ -285,22 +365,34 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    def timed(nsteps, nwarm):
+    per_step = {}
+
+    def timed(nsteps, nwarm, record=False):
+        """wall clock of exactly nsteps steps between fences (the contract's number); with `record`, an event is
+        recorded before every step and after the last, which costs nothing and gives the per-step distribution"""
         for _ in range(nwarm):
             step()
         fence()
+        evs = []
         t0 = time.perf_counter()
         for _ in range(nsteps):
+            if record:
+                e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
             step()
+        if record:
+            e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
         fence()
         dt = time.perf_counter() - t0
+        if record and len(evs) > 1:
+            ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1))
+            per_step.update(median=ts[len(ts) // 2], min=ts[0], max=ts[-1])
         if world > 1:
             t = torch.tensor([dt], device=dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
-    dt = timed(a.steps, a.warmup)
+    dt = timed(a.steps, a.warmup, record=True)
     ms = dt / a.steps * 1e3
     value = world * b * a.steps / dt
     exact = None
@@ -320,7 +412,9 @@ def main():
     E = 2 * S if a.hier else S
     line = {
         "metric": "rendered imgs/sec (G fwd+bwd)", "value": round(value, 2), "unit": "img/s", "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+        "ms_per_step_median": round(per_step.get("median", ms), 3), "ms_per_step_min": round(per_step.get("min", ms), 3),
+        "ms_per_step_max": round(per_step.get("max", ms), 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if mode == "f32" else "f32 (dense layers as 3-pass split-bf16 MFMA with fp32 accumulate, ~1e-5 rel.; everything else fp32)",
         "data": "synthetic",
@@ -335,6 +429,21 @@ def main():
     }
     if exact:
         line["exact_f32"] = exact
+    if world > 1 and ar_events:
+        # gradient exchange as the stream sees it (events around the all-reduce of every timed step; with the overlapped
+        # form this is what is left exposed after the backward): median ms, bytes per rank, ring bus bandwidth
+        tail = ar_events[-a.steps:]
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in tail)
+        med = ts[len(ts) // 2]
+        line["allreduce"] = {"ms_median": round(med, 4), "ms_min": round(ts[0], 4), "ms_max": round(ts[-1], 4),
+                             "bytes_per_rank": int(ar_bytes[0]),
+                             "bus_GBps": round(ar_bytes[0] * 2 * (world - 1) / world / (med * 1e-3) / 1e9, 2) if med > 0 else None,
+                             "frac_of_step": round(med / ms, 4)}
+    if rank == 0 and world == 1 and not a.no_full_step:
+        try:
+            line["full_step"] = full_gan_step(dev, b, img, 12, steps=4, warmup=2)
+        except Exception as e:                      # noqa: BLE001 — the secondary number must never cost the headline line
+            line["full_step"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if not a.no_roofline:
             line["roofline"] = gemm_roofline(dev, b, img * img, mode)

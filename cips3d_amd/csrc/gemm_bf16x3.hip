@@ -761,6 +761,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float* __r
 
 extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream);   // gemm_bf16x3_wide.hip
 extern "C" int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t stream);     // gemm_bf16x3_v3.hip
+extern "C" int cips_gemm_bf16x3_v3_accepts(const cips_gemm_x3_desc* d);
 static int g_wide = -1;   // -1: from env CIPS_X3_WIDE (default 1); 0 never; 1 for large problems; 2 whenever supported;
                           // 3: like 2 but never the v3 kernel (tests of the wide kernel proper)
 static int g_v3 = -1;     // env CIPS_X3_V3 (default 1): 256x256 tiles of interior shapes on gemm_bf16x3_v3.hip
@@ -781,6 +782,9 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
       const int rc3 = cips_gemm_bf16x3_v3(d, stream);
       if (rc3 != (int)hipErrorNotSupported) return rc3;
     }
+  }
+  if (d->torgb_w) return (int)hipErrorNotSupported;       // only the v3 kernel folds ToRGB in: never drop it silently
+  if (g_wide >= 2 || (g_wide == 1 && big)) {
     const int rc = cips_gemm_bf16x3_wide(d, stream);
     if (rc != (int)hipErrorNotSupported) return rc;
   }
@@ -829,6 +833,15 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   return CIPS_CHECK_LAUNCH();
 }
 
+
+extern "C" int cips_gemm_bf16x3_fuses_torgb(const cips_gemm_x3_desc* d) {
+  if (!d || !d->torgb_w) return 0;
+  if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }
+  if (g_v3 < 0) { const char* e = getenv("CIPS_X3_V3"); g_v3 = e ? atoi(e) : 1; }
+  const bool big = d->N >= 256 && d->M >= 256 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 256;
+  if (!(g_v3 && g_wide != 3 && (g_wide >= 2 || (g_wide == 1 && big)))) return 0;
+  return cips_gemm_bf16x3_v3_accepts(d) == 0 ? 1 : 0;
+}
 
 extern "C" int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t stream) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || !d->C) return (int)hipErrorInvalidValue;

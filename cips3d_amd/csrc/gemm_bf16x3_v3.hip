@@ -50,7 +50,6 @@ struct VArgs {
   // window (L2-resident); bit 2: non-temporal stores; bit 3: skip the epilogue
   int dbg;
   int skew, phases;     // workgroups of XCD x start (x % phases) * skew shader cycles late
-  int touch;            // TOUCH kernels: how many k-tiles ahead of the computing k-tile the A lines are requested
 };
 
 template <typename F, int... I>
@@ -74,11 +73,10 @@ __device__ __forceinline__ constexpr int mfma_b(int m) { return (m >> 3) == 1 ? 
 // FAST: the epilogue shapes of the training step, decided at compile time — planes out, no fp32 C; forward flavours
 // (no gate input) apply the LeakyReLU and write the gate bit plane, backward flavours (gate input) do neither; only
 // C_unmasked (the skip gradient of the add flavour) stays a run-time switch.  !FAST: every switch of the descriptor.
-// TOUCH: every k-tile each wave also requests one dword of 32 rows of the A planes several k-tiles AHEAD of the LDS-DMA
-// (a 128-byte line holds a row's slice of two k-tiles), into its idle epilogue scratch: the activation operand is read
-// from HBM / the Infinity Cache exactly once per row block, the stage ring holds one k-tile of prefetch, so without the
-// touch every k-tile's DMA pays the full miss latency; with it the DMA finds the lines in L2.
-template <bool HAS_ADD, bool HAS_MASK, bool HAS_RES, bool FAST, bool DBG = false, bool TOUCH = false>
+// RGBF: ToRGB forward folded in (descriptor fields torgb_w / torgb_part): per row and 128-column block the three partial
+// dot products of the final values with the ToRGB weights, accumulated over the wave's four column sub-blocks in
+// registers, reduced over the four lanes of a row with two DPP adds and stored as one float4 per row.
+template <bool HAS_ADD, bool HAS_MASK, bool HAS_RES, bool FAST, bool DBG = false, bool RGBF = false>
 __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cips_gemm_x3_desc& d = g.d;
@@ -117,25 +115,17 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
       sr.offB[p] = (unsigned)(row * d.ldb + kcsw * 8) * 2u;
     }
   };
-  // cache policy experiments (TOUCH kernels only, g.touch bits 8..11): bit 8: A pieces non-temporal, bit 9: B pieces
-  // non-temporal, bit 10: A pieces sc1, bit 11: B pieces sc1
-  auto dma = [&](const u16* plane_k, unsigned off, unsigned lds_addr, int pol = 0) {
-    if (TOUCH && pol == 1)
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(off), "s"(plane_k), "s"(lds_addr) : "memory");
-    else if (TOUCH && pol == 2)
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" :: "v"(off), "s"(plane_k), "s"(lds_addr) : "memory");
-    else
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(plane_k), "s"(lds_addr) : "memory");
+  auto dma = [&](const u16* plane_k, unsigned off, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(plane_k), "s"(lds_addr) : "memory");
   };
-  const int polA = TOUCH ? ((g.touch >> 8) & 1) + 2 * ((g.touch >> 10) & 1) : 0, polB = TOUCH ? ((g.touch >> 9) & 1) + 2 * ((g.touch >> 11) & 1) : 0;
   // piece pc = 0..7 of the k-tile starting at contraction index k0, into the stage at LDS byte offset `st`
   auto dma_piece = [&](const Src& sr, int pc, int k0, unsigned st) {
     const int pp = pc >> 2, which = pc & 3;
     const unsigned la = sbase + st + (unsigned)((uw + 8 * pp) * 16 * ROWB);
-    if (which == 0) dma(sr.Ahi + k0, sr.offA[pp], la + OFF_AHI, polA);
-    else if (which == 1) dma(sr.Alo + k0, sr.offA[pp], la + OFF_ALO, polA);
-    else if (which == 2) dma(sr.Bhi + k0, sr.offB[pp], la + OFF_BHI, polB);
-    else dma(sr.Blo + k0, sr.offB[pp], la + OFF_BLO, polB);
+    if (which == 0) dma(sr.Ahi + k0, sr.offA[pp], la + OFF_AHI);
+    else if (which == 1) dma(sr.Alo + k0, sr.offA[pp], la + OFF_ALO);
+    else if (which == 2) dma(sr.Bhi + k0, sr.offB[pp], la + OFF_BHI);
+    else dma(sr.Blo + k0, sr.offB[pp], la + OFF_BLO);
   };
 
   if (g.skew > 0) {
@@ -184,16 +174,6 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
     const unsigned fb0 = sbase + (wn * 128 + l31) * ROWB + ((hf ^ csw) << 4), fb1 = sbase + (wn * 128 + l31) * ROWB + (((2 + hf) ^ csw) << 4);
 
     bf16x8 F0[12], F1[12];
-    // TOUCH: lane -> row uw*32 + (lane & 31) of the A tile (both lane halves ask for the same line); the next tile's A
-    // planes for the touches that run past this tile's contraction
-    const unsigned offT = (unsigned)((uw * 32 + (lane & 31)) * d.lda) * 2u;
-    const u16 *nAhi = src.Ahi, *nAlo = src.Alo;
-    if (TOUCH && have_next) {
-      int tm2, tn2, bz2;
-      decode(tnext, tm2, tn2, bz2);
-      nAhi = (const u16*)d.A_hi + (long long)bz2 * d.strideA + (long long)tm2 * BM * d.lda;
-      nAlo = (const u16*)d.A_lo + (long long)bz2 * d.strideA + (long long)tm2 * BM * d.lda;
-    }
 
     // ---- epilogue plumbing declared here: the first inputs are requested inside the last k-tile
     const bool win = DBG && (g.dbg & 2);             // tuning: every tile's outputs land in rows 0..255 of image 0
@@ -260,17 +240,6 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
           constexpr int q = m >> 1;
           F1[q] = LDS_B128((frag_is_a(q) ? a1 : b1) + frag_off(q));
         }
-        if constexpr (TOUCH && MODE <= 1 && m == 1) {
-          // exactly one touch per k-tile (the barrier's vmcnt(1) relies on it): pair of k-tiles (kt + touch) & ~1, hi
-          // plane at even kt, lo plane at odd kt; past the end of this tile: the next tile's first pairs (or, with no
-          // next tile, a line of this one again)
-          int P = (kt + (g.touch & 0xff)) & ~1;
-          const bool over = P >= nk;
-          if (over) P = have_next ? P - nk : nk - 2;
-          const u16* pl = (kt & 1) ? (over ? nAlo : src.Alo) : (over ? nAhi : src.Ahi);
-          const unsigned la = sbase + SCR_OFF + uw * SCR_WAVE;
-          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(offT), "s"(pl + P * BK), "s"(la) : "memory");
-        }
         SB();
       });
       // k-step b
@@ -288,8 +257,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
         if constexpr (m == 3) {
           // every fragment read of stage `cur` has returned (lgkmcnt), this wave's pieces of k-tile kt+1 have landed
           // (vmcnt; they were issued a k-tile period ago): behind the barrier stage `nxt` is readable, `cur` writable
-          if constexpr (TOUCH && MODE <= 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the touch stays in flight
-          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if constexpr (MODE == 0) {
           if constexpr (m >= 4 && m <= 18 && (m & 1) == 0) dma_piece(src, (m - 4) >> 1, (kt + 2) * BK, cur);
@@ -343,6 +311,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
         LDS_W32(wb + (hs & 1) * 2048 + ((r & 3) + 8 * (r >> 2)) * 128) = acc[si][jj][8 * h + r];
     };
     float rw[3][8];                           // rgb_w columns of the current column block
+    float tw[RGBF ? 3 : 1][8], tacc[RGBF ? 4 : 1][3];      // RGBF: ToRGB weights of the current column block; sums per row set
     if (DBG && (g.dbg & 8)) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][3][15])); continue; }
     put(std::integral_constant<int, 0>{});
     static_for(std::make_integer_sequence<int, 16>{}, [&](auto HS_) {
@@ -424,6 +393,40 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
           y[2 * e + 1] += __uint_as_float(wh[e] & 0xffff0000u) + __uint_as_float(wl[e] & 0xffff0000u);
         }
       }
+      if constexpr (RGBF) {
+        constexpr int jj = hs >> 2, rs = hs & 3;             // column sub-block, row set (si, h)
+        if constexpr (rs == 0) {
+          const int col = n0 + wn * 128 + jj * 32 + q2 * 8;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float4 w0 = *reinterpret_cast<const float4*>(d.torgb_w + (long long)c * d.N + col);
+            const float4 w1 = *reinterpret_cast<const float4*>(d.torgb_w + (long long)c * d.N + col + 4);
+            tw[c][0] = w0.x; tw[c][1] = w0.y; tw[c][2] = w0.z; tw[c][3] = w0.w; tw[c][4] = w1.x; tw[c][5] = w1.y; tw[c][6] = w1.z; tw[c][7] = w1.w;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float t = (jj == 0) ? 0.f : tacc[rs][c];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t = fmaf(y[e], tw[c][e], t);
+          tacc[rs][c] = t;
+        }
+        if constexpr (jj == 3) {
+          float v[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float t = tacc[rs][c];
+            t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0xB1, 0xF, 0xF, true));
+            t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x4E, 0xF, 0xF, true));
+            v[c] = t;
+          }
+          if (q2 == 0 && !(DBG && (g.dbg & 1))) {
+            const long long row = (long long)bz * d.M + m0 + wm * 64 + (rs >> 1) * 32 + (rs & 1) * 16 + h_rr;
+            float* q = d.torgb_part + ((long long)(tn * 2 + wn) * d.batch * d.M + row) * 4;
+            *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], 0.f);
+          }
+        }
+      }
       if (do_c) {
         float* q = d.C + cbase + uc;
         st16f(q, eC * 4u, y[0], y[1], y[2], y[3]);
@@ -449,15 +452,15 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
 
 }  // namespace
 
-template <bool A, bool Mk, bool R, bool FAST, bool DBG = false, bool TOUCH = false>
+template <bool A, bool Mk, bool R, bool FAST, bool DBG = false, bool RGBF = false>
 static void launch_v3f(const VArgs& g, int grid, hipStream_t stream) {
   static bool attr = false;
   CIPS_PER_DEVICE(attr, false);
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_v3_kernel<A, Mk, R, FAST, DBG, TOUCH>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_v3_kernel<A, Mk, R, FAST, DBG, RGBF>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x3_v3_kernel<A, Mk, R, FAST, DBG, TOUCH>), dim3(grid), dim3(512), SMEM_BYTES, stream, g);
+  hipLaunchKernelGGL((gemm_bf16x3_v3_kernel<A, Mk, R, FAST, DBG, RGBF>), dim3(grid), dim3(512), SMEM_BYTES, stream, g);
 }
 template <bool A, bool Mk, bool R>
 static void launch_v3(const VArgs& g, int grid, hipStream_t stream) {
@@ -465,18 +468,16 @@ static void launch_v3(const VArgs& g, int grid, hipStream_t stream) {
   // the training step's epilogues take the compile-time form
   const bool fwd = !Mk && d.act == 1 && d.mask_out != nullptr, bwd = Mk && d.act == 0 && d.mask_out == nullptr;
   const bool fast = d.P_hi != nullptr && d.C == nullptr && (fwd || bwd) && (A || d.C_unmasked == nullptr);
-  if (fast && g.dbg) {
-    if (g.touch > 0) launch_v3f<A, Mk, R, true, true, true>(g, grid, stream);
-    else launch_v3f<A, Mk, R, true, true>(g, grid, stream);
+  if constexpr (!A && !Mk) {
+    if (d.torgb_w) { launch_v3f<A, Mk, R, true, false, true>(g, grid, stream); return; }     // the entry point checked `fast`
   }
-  else if (fast && g.touch > 0) launch_v3f<A, Mk, R, true, false, true>(g, grid, stream);
+  if (fast && g.dbg) launch_v3f<A, Mk, R, true, true>(g, grid, stream);
   else if (fast) launch_v3f<A, Mk, R, true>(g, grid, stream);
   else launch_v3f<A, Mk, R, false>(g, grid, stream);
 }
 
-// Internal entry (called by cips_gemm_bf16x3 ahead of the wide kernel): same descriptor.  hipErrorNotSupported for
-// every shape / epilogue it has no code for.
-extern "C" int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t stream) {
+// 0: this kernel takes the descriptor; else the error code cips_gemm_bf16x3_v3 returns for it
+static int v3_accepts(const cips_gemm_x3_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
   if ((d->M % BM) || (d->N % BN) || (d->K % (2 * BK))) return (int)hipErrorNotSupported;
   if ((d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7)) return (int)hipErrorInvalidValue;
@@ -489,6 +490,19 @@ extern "C" int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t str
   // 32-bit lane offsets
   if ((long long)BM * d->lda * 2 >= 0x7fffffffLL || (long long)BN * d->ldb * 2 >= 0x7fffffffLL ||
       (long long)BM * d->ldc * 4 >= 0x7fffffffLL || (long long)BM * d->ldp * 2 >= 0x7fffffffLL) return (int)hipErrorNotSupported;
+  if (d->torgb_w) {      // fused ToRGB: the forward flavours' compile-time epilogue only
+    if (!d->torgb_part || a || m || !(d->act == 1 && d->mask_out && d->P_hi && !d->C && !d->C_unmasked)) return (int)hipErrorNotSupported;
+    if ((d->N & 127) || ((uintptr_t)d->torgb_part & 15) || ((uintptr_t)d->torgb_w & 15)) return (int)hipErrorNotSupported;
+  }
+  return 0;
+}
+extern "C" int cips_gemm_bf16x3_v3_accepts(const cips_gemm_x3_desc* d) { return v3_accepts(d); }
+
+// Internal entry (called by cips_gemm_bf16x3 ahead of the wide kernel): same descriptor.  hipErrorNotSupported for
+// every shape / epilogue it has no code for.
+extern "C" int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t stream) {
+  { const int rc = v3_accepts(d); if (rc) return rc; }
+  const bool a = d->add != nullptr, m = d->mask != nullptr, r = d->res_hi != nullptr;
   VArgs g = {};
   g.d = *d;
   g.tiles_m = d->M / BM;
@@ -510,7 +524,6 @@ extern "C" int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t str
     const char* e = getenv("CIPS_X3_V3DBG"); g.dbg = e ? atoi(e) : 0;
     e = getenv("CIPS_X3_V3SKEW"); g.skew = e ? atoi(e) : 0;
     e = getenv("CIPS_X3_V3PHASES"); g.phases = e ? atoi(e) : 2;
-    e = getenv("CIPS_X3_V3TOUCH"); g.touch = e ? atoi(e) : 0;
     e = getenv("CIPS_X3_V3GRID");
     if (e && atoi(e) > 0 && atoi(e) < grid) grid = (atoi(e) / 8) * 8 > 0 ? (atoi(e) / 8) * 8 : grid;
   }

@@ -705,6 +705,29 @@ extern "C" int cips_torgb_fwd(const float* x, const float* w, const float* bias,
   return CIPS_CHECK_LAUNCH();
 }
 
+// ToRGB forward folded into the GEMM epilogue (gemm_bf16x3_v3.hip, RGBF): the column-block partials of every row are
+// added here in block order, with the bias and the running image
+__global__ __launch_bounds__(256) void torgb_finish_kernel(const float4* __restrict__ part, int nblocks, const float* __restrict__ bias,
+                                                           float* __restrict__ rgb, long long M, int accumulate) {
+  const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+    float4 t = part[m];
+    for (int j = 1; j < nblocks; ++j) { const float4 u = part[(long long)j * M + m]; t.x += u.x; t.y += u.y; t.z += u.z; }
+    float* o = rgb + m * 3;
+    const float r0 = t.x + b0, r1 = t.y + b1, r2 = t.z + b2;
+    if (accumulate) { o[0] += r0; o[1] += r1; o[2] += r2; } else { o[0] = r0; o[1] = r1; o[2] = r2; }
+  }
+}
+extern "C" int cips_torgb_finish(const float* part, int nblocks, const float* bias, float* rgb, long long M, int accumulate,
+                                 cips_stream_t stream) {
+  if (!part || !rgb || nblocks <= 0 || M <= 0 || ((uintptr_t)part & 15)) return (int)hipErrorInvalidValue;
+  long long blocks = (M + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(torgb_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(part), nblocks, bias, rgb, M, accumulate);
+  return CIPS_CHECK_LAUNCH();
+}
+
 extern "C" int cips_torgb_fwd_x3(const void* x_hi, const void* x_lo, const float* w, const float* bias, float* rgb,
                                  long long M, int K, int accumulate, cips_stream_t stream) {
   if (M <= 0 || K <= 0 || (K & 3)) return (int)hipErrorInvalidValue;

@@ -445,3 +445,113 @@ extern "C" int cips_rownorm_bwd(const float* x, const float* y, const float* gam
     hipLaunchKernelGGL(rownorm_bwd_affine_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, x, stats, dyhat, dgamma, dbeta, rows, cols);
   return CIPS_CHECK_LAUNCH();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// EqualLinear (exp/cips3d/models/discriminator.py:254-288: F.linear(input, weight * scale) [+ bias * lr_mul]) and the two
+// other bilinear forms its autograd needs; each form's own gradients are the other two, which closes the
+// double-backward of the R1 penalty (train.py:387-394):
+//   mode 0   y  (B, O) = s * x (B, K) . w^T (O, K)  [+ bias (O) * bias_scale]
+//   mode 1   dx (B, K) = s * g (B, O) . w (O, K)
+//   mode 2   dw (O, K) = s * g^T (O, B) . x (B, K)
+// The 8192 -> 512 layer (final_conv features -> space_linear) runs on the exact-fp32 MFMA GEMM (gemm_f32.hip); its
+// forward contracts over 8192 inputs for at most a few dozen rows, i.e. four 128x128 output tiles: the contraction is
+// cut into 512-wide chunks (the GEMM's batch dimension) and the partial products are summed in chunk order here.  The
+// 512 -> 1 layer has no dimension a matrix tile could hold: three streaming kernels.
+namespace {
+__global__ __launch_bounds__(256) void eql_sum_chunks_kernel(const float* __restrict__ part, float* __restrict__ y, int nch, int n,
+                                                             int O, const float* __restrict__ bias, float bias_scale) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float v = part[i];
+    for (int c = 1; c < nch; ++c) v += part[(long long)c * n + i];
+    if (bias) v += bias[i % O] * bias_scale;
+    y[i] = v;
+  }
+}
+// mode 0, narrow output: one workgroup per row b, every thread a strided slice of k, tree sum in LDS
+__global__ __launch_bounds__(256) void eql_fwd_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float bias_scale, float s,
+                                                            float* __restrict__ y, int K, int O) {
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  for (int o = 0; o < O; ++o) {
+    float t = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) t = fmaf(x[(long long)b * K + k], w[(long long)o * K + k], t);
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+      if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) y[(long long)b * O + o] = s * red[0] + (bias ? bias[o] * bias_scale : 0.f);
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void eql_dx_small_kernel(const float* __restrict__ g, const float* __restrict__ w, float s,
+                                                           float* __restrict__ dx, int B, int K, int O) {
+  const long long n = (long long)B * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / K), k = (int)(i - (long long)b * K);
+    float t = 0.f;
+    for (int o = 0; o < O; ++o) t = fmaf(g[(long long)b * O + o], w[(long long)o * K + k], t);
+    dx[i] = s * t;
+  }
+}
+__global__ __launch_bounds__(256) void eql_dw_small_kernel(const float* __restrict__ g, const float* __restrict__ x, float s,
+                                                           float* __restrict__ dw, int B, int K, int O) {
+  const long long n = (long long)O * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int o = (int)(i / K), k = (int)(i - (long long)o * K);
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) t = fmaf(g[(long long)b * O + o], x[(long long)b * K + k], t);
+    dw[i] = s * t;
+  }
+}
+__host__ int eql_chunks(int K) { return (K >= 2048 && K % 512 == 0) ? K / 512 : 1; }
+}  // namespace
+
+extern "C" long long cips_equal_linear_scratch(int mode, int B, int K, int O) {
+  if (mode != 0 || (O & 3) || (K & 3)) return 0;
+  const int nch = eql_chunks(K);
+  return nch > 1 ? (long long)nch * B * O : 0;
+}
+
+extern "C" int cips_equal_linear(int mode, const float* a, const float* b, const float* bias, float bias_scale, float s,
+                                 float* out, float* scratch, int B, int K, int O, cips_stream_t stream) {
+  if (!a || !b || !out || B <= 0 || K <= 0 || O <= 0 || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = !(O & 3) && !(K & 3);
+  if (!wide) {
+    if (mode == 0) hipLaunchKernelGGL(eql_fwd_small_kernel, dim3(B), dim3(256), 0, st, a, b, bias, bias_scale, s, out, K, O);
+    else {
+      const long long n = mode == 1 ? (long long)B * K : (long long)O * K;
+      const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+      if (mode == 1) hipLaunchKernelGGL(eql_dx_small_kernel, dim3(blocks), dim3(256), 0, st, a, b, s, out, B, K, O);
+      else hipLaunchKernelGGL(eql_dw_small_kernel, dim3(blocks), dim3(256), 0, st, a, b, s, out, B, K, O);
+    }
+    return CIPS_CHECK_LAUNCH();
+  }
+  cips_gemm_desc d = {};
+  d.alpha = s; d.batch = 1;
+  if (mode == 0) {                 // y = s x w^T: A = x (B, K), B = w stored (O, K) ("NT")
+    const int nch = eql_chunks(K);
+    if (nch > 1 && !scratch) return (int)hipErrorInvalidValue;
+    d.A = a; d.B = b; d.C = nch > 1 ? scratch : out;
+    d.M = B; d.N = O; d.K = K / nch; d.lda = K; d.ldb = K; d.ldc = O; d.b_nmajor = 1;
+    d.batch = nch; d.strideA = K / nch; d.strideB = K / nch; d.strideC = (long long)B * O;
+    if (nch == 1 && bias) { /* bias added by the finishing pass below */ }
+    int rc = cips_gemm_f32(&d, stream);
+    if (rc) return rc;
+    if (nch > 1 || bias) {
+      const int n = B * O;
+      hipLaunchKernelGGL(eql_sum_chunks_kernel, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, st,
+                         nch > 1 ? scratch : out, out, nch, n, O, bias, bias_scale);
+    }
+    return CIPS_CHECK_LAUNCH();
+  }
+  if (mode == 1) {                 // dx = s g w: A = g (B, O), B = w (O, K) row-major
+    d.A = a; d.B = b; d.C = out; d.M = B; d.N = K; d.K = O; d.lda = O; d.ldb = K; d.ldc = K;
+  } else {                         // dw = s g^T x: A = g stored (B, O) = (contraction, M) ("TN"), B = x (B, K)
+    d.A = a; d.B = b; d.C = out; d.M = O; d.N = K; d.K = B; d.lda = O; d.ldb = K; d.ldc = K; d.a_kmajor = 1;
+  }
+  return cips_gemm_f32(&d, stream);
+}

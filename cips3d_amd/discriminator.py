@@ -311,11 +311,12 @@ def _nhwc(t):
 # never cached.  CIPS_D_WCACHE=0 disables the cache.
 # A write that bypasses the version counter (`p.data.copy_()`, `p.data.mul_()` — the reference's own EMA helper writes
 # through .data —, an optimiser step replayed from a hipGraph, a raw-pointer kernel) leaves stale planes in use: such
-# writers call invalidate_weight_cache(module_or_parameters) afterwards.  The cache lives in a WeakKeyDictionary beside
+# writers call invalidate_weight_cache(module_or_parameters) afterwards.  The cache lives in a weakly keyed table beside
 # the parameters, not in Parameter.__dict__: pickling / deepcopying a module does not carry GPU planes along.
 _WCACHE_ON = _os.environ.get("CIPS_D_WCACHE", "1") != "0"
 import weakref as _weakref
-_WCACHE = _weakref.WeakKeyDictionary()                     # Parameter -> {(kind, scale): (version, data_ptr, operand)}
+_WCACHE = {}        # id(Parameter) -> (weakref to it, {(kind, scale): (version, data_ptr, operand)}); the weakref's callback
+                    # drops the entry with the Parameter (a WeakKeyDictionary would compare tensor keys with ==)
 
 
 def invalidate_weight_cache(what=None):
@@ -326,16 +327,18 @@ def invalidate_weight_cache(what=None):
         return
     params = what.parameters() if isinstance(what, nn.Module) else what
     for p in params:
-        _WCACHE.pop(p, None)
+        _WCACHE.pop(id(p), None)
 
 
 def _cached(w, scale, kind, build):
     """build(w_eff) -> operand for `kind`, memoised on (parameter, version, scale)"""
     if not (_WCACHE_ON and isinstance(w, nn.Parameter)):
         return build(w if scale == 1.0 else w * scale)
-    ent = _WCACHE.get(w)                                   # entries die with the Parameter object
-    if ent is None:
-        ent = _WCACHE[w] = {}
+    slot = _WCACHE.get(id(w))                              # entries die with the Parameter object
+    if slot is None or slot[0]() is not w:
+        key_id = id(w)
+        slot = _WCACHE[key_id] = (_weakref.ref(w, lambda _r, k=key_id: _WCACHE.pop(k, None)), {})
+    ent = slot[1]
     key = (kind, float(scale))
     hit = ent.get(key)
     if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
@@ -742,9 +745,83 @@ class ResBlock(nn.Module):
         return (out + skip) / math.sqrt(2)
 
 
+def _eql(mode, a, b, s, B, K, O, bias=None, bias_scale=1.0):
+    """cips_equal_linear: mode 0  s a b^T (+ bias * bias_scale) -> (B, O);  1  s a b -> (B, K);  2  s a^T b -> (O, K)"""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    a, b = a.contiguous().float(), b.contiguous().float()
+    if not a.is_cuda:
+        raise RuntimeError("EqualLinear runs on the HIP library only: GPU tensors required")
+    out = torch.empty({0: (B, O), 1: (B, K), 2: (O, K)}[mode], device=a.device)
+    n = int(lib.cips_equal_linear_scratch(mode, B, K, O))
+    scratch = torch.empty(n, device=a.device) if n else None
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cips_equal_linear(mode, P(a), P(b), P(bias.contiguous().float() if bias is not None else None),
+                                         float(bias_scale), float(s), P(out), P(scratch), B, K, O,
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "cips_equal_linear")
+    return out
+
+
+class _EqLinFwd(Function):
+    """y = s x w^T (+ bias * bias_scale).  Together with _EqLinDx (s g w) and _EqLinDw (s g^T x) the three forms are
+    closed under differentiation: every backward below is again one of them, so the R1 double-backward
+    (train.py:387-394) needs nothing else."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, s, bias_scale):
+        ctx.save_for_backward(x, w)
+        ctx.s, ctx.bs, ctx.has_bias = s, bias_scale, bias is not None
+        return _eql(0, x, w, s, x.shape[0], x.shape[1], w.shape[0], bias, bias_scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dx = _EqLinDx.apply(g, w, ctx.s) if ctx.needs_input_grad[0] else None
+        dw = _EqLinDw.apply(g, x, ctx.s) if ctx.needs_input_grad[1] else None
+        db = g.sum(0) * ctx.bs if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None
+
+
+class _EqLinDx(Function):
+    @staticmethod
+    def forward(ctx, g, w, s):
+        ctx.save_for_backward(g, w)
+        ctx.s = s
+        return _eql(1, g, w, s, g.shape[0], w.shape[1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, u):
+        g, w = ctx.saved_tensors
+        dg = _EqLinFwd.apply(u, w, None, ctx.s, 1.0) if ctx.needs_input_grad[0] else None
+        dw = _EqLinDw.apply(g, u, ctx.s) if ctx.needs_input_grad[1] else None
+        return dg, dw, None
+
+
+class _EqLinDw(Function):
+    @staticmethod
+    def forward(ctx, g, x, s):
+        ctx.save_for_backward(g, x)
+        ctx.s = s
+        return _eql(2, g, x, s, g.shape[0], x.shape[1], g.shape[1])
+
+    @staticmethod
+    def backward(ctx, u):
+        g, x = ctx.saved_tensors
+        dg = _EqLinFwd.apply(x, u, None, ctx.s, 1.0) if ctx.needs_input_grad[0] else None
+        dx = _EqLinDx.apply(g, u, ctx.s) if ctx.needs_input_grad[1] else None
+        return dg, dx, None
+
+
+_LINEAR_HIP = _os.environ.get("CIPS_D_LINEAR_HIP", "1") != "0"
+
+
 class EqualLinear(nn.Module):
-    """discriminator.py:254-288.  (b x 8192) @ (8192 x 512) and (b x 512) @ (512 x 1): tiny-M GEMMs,
-    left on torch (natively double-differentiable); the activation uses the HIP fused op."""
+    """discriminator.py:254-288.  (b x 8192) @ (8192 x 512) and (b x 512) @ (512 x 1) on the HIP library
+    (cips_equal_linear: the exact-fp32 MFMA GEMM with the long contraction cut into chunks, streaming kernels for the
+    one-column output layer), double-differentiable through _EqLinFwd / _EqLinDx / _EqLinDw; the activation is the fused
+    bias + LeakyReLU op.  CIPS_D_LINEAR_HIP=0: torch.nn.functional.linear (hipBLASLt), for A/B runs."""
 
     def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
         super().__init__()
@@ -755,6 +832,11 @@ class EqualLinear(nn.Module):
         self.lr_mul = lr_mul
 
     def forward(self, input):
+        if _LINEAR_HIP and input.dim() == 2:
+            if self.activation:
+                out = _EqLinFwd.apply(input, self.weight, None, self.scale, 1.0)
+                return fused_leaky_relu(out, self.bias * self.lr_mul)
+            return _EqLinFwd.apply(input, self.weight, self.bias, self.scale, self.lr_mul)
         if self.activation:
             out = F.linear(input, self.weight * self.scale)
             return fused_leaky_relu(out, self.bias * self.lr_mul)

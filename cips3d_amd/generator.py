@@ -653,6 +653,12 @@ class GeneratorNerfINR(nn.Module):
                         fine_z, fine_pts = ops.resample_fwd(
                             sig_c, z_c, noise_c.reshape(b * n, S) if nerf_noise != 0 else None, nerf_noise,
                             u, ray_origins, dirs.reshape(b * n, 3) if dirs is not None else None, b, n, S, clamp, rays=rp)
+                        if ops.FINE_Z_REC is not None:
+                            ops.FINE_Z_REC.append(fine_z.detach().clone())
+                        if ops.FINE_Z_PIN is not None:       # parity tests: the reference's sample placement
+                            if not gen_rays:
+                                raise RuntimeError("pinned fine samples need the in-kernel ray path (whole images)")
+                            fine_z = next(ops.FINE_Z_PIN).to(fine_z.device).reshape(fine_z.shape).contiguous()
                     if gen_rays:
                         feat_f, sig_f, _ = self.siren.evaluate_rays(nerf_styles, rgeom, xg, yg, zg, cam2world,
                                                                     zvals=fine_z.view(b, n * S))

@@ -677,6 +677,30 @@ def torgb_bwd_x(drgb2d, w, add, mask, out_unmasked, out):
 #   GATE_REC: list that receives the bit plane every layer actually used, in call order.
 GATE_PIN = None
 GATE_REC = None
+# The other discontinuity of the path: importance resampling places the fine samples by a searchsorted over the coarse
+# weights' cdf (pigan_utils.py:164-273); a cdf value within rounding of the uniform draw puts a sample in the
+# neighbouring bin.  FINE_Z_REC collects the depths every hierarchical forward resampled (b*n, S); FINE_Z_PIN (an
+# iterator of such tensors) replaces them — parity tests compare gradients for the SAME sample placement.
+FINE_Z_PIN = None
+FINE_Z_REC = None
+
+
+class resample_debug:
+    """with resample_debug(pin=[fine_z, ...] or None, rec=list or None): ...   (tests only)"""
+
+    def __init__(self, pin=None, rec=None):
+        self.pin, self.rec = pin, rec
+
+    def __enter__(self):
+        global FINE_Z_PIN, FINE_Z_REC
+        self.old = (FINE_Z_PIN, FINE_Z_REC)
+        FINE_Z_PIN = iter(self.pin) if self.pin is not None else None
+        FINE_Z_REC = self.rec
+        return self
+
+    def __exit__(self, *exc):
+        global FINE_Z_PIN, FINE_Z_REC
+        FINE_Z_PIN, FINE_Z_REC = self.old
 
 
 class gate_debug:
@@ -863,10 +887,9 @@ class Planes:
         return self.hi.float() + self.lo.float()
 
 
-def gemm_x3(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, T=None, ldt=0, strideT=0,
-            mask_out=None, add=None, rgb_g=None, rgb_w=None, C_unmasked=None, mask=None, act=0, res=None, gate_bits=0):
-    """C[b][m][n] = epi(sum_k A[b][m][k] * B[b][n][k]); A, B, P, T, res: Planes; row-major aux use ld = N."""
-    lib = _lib.load()
+def _x3_desc(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, T=None, ldt=0, strideT=0,
+             mask_out=None, add=None, rgb_g=None, rgb_w=None, C_unmasked=None, mask=None, act=0, res=None, gate_bits=0,
+             torgb=None):
     d = GemmX3Desc()
     d.A_hi, d.A_lo, d.B_hi, d.B_lo = _p(A.hi), _p(A.lo), _p(Bm.hi), _p(Bm.lo)
     d.M, d.N, d.K, d.lda, d.ldb = M, N, K, lda, ldb
@@ -881,7 +904,33 @@ def gemm_x3(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, T
     d.act, d.slope = act, LRELU_SLOPE
     d.res_hi, d.res_lo = (_p(res.hi), _p(res.lo)) if res is not None else (None, None)
     d.gate_bits = gate_bits        # bit 0: `mask` is a uint8 bit plane (M, N/8); bit 1: `mask_out` is written as one
+    if torgb is not None:          # (T (3, N), partials (N/128, batch*M, 4)): ToRGB forward folded into the epilogue
+        d.torgb_w, d.torgb_part = _p(torgb[0]), _p(torgb[1])
+    return d
+
+
+def gemm_x3(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, **epi):
+    """C[b][m][n] = epi(sum_k A[b][m][k] * B[b][n][k]); A, B, P, T, res: Planes; row-major aux use ld = N."""
+    lib = _lib.load()
+    d = _x3_desc(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, **epi)
     check(lib.cips_gemm_bf16x3(_ct.byref(d), _stream()), "cips_gemm_bf16x3")
+
+
+def gemm_x3_torgb(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, P, rgb_w, rgb_b, rgb2d, accumulate, **epi):
+    """gemm_x3 with planes output P followed by ToRGB forward on it (rgb2d (batch*M, 3) (+)= P . rgb_w^T + rgb_b):
+    folded into the GEMM epilogue when the library's 256x256-tile kernel takes the shape (partials per 128-column
+    block + one finishing launch), else the ToRGB kernel on the written planes."""
+    lib = _lib.load()
+    part = torch.empty(max(N // 128, 1), batch * M, 4, device=P.hi.device)
+    d = _x3_desc(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, P=P, torgb=(rgb_w, part), **epi)
+    if N % 128 == 0 and rgb_w.is_contiguous() and lib.cips_gemm_bf16x3_fuses_torgb(_ct.byref(d)):
+        check(lib.cips_gemm_bf16x3(_ct.byref(d), _stream()), "cips_gemm_bf16x3")
+        check(lib.cips_torgb_finish(_p(part), N // 128, _p(rgb_b), _p(rgb2d), batch * M, 1 if accumulate else 0, _stream()),
+              "cips_torgb_finish")
+        return
+    d.torgb_w, d.torgb_part = None, None
+    check(lib.cips_gemm_bf16x3(_ct.byref(d), _stream()), "cips_gemm_bf16x3")
+    torgb_fwd_x3(P, rgb_w, rgb_b, rgb2d, accumulate)
 
 
 def gemm_x3_km(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C):
@@ -1134,6 +1183,8 @@ INR_GATE_BITS = _os.environ.get("CIPS_INR_GATE_BITS", "1") != "0"
 # launch: 4 TB/s of writes and an idle matrix pipe) are spread over the other chain's main loops.
 # CIPS_INR_CHUNKS=1: one chain (the round-2 behaviour).
 INR_CHUNKS = int(_os.environ.get("CIPS_INR_CHUNKS", "1"))
+# ToRGB forward folded into the epilogue of the block's second GEMM (CIPS_TORGB_FUSED=0: the separate ToRGB kernel)
+TORGB_FUSED = _os.environ.get("CIPS_TORGB_FUSED", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -1250,6 +1301,13 @@ class InrHeadX3Function(torch.autograd.Function):
                 if e["pin2"] is not None:
                     gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, nb, n * cout, cout * cout, P=oP, T=oT, ldt=n,
                             strideT=cout * n, res=xP if skip else None, mask=m2, gate_bits=1)
+                elif bits and k >= 3 and oT is None and TORGB_FUSED:
+                    gemm_x3_torgb(a1P, wbt2, n, cout, cout, cout, cout, nb, n * cout, cout * cout, oP, rgbp[2 * (k - 3)],
+                                  rgbp[2 * (k - 3) + 1], rgb[b0:b1].view(nb * n, 3), not first_rgb,
+                                  act=1, res=xP if skip else None, mask_out=m2, gate_bits=2)
+                    first_rgb = False
+                    xP = oP
+                    continue
                 elif bits:
                     gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, nb, n * cout, cout * cout, P=oP, T=oT, ldt=n,
                             strideT=cout * n, act=1, res=xP if skip else None, mask_out=m2, gate_bits=2)

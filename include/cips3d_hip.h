@@ -281,9 +281,21 @@ typedef struct cips_gemm_x3_desc {
    * strideP/8): bit 0 of gate_bits = `mask` is one, bit 1 = `mask_out` is written as one (value > 0).  Needs
    * N % 32 == 0, ldp % 32 == 0, strideP % 32 == 0.  0 = bf16 planes as above. */
   int gate_bits;
+  /* ToRGB forward folded into the epilogue (ABI 3; generator.py:949-1006, 1139-1144: rgb += out . T^T + tau): with
+   * torgb_w (3, N) set, every 128-column block j of the FINAL value of a row (what P receives) leaves the partial
+   * products  torgb_part[j][b*M + m][c] = sum_{n in block j} value[m][n] * torgb_w[c][n]  (c = 0..2, 4 floats per row,
+   * the 4th is 0); torgb_part holds (N/128) * batch*M * 4 floats.  cips_torgb_finish adds the blocks in order, the
+   * bias and (optionally) the running rgb.  Only the 256x256-tile v3 kernel implements it: cips_gemm_bf16x3 returns
+   * hipErrorNotSupported for any other shape (use cips_torgb_fwd_x3 on the planes then). */
+  const float* torgb_w; float* torgb_part;
 } cips_gemm_x3_desc;
 
 int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream);
+/* 1 when cips_gemm_bf16x3 would run this descriptor on the v3 kernel (the only one with the fused ToRGB partials) */
+int cips_gemm_bf16x3_fuses_torgb(const cips_gemm_x3_desc* d);
+/* rgb[m][c] = (accumulate ? rgb[m][c] : 0) + bias[c] + sum_j part[j][m][c];  part (nblocks, M, 4), rgb (M, 3) */
+int cips_torgb_finish(const float* part, int nblocks, const float* bias, float* rgb, long long M, int accumulate,
+                      cips_stream_t stream);
 /* K-major form: C[b][m][n] = sum_k A[b][k][m] * B[b][k][n] (A planes [K][lda], B planes [K][ldb]: the row-major
  * activation / gradient planes themselves; LDS transpose reads build the fragments).  fp32 C output only. */
 /* Tile-form selection of cips_gemm_bf16x3: 0 = 256x128 tiles always, 1 = 256x256 tiles for large problems (default;
@@ -446,6 +458,18 @@ int cips_upfirdn2d(const float* input, const float* kernel, float* out,
                    int major, int in_h, int in_w, int minor, int kernel_h, int kernel_w,
                    int up_x, int up_y, int down_x, int down_y,
                    int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream);
+
+/* EqualLinear (exp/cips3d/models/discriminator.py:254-288: F.linear(input, weight * scale) [+ bias * lr_mul]) and the two
+ * other bilinear forms of its autograd (each form's gradients are the other two: the R1 double-backward closes):
+ *   mode 0   out (B, O) = s * a (B, K) . b^T (O, K)  [+ bias (O) * bias_scale]        a = x, b = weight
+ *   mode 1   out (B, K) = s * a (B, O) . b (O, K)                                      a = dy, b = weight
+ *   mode 2   out (O, K) = s * a^T (O, B) . b (B, K)                                    a = dy, b = x
+ * O % 4 == 0 and K % 4 == 0: on cips_gemm_f32 (mode 0 with K >= 2048 cut into 512-wide chunks whose partial products
+ * land in `scratch`, cips_equal_linear_scratch floats, and are summed in chunk order); else three streaming kernels
+ * (the 512 -> 1 output layer).  bias only with mode 0. */
+long long cips_equal_linear_scratch(int mode, int B, int K, int O);
+int cips_equal_linear(int mode, const float* a, const float* b, const float* bias, float bias_scale, float s, float* out,
+                      float* scratch, int B, int K, int O, cips_stream_t stream);
 
 /* DiffAugment with policy 'color,translation,cutout' (exp/cips3d/models/diffaug.py:9-85; applied to every discriminator
  * input, exp/cips3d/models/discriminator.py:507-508) as one affine operator and its adjoint.  rb, rs, rc: the (B) raw

@@ -20,7 +20,7 @@ m = {k: sum(v[1:]) / max(1, len(v) - 1) for k, v in vals.items()}     # skip the
 # 32-B requests are counted separately; writes: 64-B requests (WRREQ_64B) else 32 B.
 rd = (m.get("TCC_EA0_RDREQ_sum", 0) - m.get("TCC_EA0_RDREQ_32B_sum", 0)) * 128 + m.get("TCC_EA0_RDREQ_32B_sum", 0) * 32
 wr = m.get("TCC_EA0_WRREQ_64B_sum", 0) * 64 + (m.get("TCC_EA0_WRREQ_sum", 0) - m.get("TCC_EA0_WRREQ_64B_sum", 0)) * 32
-out = {"kernel": "gemm_bf16x3_wide_kernel<0,0,0>, modfc 512x512 forward form (planes out), B=32, M=4096, N=512, K=512",
+out = {"kernel": "head NT GEMM (gemm_bf16x3_v3_kernel where the shape qualifies), modfc 512x512 forward form (lrelu, planes out), B=32, M=4096, N=512, K=512",
        "counters_mean_per_launch": m, "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
        "algorithmic_bytes": 32 * 4096 * 512 * 4 + 32 * 512 * 512 * 4 + 32 * 4096 * 512 * 4,
        "method": "rocprofv3 --kernel-trace --pmc (separate passes for reads and writes); reads = RDREQ x 128 B "

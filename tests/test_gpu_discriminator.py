@@ -306,3 +306,42 @@ def test_conv_layer_with_activation_in_the_gemm_epilogue(cfg, monkeypatch):
     for a, b, what in zip(res[True], res[False], ("y", "dx", "x.grad", "w.grad", "bias.grad")):
         assert a.shape == b.shape and rel_err(a, b) < 1e-5, (what, float(rel_err(a, b)))
     assert H < 16 or float((res[True][0] - res[False][0]).abs().max()) <= 1e-6 * float(res[False][0].abs().max())
+
+
+@pytest.mark.parametrize("B,K,O,bias,act", [(6, 8192, 512, True, True), (6, 512, 1, True, False), (5, 64, 8, False, False),
+                                            (3, 2048, 4, True, False)])
+def test_equal_linear_hip_forward_backward_double_backward(B, K, O, bias, act):
+    """EqualLinear on the HIP library (cips_equal_linear: chunked exact-fp32 GEMM for the 8192 -> 512 layer, streaming
+    kernels for 512 -> 1) against the reference formula (discriminator.py:254-288) evaluated in fp64: output, input and
+    parameter gradients, and an R1-style second-order gradient (penalty on the input gradient, differentiated w.r.t. the
+    weight) through the three-form closure _EqLinFwd / _EqLinDx / _EqLinDw."""
+    from cips3d_amd.discriminator import EqualLinear
+    import math
+    d = torch.device("cuda:0")
+    torch.manual_seed(B + K + O)
+    lin = EqualLinear(K, O, bias=bias, bias_init=0.3 if bias else 0, activation="fused_lrelu" if act else None).to(d)
+    x = torch.randn(B, K, device=d, requires_grad=True)
+    c = torch.randn(B, O, device=d)
+
+    def ref(xr, w, bvec):
+        out = xr @ (w * lin.scale).t()
+        if act:
+            return torch.nn.functional.leaky_relu(out + bvec * lin.lr_mul, 0.2) * math.sqrt(2)
+        return out + (bvec * lin.lr_mul if bvec is not None else 0)
+
+    y = lin(x)
+    gx, = torch.autograd.grad((y * c).sum(), x, create_graph=True)
+    pen = gx.pow(2).sum()
+    gw_pen, = torch.autograd.grad(pen, lin.weight, retain_graph=True)
+    grads = torch.autograd.grad((y * c).sum() + 0.1 * pen, [x, lin.weight] + ([lin.bias] if bias else []))
+    xr = x.detach().double().requires_grad_(True); wr = lin.weight.detach().double().requires_grad_(True)
+    br = lin.bias.detach().double().requires_grad_(True) if bias else None
+    yr = ref(xr, wr, br)
+    gxr, = torch.autograd.grad((yr * c.double()).sum(), xr, create_graph=True)
+    penr = gxr.pow(2).sum()
+    gw_penr, = torch.autograd.grad(penr, wr, retain_graph=True)
+    gradsr = torch.autograd.grad((yr * c.double()).sum() + 0.1 * penr, [xr, wr] + ([br] if bias else []))
+    assert max_rel(y, yr) < 2e-6 and max_rel(gx, gxr) < 2e-6, (max_rel(y, yr), max_rel(gx, gxr))
+    assert max_rel(gw_pen, gw_penr) < 1e-5, max_rel(gw_pen, gw_penr)
+    for a, b in zip(grads, gradsr):
+        assert max_rel(a, b) < 1e-5, max_rel(a, b)

@@ -499,6 +499,33 @@ def test_gemm_bf16x3_wide(M, N, K, batch, flavour, tile_mode):
         lib.cips_gemm_bf16x3_set_wide(-1)
 
 
+@pytest.mark.parametrize("res", [False, True])
+@pytest.mark.parametrize("M,N,K,batch,acc", [(4096, 512, 512, 20, False), (256, 256, 64, 3, True), (300, 256, 64, 2, False)])
+def test_gemm_bf16x3_fused_torgb(M, N, K, batch, acc, res):
+    """ToRGB forward folded into the epilogue of the 256x256-tile v3 kernel (partials per 128-column block + the
+    finishing launch) against the product of the written planes with the ToRGB weights; the planes and the gate plane
+    must be the ones the unfused GEMM writes, bit for bit.  (300 rows: not a v3 shape -> the separate ToRGB kernel.)"""
+    from cips3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K + batch)
+    A = torch.randn(batch, M, K, generator=g); B = torch.randn(batch, N, K, generator=g) * 0.05
+    Ap = ops.Planes(*[t.to(d) for t in _planes(A)]); Bp = ops.Planes(*[t.to(d) for t in _planes(B)])
+    resP = ops.Planes(*[t.to(d) for t in _planes(torch.randn(batch, M, N, generator=g))]) if res else None
+    T = torch.randn(3, N, generator=g).to(d); tau = torch.randn(3, generator=g).to(d)
+    rgb0 = torch.randn(batch * M, 3, generator=g).to(d)
+    P0 = ops.Planes.empty(batch, M, N, device=d); m0 = torch.zeros(batch, M, N // 8, device=d, dtype=torch.uint8)
+    ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P0, act=1, res=resP, mask_out=m0, gate_bits=2)
+    P1 = ops.Planes.empty(batch, M, N, device=d); m1 = torch.zeros(batch, M, N // 8, device=d, dtype=torch.uint8)
+    rgb = rgb0.clone()
+    ops.gemm_x3_torgb(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P1, T, tau, rgb, acc, act=1, res=resP, mask_out=m1, gate_bits=2)
+    torch.cuda.synchronize()
+    assert torch.equal(P0.hi, P1.hi) and torch.equal(P0.lo, P1.lo) and torch.equal(m0, m1)
+    want = P0.float().double().view(batch * M, N) @ T.double().t() + tau.double() + (rgb0.double() if acc else 0.0)
+    e = rel_err(rgb, want)
+    print(f"fused ToRGB {M}x{N}x{K}x{batch} res={res}: rel err {e:.3e}")
+    assert e < 2e-5
+
+
 @pytest.mark.parametrize("M,N,K,batch", [(512, 512, 4096, 32), (512, 512, 2048, 3), (256, 256, 64, 2), (520, 264, 96, 2),
                                          (512, 768, 1024, 40)])
 def test_gemm_bf16x3_kmajor_wide(M, N, K, batch):

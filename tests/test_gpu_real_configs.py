@@ -202,8 +202,13 @@ def test_discriminator_real_sizes_vs_oracle(size, b, alpha):
     _grad_compare(list(Dd.named_parameters()), ref_grads, f"D {size}x{size} gradients (oracle's gates pinned)")
 
 
-def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed):
-    """forward + every parameter gradient of `(imgs * G0).sum()` against the oracle, the oracle's LeakyReLU gates pinned"""
+def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, pin_fine=False):
+    """forward + every parameter gradient of `(imgs * G0).sum()` against the oracle, the oracle's LeakyReLU gates pinned.
+    pin_fine: also the oracle's placement of the resampled (fine) samples — the searchsorted of the importance
+    resampling is the path's second discontinuity: a cdf value within rounding of the uniform draw lands a sample in the
+    neighbouring bin, and the sigma head's gradient (a sum with heavy cancellation) moves by a finite amount per such
+    sample.  The free-running placement is compared first and the differing samples are counted."""
+    from cips3d_amd import ops
     d = torch.device("cuda:0")
     g = torch.Generator().manual_seed(seed)
     zs, rand = _draws(g, b, img, S, hier)
@@ -213,20 +218,32 @@ def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed):
     tape = orc.GateTape()
     with orc.gate_tape(tape):
         ref = orc.generator_forward(dict(Gc.named_parameters()), zs, rand, img, KW["fov"], KW["ray_start"], KW["ray_end"],
-                                    S, KW["h_stddev"], KW["v_stddev"], hier, nerf_noise=nerf_noise, return_aux_img=aux)
+                                    S, KW["h_stddev"], KW["v_stddev"], hier, nerf_noise=nerf_noise, return_aux_img=aux,
+                                    keep=pin_fine)
     (ref["imgs"] * G0).sum().backward()
     ref_grads = {k: p.grad for k, p in Gc.named_parameters() if p.grad is not None}
     ref_imgs = ref["imgs"].detach()
+    ref_fz = ref["fine_z"].detach().reshape(b * img * img, S) if pin_fine else None
     pins = [pack_bitplane(t) for t in tape.rec]
     del ref, tape
     Gd = seeded_generator(1234, device=d)
-    imgs = _product_forward(Gd, zs, rand, d, img, S, hier, aux=aux, pin=pins, nerf_noise=nerf_noise)
+    if pin_fine:
+        rec = []
+        with torch.no_grad(), ops.resample_debug(rec=rec):
+            free = _product_forward(Gd, zs, rand, d, img, S, hier, aux=aux, nerf_noise=nerf_noise)
+        dz = (rec[0].cpu() - ref_fz).abs()
+        moved = int((dz > 1e-4 * (KW["ray_end"] - KW["ray_start"])).sum())
+        print(f"{what}: free-running sample placement: {moved} of {dz.numel()} fine samples in another bin than the oracle's "
+              f"({moved / dz.numel():.1e}); images max_rel {max_rel(free, ref_imgs):.3e}")
+        assert moved <= 2e-3 * dz.numel() and max_rel(free, ref_imgs) < TOL
+    with ops.resample_debug(pin=[ref_fz] if pin_fine else None):
+        imgs = _product_forward(Gd, zs, rand, d, img, S, hier, aux=aux, pin=pins, nerf_noise=nerf_noise)
     e = max_rel(imgs, ref_imgs)
     print(f"{what}: imgs max_rel {e:.3e}")
     assert imgs.shape == (nimg, 3, img, img) and e < TOL
     (imgs * G0.to(d)).sum().backward()
     torch.cuda.synchronize()
-    _grad_compare(list(Gd.named_parameters()), ref_grads, f"{what} gradients (oracle's gates pinned)")
+    _grad_compare(list(Gd.named_parameters()), ref_grads, f"{what} gradients (oracle's gates" + (" and fine-sample placement" if pin_fine else "") + " pinned)")
     return len(ref_grads)
 
 
@@ -241,7 +258,7 @@ def test_c2_headline_geometry_flat_march_forward_backward_vs_oracle():
 def test_c3_r128_pair_forward_backward_vs_oracle():
     """C3 geometry with gradients: r128, S = 12 + 12, aux image, an image pair (the weight-gradient GEMMs contract over
     16 384 pixels per image)."""
-    _g_forward_backward_vs_oracle("C3 geometry b=2 r128 S=12+12, aux", 2, 128, 12, True, True, 0.1, 1283)
+    _g_forward_backward_vs_oracle("C3 geometry b=2 r128 S=12+12, aux", 2, 128, 12, True, True, 0.1, 1283, pin_fine=True)
 
 
 def _aug_draws(g, nb, size):
