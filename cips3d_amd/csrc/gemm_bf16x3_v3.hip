@@ -195,8 +195,12 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
     const unsigned eC = (unsigned)((wm * 64 + h_rr) * d.ldc + wn * 128 + q2 * 8);         // lane element offsets in the tile
     const unsigned eP = (unsigned)((wm * 64 + h_rr) * d.ldp + wn * 128 + q2 * 8);
     // half-sub-tile hs = 0..15: column block jj = hs>>2, row block si = (hs>>1)&1, half h = hs&1 (16 rows)
-    auto uoffC = [&](int hs) -> long long { return (long long)((((hs >> 1) & 1) * 32 + (hs & 1) * 16)) * d.ldc + (hs >> 2) * 32; };
-    auto uoffP = [&](int hs) -> long long { return (long long)((((hs >> 1) & 1) * 32 + (hs & 1) * 16)) * d.ldp + (hs >> 2) * 32; };
+    // (RGBF: the other nesting — row set (si, h) = hs>>2 outermost, column block jj = hs&3 innermost — so that a row's ToRGB
+    // sums are complete after four consecutive steps and only one set of three accumulators is live)
+    auto JJ = [](int hs) -> int { return RGBF ? (hs & 3) : (hs >> 2); };
+    auto RS = [](int hs) -> int { return RGBF ? (hs >> 2) : (hs & 3); };
+    auto uoffC = [&](int hs) -> long long { return (long long)(((RS(hs) >> 1) * 32 + (RS(hs) & 1) * 16)) * d.ldc + JJ(hs) * 32; };
+    auto uoffP = [&](int hs) -> long long { return (long long)(((RS(hs) >> 1) * 32 + (RS(hs) & 1) * 16)) * d.ldp + JJ(hs) * 32; };
     struct Pre { float4 add[HAS_ADD ? 2 : 1]; float gg[HAS_ADD ? 3 : 1]; unsigned mask; uint4 rh, rl; };
     const bool has_rgb = HAS_ADD && d.rgb_g != nullptr;
     auto prefetch = [&](int hs, Pre& p) {
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
         p.add[0] = *reinterpret_cast<const float4*>(q + eC * 4u);
         p.add[1] = *reinterpret_cast<const float4*>(q + eC * 4u + 16);
         if (has_rgb) {
-          const int row = m0 + wm * 64 + ((hs >> 1) & 1) * 32 + (hs & 1) * 16 + h_rr;
+          const int row = m0 + wm * 64 + (RS(hs) >> 1) * 32 + (RS(hs) & 1) * 16 + h_rr;
           const float* gp = d.rgb_g + ((long long)bz * d.M + row) * 3;
           p.gg[0] = gp[0]; p.gg[1] = gp[1]; p.gg[2] = gp[2];
         }
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
       }
     };
     constexpr bool HAS_IN = HAS_ADD || HAS_MASK || HAS_RES;
-    constexpr int NPF = HAS_ADD ? 3 : 4;        // ring of epilogue-input slots; slot hs % NPF is refilled NPF-1 half-sub-tiles ahead
+    constexpr int NPF = (HAS_ADD || RGBF) ? 3 : 4;        // ring of epilogue-input slots; slot hs % NPF is refilled NPF-1 half-sub-tiles ahead
     Pre pre[NPF];
 
     // ---- one k-tile.  MODE 0: steady state (fragments of the next k-tile + DMA of k-tile kt+2); 1: next-to-last
@@ -305,13 +309,13 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
     const unsigned rsw = (h_rr >> 2) & 1;
     const unsigned rb0 = sw + h_rr * 128 + (((2 * q2) ^ rsw) << 4), rb1 = sw + h_rr * 128 + (((2 * q2 + 1) ^ rsw) << 4);
     auto put = [&](auto HS_) {                // accumulators of half-sub-tile hs -> scratch half hs & 1
-      constexpr int hs = decltype(HS_)::value, jj = hs >> 2, si = (hs >> 1) & 1, h = hs & 1;
+      constexpr int hs = decltype(HS_)::value, jj = RGBF ? (hs & 3) : (hs >> 2), rsx = RGBF ? (hs >> 2) : (hs & 3), si = rsx >> 1, h = rsx & 1;
 #pragma unroll
       for (int r = 0; r < 8; ++r)
         LDS_W32(wb + (hs & 1) * 2048 + ((r & 3) + 8 * (r >> 2)) * 128) = acc[si][jj][8 * h + r];
     };
     float rw[3][8];                           // rgb_w columns of the current column block
-    float tw[RGBF ? 3 : 1][8], tacc[RGBF ? 4 : 1][3];      // RGBF: ToRGB weights of the current column block; sums per row set
+    float tacc[3] = {0.f, 0.f, 0.f};          // RGBF: the current row set's ToRGB sums
     if (DBG && (g.dbg & 8)) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][3][15])); continue; }
     put(std::integral_constant<int, 0>{});
     static_for(std::make_integer_sequence<int, 16>{}, [&](auto HS_) {
@@ -394,28 +398,22 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
         }
       }
       if constexpr (RGBF) {
-        constexpr int jj = hs >> 2, rs = hs & 3;             // column sub-block, row set (si, h)
-        if constexpr (rs == 0) {
-          const int col = n0 + wn * 128 + jj * 32 + q2 * 8;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float4 w0 = *reinterpret_cast<const float4*>(d.torgb_w + (long long)c * d.N + col);
-            const float4 w1 = *reinterpret_cast<const float4*>(d.torgb_w + (long long)c * d.N + col + 4);
-            tw[c][0] = w0.x; tw[c][1] = w0.y; tw[c][2] = w0.z; tw[c][3] = w0.w; tw[c][4] = w1.x; tw[c][5] = w1.y; tw[c][6] = w1.z; tw[c][7] = w1.w;
-          }
-        }
+        constexpr int jj = hs & 3, rs = hs >> 2;             // column sub-block (innermost), row set (si, h)
+        const int col = n0 + wn * 128 + jj * 32 + q2 * 8;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          float t = (jj == 0) ? 0.f : tacc[rs][c];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) t = fmaf(y[e], tw[c][e], t);
-          tacc[rs][c] = t;
+          const float4 w0 = *reinterpret_cast<const float4*>(d.torgb_w + (long long)c * d.N + col);
+          const float4 w1 = *reinterpret_cast<const float4*>(d.torgb_w + (long long)c * d.N + col + 4);
+          float t = (jj == 0) ? 0.f : tacc[c];
+          t = fmaf(y[0], w0.x, t); t = fmaf(y[1], w0.y, t); t = fmaf(y[2], w0.z, t); t = fmaf(y[3], w0.w, t);
+          t = fmaf(y[4], w1.x, t); t = fmaf(y[5], w1.y, t); t = fmaf(y[6], w1.z, t); t = fmaf(y[7], w1.w, t);
+          tacc[c] = t;
         }
         if constexpr (jj == 3) {
           float v[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            float t = tacc[rs][c];
+            float t = tacc[c];
             t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0xB1, 0xF, 0xF, true));
             t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x4E, 0xF, 0xF, true));
             v[c] = t;

@@ -656,9 +656,9 @@ class GeneratorNerfINR(nn.Module):
                         if ops.FINE_Z_REC is not None:
                             ops.FINE_Z_REC.append(fine_z.detach().clone())
                         if ops.FINE_Z_PIN is not None:       # parity tests: the reference's sample placement
-                            if not gen_rays:
-                                raise RuntimeError("pinned fine samples need the in-kernel ray path (whole images)")
                             fine_z = next(ops.FINE_Z_PIN).to(fine_z.device).reshape(fine_z.shape).contiguous()
+                            if not gen_rays:             # materialised points: origin + direction * depth (generator_nerf_inr.py:537-598)
+                                fine_pts = (ray_origins.view(b, 1, 1, 3) + dirs.reshape(b, n, 1, 3) * fine_z.view(b, n, S, 1)).reshape(b, n * S, 3).contiguous()
                     if gen_rays:
                         feat_f, sig_f, _ = self.siren.evaluate_rays(nerf_styles, rgeom, xg, yg, zg, cam2world,
                                                                     zvals=fine_z.view(b, n * S))

@@ -289,6 +289,26 @@ def inr_head(sd, fea, w_inr, prefix="inr_net.", return_all=False):
 # ----------------------------------------------------------------------------------------
 # generator.forward — exp/cips3d/models/generator.py:1256-1370, 1378-1534, 1659-1762
 # ----------------------------------------------------------------------------------------
+_FINE_Z_PIN = [None]
+
+
+class fine_z_pin:
+    """with fine_z_pin(fz): the hierarchical pass below takes its fine depths (b, n, S, 1) from `fz` instead of resampling
+    them (test infrastructure: the searchsorted of sample_pdf is a discontinuity — an fp64 evaluation of the same network
+    places ~0.2 % of the samples in a neighbouring bin; gradients are compared for ONE placement)."""
+
+    def __init__(self, fz):
+        self.fz = fz
+
+    def __enter__(self):
+        self.old = _FINE_Z_PIN[0]
+        _FINE_Z_PIN[0] = self.fz
+        return self
+
+    def __exit__(self, *exc):
+        _FINE_Z_PIN[0] = self.old
+
+
 def _points_forward(sd, w_nerf, w_inr, pts, z, origins, dirs, b, n, S, hierarchical_sample, nerf_noise, clamp_mode,
                     noise_c, u, noise_f, return_aux_img, nerf_nograd, keep=None, last_back=False, white_back=False):
     """points_forward (exp/cips3d/models/generator.py:1659-1762) for n rays per image:
@@ -299,6 +319,9 @@ def _points_forward(sd, w_nerf, w_inr, pts, z, origins, dirs, b, n, S, hierarchi
     if hierarchical_sample:
         with torch.no_grad():
             fp, fz, book = fine_points(coarse, z, noise_c, nerf_noise, u, origins, dirs, clamp_mode)
+            if _FINE_Z_PIN[0] is not None:
+                fz = _FINE_Z_PIN[0].to(z.dtype).reshape(b, n, S, 1)
+                fp = (origins.unsqueeze(2).contiguous() + dirs.unsqueeze(2).contiguous() * fz.expand(-1, -1, -1, 3).contiguous()).reshape(b, n * S, 3)
         with ctx:
             fine = siren(sd, fp, w_nerf).reshape(b, n, S, 33)
         all_o = torch.cat([fine, coarse], dim=-2)
