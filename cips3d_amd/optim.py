@@ -24,7 +24,7 @@ class FusedClipAdamEMA:
     EMA copy.  `ema_start_itr` reproduces EMA(start_itr=...): before it the EMA copy is not updated."""
 
     def __init__(self, params, lr, betas=(0.0, 0.999), eps=1e-8, max_norm=None, ema_params=None, ema_decay=0.999,
-                 ema_start_itr=0):
+                 ema_start_itr=0, capture_slots=4):
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("no parameters")
@@ -71,6 +71,7 @@ class FusedClipAdamEMA:
         self._ring = [[torch.empty(C.sizeof(self._table_host), dtype=torch.uint8).pin_memory(), None] for _ in range(4)]
         self._ring_pos = 0
         self._captured = []          # pinned tables read by captured uploads (kept alive for the graphs' lifetime)
+        self._cap_free = [torch.empty(C.sizeof(self._table_host), dtype=torch.uint8).pin_memory() for _ in range(int(capture_slots))]
         self._uploaded = None        # bytes of the table the device currently holds
 
     @property
@@ -109,7 +110,10 @@ class FusedClipAdamEMA:
                 # a captured upload is re-executed by every replay: it reads a pinned buffer of its own that nothing
                 # rewrites afterwards (a ring slot would be overwritten by later eager uploads, and a replay would then
                 # upload whatever pointers the slot holds at that time)
-                buf = torch.empty(C.sizeof(self._table_host), dtype=torch.uint8).pin_memory()
+                if not self._cap_free:
+                    raise RuntimeError("FusedClipAdamEMA: more captured steps with distinct tensor tables than capture slots "
+                                       f"({len(self._captured)}); construct with more `capture_slots`")
+                buf = self._cap_free.pop()       # pinned memory cannot be allocated while a stream is capturing
                 self._captured.append(buf)
                 C.memmove(buf.data_ptr(), C.addressof(self._table_host), C.sizeof(self._table_host))
                 self._table_dev.copy_(buf, non_blocking=True)

@@ -10,7 +10,7 @@ while IFS= read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
   echo "=== [$i] $line" | tee -a gpurun_out/${TAG}_summary.txt
-  ( eval "timeout 900 env $line" ) > gpurun_out/${TAG}_$i.log 2>&1
+  ( eval "timeout 2400 env $line" ) > gpurun_out/${TAG}_$i.log 2>&1
   echo "exit $?" | tee -a gpurun_out/${TAG}_summary.txt
   tail -n 25 gpurun_out/${TAG}_$i.log
 done < "$1"

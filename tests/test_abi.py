@@ -68,6 +68,19 @@ def test_product_never_imports_oracle():
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} references the oracle"
 
 
+def test_product_holds_no_copy_of_the_reference_diffaugment():
+    """Round-2 verdict: the op-by-op torch DiffAugment (a renamed copy of exp/cips3d/models/diffaug.py:30-85) left the
+    product; the policy runs on the HIP operator (cips_diffaug) only.  The function bodies must stay gone."""
+    pkg = os.path.join(ROOT, "cips3d_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                for needle in ("rand_brightness", "rand_saturation", "rand_contrast", "rand_translation", "rand_cutout",
+                               "AUGMENT_FNS", "torch.meshgrid", "mask[gb, gx, gy]", "F.pad(x, [1, 1, 1, 1"):
+                    assert needle not in src, (f, needle)
+
+
 def test_entry_points_validate_arguments_before_touching_the_device():
     """Malformed descriptors are refused with hipErrorInvalidValue (1) / hipErrorNotSupported (801) before any HIP
     call — so this runs without a GPU.  (Contraction lengths must be multiples of 32 bf16, planes 16-byte aligned,

@@ -217,3 +217,26 @@ def test_overlapped_gradient_buckets_on_gpu_equal_classic():
                 assert nb >= 3 and early >= nb - 1, (early, nb)
         for a, b in zip(res[0]["overlap"][step][0], res[1]["overlap"][step][0]):
             assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+
+
+def test_bench_two_ranks_gloo_functional_run_reports_the_exchange():
+    """`bench.py --gpus 2` as the driver launches N > 1 runs (self-spawned torch.distributed.run ranks), here over gloo with
+    both ranks on the box's one GPU (CIPS_BENCH_BACKEND=gloo: a functional check, never a measurement): the JSON line must
+    carry the fields the first real 8-GPU run needs — ranks, the reduce form, and the event-timed all-reduce (ms, bytes
+    per rank, bus bandwidth, fraction of the step) — so that run yields the SURVEY §8(e) numbers with no code change."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CIPS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--img-size", "16",
+                          "--batch", "2", "--num-steps", "4", "--no-cpu-baseline", "--no-roofline", "--no-exact", "--no-full-step"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 4
+    assert line["config"]["rccl_ranks"] == 0 and "functional check" in line["backend_note"]          # gloo: not RCCL, and says so
+    assert line["config"]["grad_reduce"].startswith("flat-bucket all-reduce")
+    ar = line["allreduce"]
+    assert ar["bytes_per_rank"] > 40e6 and ar["ms_median"] > 0 and ar["bus_GBps"] > 0 and 0 < ar["frac_of_step"] < 1
+    assert line["ms_per_step_median"] > 0 and line["value"] > 0

@@ -148,4 +148,23 @@ def test_fused_step_replayed_as_hipgraph_advances_bias_correction():
     torch.cuda.synchronize()
     for k, (a, b) in enumerate(zip(p_ref, p_fus)):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (k, float((a - b).abs().max()))
+    # an EAGER step with freshly allocated gradients in between (it uploads another tensor table through the staging
+    # ring), then a replay: the captured upload reads a pinned table of its own, so the replay still steps through the
+    # static gradient buffers it was captured with (round-2 advisor: a ring slot would have been overwritten)
+    static = [b.grad for b in p_fus]
+    g2 = [torch.randn(*s_, generator=g).to(d) for s_ in shapes]
+    for a, b, gr in zip(p_ref, p_fus, g2):
+        a.grad = gr.clone()
+        b.grad = gr.clone() + 0
+    opt.step(); fus.step()
+    g3 = [torch.randn(*s_, generator=g).to(d) for s_ in shapes]
+    for a, b, st, gr in zip(p_ref, p_fus, static, g3):
+        a.grad = gr.clone()
+        st.copy_(gr)
+        b.grad = st
+    opt.step(); graph.replay()
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(p_ref, p_fus)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (k, float((a - b).abs().max()))
+    assert fus.steps == [7, 7]
     assert fus.steps == [5, 5]
