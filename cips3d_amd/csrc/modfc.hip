@@ -320,10 +320,12 @@ __global__ __launch_bounds__(256) void torgb_bwd_w_partial_x3_k512_kernel(const 
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[c][q] = 0.f;
-  for (long long m = m0 + wave; m < m1; m += 16) {          // 4 rows in flight: m, m+4, m+8, m+12
-    float v[4][8], g[4][3];
+  constexpr int RF = 8;                                     // rows in flight per wave: m, m+4, ..., m+28 (4 in round 2:
+                                                            // 8 KiB of loads per wave in flight left the kernel at 3 TB/s)
+  for (long long m = m0 + wave; m < m1; m += 4 * RF) {
+    float v[RF][8], g[RF][3];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RF; ++r) {
       const long long mm = m + 4 * r;
       const bool ok = mm < m1;
       ld8x3(xh, xl, (ok ? mm : m) * K + lane * 8, v[r]);
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void torgb_bwd_w_partial_x3_k512_kernel(const 
       for (int c = 0; c < 3; ++c) g[r][c] = ok ? drgb[mm * 3 + c] : 0.f;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RF; ++r)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         gs[c] += g[r][c];

@@ -31,18 +31,14 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 CASES = [
     ("base", {}),
+    ("column block innermost (dbg 16)", {"CIPS_X3_V3DBG": "16"}),
+    ("column block innermost + nt stores (dbg 20)", {"CIPS_X3_V3DBG": "20"}),
     ("base again", {}),
+    ("column block innermost (dbg 16)", {"CIPS_X3_V3DBG": "16"}),
+    ("column block innermost + nt stores (dbg 20)", {"CIPS_X3_V3DBG": "20"}),
     ("skip epilogue (dbg 8)", {"CIPS_X3_V3DBG": "8"}),
-    ("A nt", {"CIPS_X3_V3TOUCH": "256"}),
-    ("B nt", {"CIPS_X3_V3TOUCH": "512"}),
-    ("A+B nt", {"CIPS_X3_V3TOUCH": "768"}),
-    ("A sc1", {"CIPS_X3_V3TOUCH": "1024"}),
-    ("B sc1", {"CIPS_X3_V3TOUCH": "2048"}),
-    ("A nt + skip epilogue", {"CIPS_X3_V3TOUCH": "256", "CIPS_X3_V3DBG": "8"}),
-    ("B nt + skip epilogue", {"CIPS_X3_V3TOUCH": "512", "CIPS_X3_V3DBG": "8"}),
-    ("A sc1 + skip epilogue", {"CIPS_X3_V3TOUCH": "1024", "CIPS_X3_V3DBG": "8"}),
-    ("A nt + nt stores", {"CIPS_X3_V3TOUCH": "256", "CIPS_X3_V3DBG": "4"}),
     ("base 3", {}),
+    ("column block innermost (dbg 16)", {"CIPS_X3_V3DBG": "16"}),
 ]
 KEYS = ["CIPS_X3_V3DBG", "CIPS_X3_V3SKEW", "CIPS_X3_V3PHASES", "CIPS_X3_V3GRID", "CIPS_X3_V3TOUCH"]
 for name, env in CASES:
@@ -56,9 +52,9 @@ ref = {}
 for fl in F:
     F[fl](); torch.cuda.synchronize()
     ref[fl] = (oP.hi.clone(), oP.lo.clone())
-os.environ["CIPS_X3_V3TOUCH"] = "4"
+os.environ["CIPS_X3_V3DBG"] = "16"
 for fl in F:
     oP.hi.zero_(); oP.lo.zero_()
     F[fl](); torch.cuda.synchronize()
-    print(f"touch variant {fl}: bit-identical {torch.equal(oP.hi, ref[fl][0]) and torch.equal(oP.lo, ref[fl][1])}")
-os.environ.pop("CIPS_X3_V3TOUCH", None)
+    print(f"column-block-innermost variant {fl}: bit-identical {torch.equal(oP.hi, ref[fl][0]) and torch.equal(oP.lo, ref[fl][1])}")
+os.environ.pop("CIPS_X3_V3DBG", None)

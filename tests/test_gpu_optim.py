@@ -167,4 +167,3 @@ def test_fused_step_replayed_as_hipgraph_advances_bias_correction():
     for k, (a, b) in enumerate(zip(p_ref, p_fus)):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (k, float((a - b).abs().max()))
     assert fus.steps == [7, 7]
-    assert fus.steps == [5, 5]
