@@ -670,6 +670,97 @@ __global__ __launch_bounds__(256) void modfc_prep_bwd_s_batch_kernel(BwdJobs J, 
   if (lane == 0) J.ds[job][row] = acc;
 }
 
+// ---- vector forms of the column reductions and the fused dW / ds pass (round 3) ------------------------------------
+// The per-image gradient G = dL/dWb of the 18 head layers is 604 MB at C2.  The three-pass backward above reads it
+// three times (c, dW, ds); here the column sums c read it once with 16-byte lanes and ONE further pass produces both
+// dW (sum over images, registers) and ds (sum over columns, one wave reduction per image) — two reads instead of three.
+// A block is 64 columns x 16 row groups, every lane owns 4 consecutive columns.
+template <bool WITH_G>
+__global__ __launch_bounds__(256) void modfc_colsum4_batch_kernel(PrepJobs P, BwdJobs J, int B, float eps) {
+  __shared__ float4 red[16][17];
+  const int job = blockIdx.z, b = blockIdx.y;
+  const int in_dim = WITH_G ? J.in_dim[job] : P.in_dim[job], out_dim = WITH_G ? J.out_dim[job] : P.out_dim[job];
+  if (blockIdx.x * 64 >= out_dim) return;
+  const float* __restrict__ W = WITH_G ? J.W[job] : P.W[job];
+  const float* __restrict__ sb = (WITH_G ? J.s[job] : P.s[job]) + (long long)b * in_dim;
+  const float* __restrict__ Gb = WITH_G ? J.G[job] + (long long)b * in_dim * out_dim : nullptr;
+  const int c = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + 4 * c;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < out_dim) {
+#pragma unroll 4
+    for (int k = kg; k < in_dim; k += 16) {
+      const float4 w = *reinterpret_cast<const float4*>(W + (long long)k * out_dim + n);
+      const float m = sb[k] + 1.f;
+      if (WITH_G) {
+        const float4 g = *reinterpret_cast<const float4*>(Gb + (long long)k * out_dim + n);
+        q.x = fmaf(g.x, w.x * m, q.x); q.y = fmaf(g.y, w.y * m, q.y); q.z = fmaf(g.z, w.z * m, q.z); q.w = fmaf(g.w, w.w * m, q.w);
+      } else {
+        const float4 u = make_float4(w.x * m, w.y * m, w.z * m, w.w * m);
+        q.x = fmaf(u.x, u.x, q.x); q.y = fmaf(u.y, u.y, q.y); q.z = fmaf(u.z, u.z, q.z); q.w = fmaf(u.w, u.w, q.w);
+      }
+    }
+  }
+  red[kg][c] = q;
+  __syncthreads();
+  if (kg == 0 && n < out_dim) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { const float4 v = red[g][c]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    if (WITH_G) *reinterpret_cast<float4*>(J.cbuf[job] + (long long)b * out_dim + n) = t;
+    else *reinterpret_cast<float4*>(P.demod[job] + (long long)b * out_dim + n) =
+        make_float4(rsqrtf(t.x + eps), rsqrtf(t.y + eps), rsqrtf(t.z + eps), rsqrtf(t.w + eps));
+  }
+}
+
+// one wave per weight row k, lanes own 4 consecutive columns of each 256-column chunk (out_dim <= 256 NCH, B <= 64):
+// dW[k][n] = sum_b m_bk du_bkn in registers (images in ascending order, as the three-pass kernel adds them), and
+// ds[b][k] = sum_n W_kn du_bkn as one wave reduction per image, kept by lane b.
+template <int NCH>
+__global__ __launch_bounds__(256) void modfc_prep_bwd_ws_batch_kernel(BwdJobs J, int B) {
+  const int job = blockIdx.y;
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= in_dim) return;
+  const float* __restrict__ s = J.s[job]; const float* __restrict__ demod = J.demod[job];
+  const float* __restrict__ G = J.G[job]; const float* __restrict__ cbuf = J.cbuf[job];
+  float4 w[NCH], acc[NCH];
+  bool ok[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int n = c * 256 + 4 * lane;
+    ok[c] = n < out_dim;
+    w[c] = ok[c] ? *reinterpret_cast<const float4*>(J.W[job] + (long long)k * out_dim + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float dsv = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float m = s[(long long)b * in_dim + k] + 1.f;
+    const long long row = (long long)b * in_dim + k;
+    float part = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (!ok[c]) continue;
+      const int n = c * 256 + 4 * lane;
+      const float4 g = *reinterpret_cast<const float4*>(G + row * out_dim + n);
+      const float4 d = *reinterpret_cast<const float4*>(demod + (long long)b * out_dim + n);
+      const float4 cb = *reinterpret_cast<const float4*>(cbuf + (long long)b * out_dim + n);
+      const float dx = d.x * (g.x - d.x * d.x * (w[c].x * m) * cb.x), dy = d.y * (g.y - d.y * d.y * (w[c].y * m) * cb.y);
+      const float dz = d.z * (g.z - d.z * d.z * (w[c].z * m) * cb.z), dw = d.w * (g.w - d.w * d.w * (w[c].w * m) * cb.w);
+      acc[c].x = fmaf(m, dx, acc[c].x); acc[c].y = fmaf(m, dy, acc[c].y); acc[c].z = fmaf(m, dz, acc[c].z); acc[c].w = fmaf(m, dw, acc[c].w);
+      part = fmaf(w[c].x, dx, part); part = fmaf(w[c].y, dy, part); part = fmaf(w[c].z, dz, part); part = fmaf(w[c].w, dw, part);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == b) dsv = part;
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (ok[c]) *reinterpret_cast<float4*>(J.dW[job] + (long long)k * out_dim + c * 256 + 4 * lane) = acc[c];
+  if (lane < B) J.ds[job][(long long)lane * in_dim + k] = dsv;
+}
+
 }  // namespace
 
 extern "C" int cips_modfc_prep(const float* weight, const float* s, float* wb, float* wbt, float* demod,
@@ -818,11 +909,19 @@ extern "C" int cips_modfc_prep_x3_batch(const cips_modfc_prep_job* jobs, int njo
     max_in = j.in_dim > max_in ? j.in_dim : max_in; max_out = j.out_dim > max_out ? j.out_dim : max_out;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(modfc_demod_batch_kernel, dim3((max_out + 31) / 32, B, njobs), dim3(256), 0, st, J, B, eps);
   bool wide = true;                              // 64 x 64 tiles with vector accesses when every job's shape allows
-  for (int i = 0; i < njobs; ++i) wide = wide && (jobs[i].out_dim % 4 == 0) && (jobs[i].in_dim % 8 == 0);
-  static int planes64 = -1;
+  bool vec4 = true;                              // 16-byte lanes in the column reductions
+  for (int i = 0; i < njobs; ++i) {
+    wide = wide && (jobs[i].out_dim % 4 == 0) && (jobs[i].in_dim % 8 == 0);
+    vec4 = vec4 && (jobs[i].out_dim % 4 == 0);
+  }
+  static int planes64 = -1, fused = -1;
   if (planes64 < 0) { const char* e = getenv("CIPS_MODFC_PLANES64"); planes64 = (e && atoi(e) == 0) ? 0 : 1; }
+  if (fused < 0) { const char* e = getenv("CIPS_MODFC_VEC4"); fused = (e && atoi(e) == 0) ? 0 : 1; }
+  if (vec4 && fused)
+    hipLaunchKernelGGL(modfc_colsum4_batch_kernel<false>, dim3((max_out + 63) / 64, B, njobs), dim3(256), 0, st, J, BwdJobs{}, B, eps);
+  else
+    hipLaunchKernelGGL(modfc_demod_batch_kernel, dim3((max_out + 31) / 32, B, njobs), dim3(256), 0, st, J, B, eps);
   if (wide && planes64)
     hipLaunchKernelGGL(modfc_planes_batch64_kernel, dim3((max_out + 63) / 64, (max_in + 63) / 64, B * njobs), dim3(256), 0, st, J, B);
   else
@@ -846,6 +945,18 @@ extern "C" int cips_modfc_prep_bwd_batch(const cips_modfc_bwd_job* jobs, int njo
     max_nw = nw > max_nw ? nw : max_nw;
   }
   hipStream_t st = (hipStream_t)stream;
+  bool vec4 = B <= 64 && max_out <= 1024;        // two reads of G instead of three (see modfc_prep_bwd_ws_batch_kernel)
+  for (int i = 0; i < njobs; ++i) vec4 = vec4 && (jobs[i].out_dim % 4 == 0);
+  static int fused = -1;
+  if (fused < 0) { const char* e = getenv("CIPS_MODFC_VEC4"); fused = (e && atoi(e) == 0) ? 0 : 1; }
+  if (vec4 && fused) {
+    hipLaunchKernelGGL(modfc_colsum4_batch_kernel<true>, dim3((max_out + 63) / 64, B, njobs), dim3(256), 0, st, PrepJobs{}, J, B, 0.f);
+    if (max_out <= 512)
+      hipLaunchKernelGGL(modfc_prep_bwd_ws_batch_kernel<2>, dim3((max_in + 3) / 4, njobs), dim3(256), 0, st, J, B);
+    else
+      hipLaunchKernelGGL(modfc_prep_bwd_ws_batch_kernel<4>, dim3((max_in + 3) / 4, njobs), dim3(256), 0, st, J, B);
+    return CIPS_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(modfc_prep_bwd_c_batch_kernel, dim3((max_out + 31) / 32, B, njobs), dim3(256), 0, st, J);
   hipLaunchKernelGGL(modfc_prep_bwd_w_batch_kernel, dim3((unsigned)((max_nw + 255) / 256), njobs), dim3(256), 0, st, J, B);
   hipLaunchKernelGGL(modfc_prep_bwd_s_batch_kernel, dim3((unsigned)(((long long)B * max_in + 3) / 4), njobs), dim3(256), 0, st, J, B);

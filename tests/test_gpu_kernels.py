@@ -374,6 +374,36 @@ def test_modfc_prep_forward_backward():
     assert rel_err(dW, W.grad) < 1e-4 and rel_err(ds, s.grad) < 1e-4
 
 
+@pytest.mark.parametrize("shapes,B_", [([(64, 96), (512, 512), (36, 520), (128, 1024)], 5), ([(512, 512), (32, 512)], 64),
+                                       ([(64, 96), (40, 30)], 3), ([(48, 64)], 70)])
+def test_modfc_prep_batch_forward_backward(shapes, B_):
+    """The batched forms the head uses (all layers in one call): 16-byte column reductions and the fused dW / ds pass when
+    every out_dim is a multiple of 4 (B <= 64, out_dim <= 1024), the scalar three-pass kernels otherwise — both against
+    torch autograd of the modulate / demodulate rule (exp/comm/models/mod_conv_fc.py:19-120)."""
+    from cips3d_amd import ops
+    g = torch.Generator().manual_seed(14)
+    d = dev()
+    Ws = [torch.randn(i, o, generator=g).requires_grad_(True) for i, o in shapes]
+    ss = [(torch.randn(B_, i, generator=g) * 0.5).requires_grad_(True) for i, o in shapes]
+    ups = [torch.randn(B_, i, o, generator=g) for i, o in shapes]
+    refs = []
+    for W, s, up in zip(Ws, ss, ups):
+        w = W.double().unsqueeze(0) * (s.double().unsqueeze(-1) + 1)
+        dm = torch.rsqrt(w.pow(2).sum([1]) + 1e-8)
+        wb = w * dm.unsqueeze(1)
+        (wb * up.double()).sum().backward()
+        refs.append((wb.detach(), dm.detach()))
+    prep = ops.modfc_prep_x3_batch([(W.detach().to(d), s.detach().to(d)) for W, s in zip(Ws, ss)])
+    for (wbP, wbtP, dm_d), (wb, dm) in zip(prep, refs):
+        assert max_rel(dm_d, dm.float()) < 1e-5
+        assert rel_err(wbP.float(), wb.float()) < 2e-5
+        if wbtP is not None and wbtP.hi is not None:
+            assert rel_err(wbtP.float(), wb.float().transpose(1, 2)) < 2e-5
+    res = ops.modfc_prep_bwd_batch([(W.detach().to(d), s.detach().to(d), p[2], up.to(d)) for W, s, p, up in zip(Ws, ss, prep, ups)])
+    for (dW, ds), W, s in zip(res, Ws, ss):
+        assert rel_err(dW, W.grad) < 1e-4 and rel_err(ds, s.grad) < 1e-4
+
+
 def _planes(x):
     hi = x.bfloat16()
     lo = (x - hi.float()).bfloat16()
