@@ -15,6 +15,7 @@
 #include "common.h"
 #include "../../include/cips3d_hip.h"
 #include <stdlib.h>
+#include <utility>
 
 namespace {
 
@@ -244,6 +245,237 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_km_wide_kernel(KArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3: the same tile, LDS image, DMA pieces and fragment reads under the schedule of gemm_bf16x3_v3.hip —
+//   * the 12 operand fragments of a k-step live in TWO register sets: the transpose reads of k-step j+1 are issued
+//     between the MFMAs of k-step j (one fragment = two ds_read_b64_tr_b16 per two MFMAs) instead of as a 24-read burst
+//     in front of them (the two waves of a SIMD run in lockstep behind the barriers: neither covers the other's burst);
+//   * ONE barrier per k-tile, four MFMAs into its second k-step: it publishes k-tile t+1 (DMA'd a whole k-tile period
+//     earlier, not half of one) and frees the current stage for k-tile t+2, whose eight pieces follow one per two MFMAs.
+// Same MFMA order per accumulator as the kernel above: results are bit-identical.
+template <typename F, int... I>
+__device__ __forceinline__ void kstatic_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+// fragment order of a k-step: 0 a_lo[0], 1..4 b_hi[0..3], 5 a_lo[1], 6 a_hi[0], 7..10 b_lo[0..3], 11 a_hi[1]
+__device__ __forceinline__ constexpr bool kf_is_a(int q) { return q == 0 || q == 5 || q == 6 || q == 11; }
+__device__ __forceinline__ constexpr int kf_idx(int q) { return q == 0 || q == 6 ? 0 : q == 5 || q == 11 ? 1 : q <= 4 ? q - 1 : q - 7; }
+__device__ __forceinline__ constexpr int kf_plane(int q) { return q == 0 || q == 5 ? OFF_ALO : q == 6 || q == 11 ? OFF_AHI : q <= 4 ? OFF_BHI : OFF_BLO; }
+__device__ __forceinline__ constexpr int km_a(int m) { return (m >> 3) == 0 ? (((m >> 2) & 1) ? 5 : 0) : (((m >> 2) & 1) ? 11 : 6); }
+__device__ __forceinline__ constexpr int km_b(int m) { return (m >> 3) == 1 ? 7 + (m & 3) : 1 + (m & 3); }
+
+template <bool CONV>
+__global__ __launch_bounds__(512) void gemm_bf16x3_km_v3_kernel(KArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const cips_gemm_x3_desc& d = g.d;
+  const int tid = threadIdx.x;
+  const int lane0 = tid & 63;
+  const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = uw, wm = wave >> 1, wn = wave & 1;       // 4 x 2 waves, 64 x 128 outputs each
+  const int M = d.M, N = d.N;
+  const int nk_all = d.K / BK;
+  const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
+  for (int tseq = blockIdx.x; tseq < g.total; tseq += gridDim.x) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int l31 = lane & 31, hf = lane >> 5, s16 = lane & 15, mhalf = (lane >> 4) & 1;
+    int bid = tseq;
+    {
+      const int nx = 8;
+      int q = g.total / nx, r = g.total % nx;
+      int xcd = bid % nx, idx = bid / nx;
+      int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      bid = base + idx;
+    }
+    const int tn = bid % g.tiles_n;
+    const int tm = (bid / g.tiles_n) % g.tiles_m;
+    const int bz = (bid / (g.tiles_n * g.tiles_m)) % d.batch;
+    const int gi = bid / (g.tiles_n * g.tiles_m * d.batch);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int gp = CONV ? 0 : gi;
+    const long long kt0 = CONV ? (long long)bz * g.cv.ktiles / g.cv.nchunks : 0;
+    const int nk = CONV ? (int)((long long)(bz + 1) * g.cv.ktiles / g.cv.nchunks - kt0) : nk_all;     // >= 2 (host)
+    const u16* Ahi = (const u16*)g.A_hi[gp] + (CONV ? kt0 * BK * d.lda : (long long)bz * d.strideA);
+    const u16* Alo = (const u16*)g.A_lo[gp] + (CONV ? kt0 * BK * d.lda : (long long)bz * d.strideA);
+    const u16* Bhi = (const u16*)g.B_hi[gp] + (CONV ? 0 : (long long)bz * d.strideB);
+    const u16* Blo = (const u16*)g.B_lo[gp] + (CONV ? 0 : (long long)bz * d.strideB);
+    float* Cg = g.C[gp] + (CONV ? (long long)gi * d.M * d.ldc : 0);
+    const int tap_ky = CONV ? gi / g.cv.kw : 0, tap_kx = CONV ? gi - tap_ky * g.cv.kw : 0;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lh = lane >> 5, c16 = lane & 31;
+    unsigned offA[2], offB[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int k3 = 2 * par + lh;
+      const int pr = (c16 >> 1) ^ (2 * k3);
+      int m = m0 + (pr * 2 + (c16 & 1)) * 8, n = n0 + (pr * 2 + (c16 & 1)) * 8;
+      m = (m < M) ? m : 0;
+      n = (n < N) ? n : 0;
+      offA[par] = (unsigned)(lh * d.lda + m) * 2u;
+      offB[par] = (unsigned)(lh * d.ldb + n) * 2u;
+    }
+    auto dma = [&](const u16* p, unsigned off, unsigned la) {
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(p), "s"(la) : "memory");
+    };
+    unsigned colB[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) colB[par] = offB[par] - (unsigned)(lh * d.ldb) * 2u;
+    auto conv_row_off = [&](long long q, int par) -> unsigned {
+      const int hw = g.cv.Ho * g.cv.Wo;
+      const int b = (int)(q / hw), r = (int)(q - (long long)b * hw);
+      const int oy = r / g.cv.Wo, ox = r - oy * g.cv.Wo;
+      const int iy = oy * g.cv.stride - g.cv.pad + tap_ky, ix = ox * g.cv.stride - g.cv.pad + tap_kx;
+      const bool ok = (unsigned)iy < (unsigned)g.cv.H && (unsigned)ix < (unsigned)g.cv.W;
+      const long long row = ok ? ((long long)b * g.cv.H + iy) * g.cv.W + ix : g.cv.zero_row;
+      return (unsigned)(row * d.ldb * 2) + colB[par];
+    };
+    unsigned cvoff[2] = {0, 0};
+    auto conv_prep = [&](int k0) {
+      if constexpr (CONV) {
+        const long long qb = kt0 * BK + k0 + lh;
+        cvoff[0] = conv_row_off(qb + 2 * uw, uw & 1);
+        cvoff[1] = conv_row_off(qb + 2 * (uw + 8), uw & 1);
+      }
+    };
+    auto dma_piece = [&](int pc, int k0, unsigned st) {            // st: LDS byte offset of the stage
+      const int idx = uw + 8 * (pc >> 2), which = pc & 3;
+      const long long rowoff = (long long)(k0 + 2 * idx);
+      const unsigned la = sbase + st + (unsigned)idx * 1024u;
+      if (which == 0) dma(Ahi + rowoff * d.lda, offA[idx & 1], la + OFF_AHI);
+      else if (which == 1) dma(Alo + rowoff * d.lda, offA[idx & 1], la + OFF_ALO);
+      else if constexpr (CONV) dma(which == 2 ? Bhi : Blo, cvoff[pc >> 2], la + (which == 2 ? OFF_BHI : OFF_BLO));
+      else if (which == 2) dma(Bhi + rowoff * d.ldb, offB[idx & 1], la + OFF_BHI);
+      else dma(Blo + rowoff * d.ldb, offB[idx & 1], la + OFF_BLO);
+    };
+    auto fbase = [&](int colw, int ks) -> unsigned {
+      const int kb = 16 * ks + 8 * hf + (s16 >> 2);
+      const int col = colw + 16 * mhalf + 4 * (s16 & 3);
+      const int pr = (col >> 4) ^ (2 * (kb & 3));
+      return sbase + kb * ROW + pr * 32 + (col & 15) * 2;
+    };
+    unsigned fa[2][2], fb[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[ks][i] = fbase(wm * 64 + i * 32, ks);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[ks][j] = fbase(wn * 128 + j * 32, ks);
+    }
+    auto frag = [&](unsigned base, int off) -> bf16x8 {
+      short4v a = LDS_TR(base + off);
+      short4v b = LDS_TR(base + off + 4 * ROW);
+      short8v v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    bf16x8 F0[12], F1[12];
+    auto rd = [&](auto Q_, const unsigned (&A)[2], const unsigned (&B)[4]) -> bf16x8 {
+      constexpr int q = decltype(Q_)::value;
+      if constexpr (kf_is_a(q)) return frag(A[kf_idx(q)], kf_plane(q));
+      else return frag(B[kf_idx(q)], kf_plane(q));
+    };
+
+    // one k-tile.  MODE 0: steady state (DMA of k-tile kt+2, fragments of k-tile kt+1); 1: next-to-last (fragments only);
+    // 2: last
+    auto ktile = [&](auto MODE_, int kt) {
+      constexpr int MODE = decltype(MODE_)::value;
+      const unsigned cur = (unsigned)(kt & 1) * STAGE, nxt = STAGE - cur;
+      unsigned a1[2] = {fa[1][0] + cur, fa[1][1] + cur}, b1[4] = {fb[1][0] + cur, fb[1][1] + cur, fb[1][2] + cur, fb[1][3] + cur};
+      unsigned a0n[2] = {fa[0][0] + nxt, fa[0][1] + nxt}, b0n[4] = {fb[0][0] + nxt, fb[0][1] + nxt, fb[0][2] + nxt, fb[0][3] + nxt};
+      asm volatile("" : "+v"(a1[0]), "+v"(a1[1]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]));
+      asm volatile("" : "+v"(a0n[0]), "+v"(a0n[1]), "+v"(b0n[0]), "+v"(b0n[1]), "+v"(b0n[2]), "+v"(b0n[3]));
+      if constexpr (MODE == 0) conv_prep((kt + 2) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step a: MFMAs on set 0, the twelve fragments of k-step b into set 1 (one per two MFMAs)
+      kstatic_for(std::make_integer_sequence<int, 24>{}, [&](auto M_) {
+        constexpr int m = decltype(M_)::value;
+        acc[(m >> 2) & 1][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F0[km_a(m)], F0[km_b(m)], acc[(m >> 2) & 1][m & 3], 0, 0, 0);
+        if constexpr ((m & 1) == 0) {
+          constexpr int q = m >> 1;
+          F1[q] = rd(std::integral_constant<int, q>{}, a1, b1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // k-step b
+      kstatic_for(std::make_integer_sequence<int, 24>{}, [&](auto M_) {
+        constexpr int m = decltype(M_)::value;
+        acc[(m >> 2) & 1][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F1[km_a(m)], F1[km_b(m)], acc[(m >> 2) & 1][m & 3], 0, 0, 0);
+        if constexpr (m == 3) {
+          // every read of stage `cur` has returned, this wave's pieces of k-tile kt+1 have landed (issued a k-tile period
+          // ago): behind the barrier stage `nxt` is readable and `cur` writable
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if constexpr (MODE == 0) {
+          if constexpr (m >= 4 && m <= 18 && (m & 1) == 0) dma_piece((m - 4) >> 1, (kt + 2) * BK, cur);
+        }
+        if constexpr (MODE <= 1) {
+          if constexpr (m >= 5 && m <= 15 && (m & 1) == 1) {
+            constexpr int q = m - 5;
+            F0[q] = rd(std::integral_constant<int, q>{}, a0n, b0n);
+            F0[q + 1] = rd(std::integral_constant<int, q + 1>{}, a0n, b0n);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+
+    // ---- tile start: k-tiles 0 and 1 requested; k-tile 0 has landed everywhere; its first fragments
+    conv_prep(0);
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) dma_piece(pc, 0, 0);
+    conv_prep(BK);
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) dma_piece(pc, BK, STAGE);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    kstatic_for(std::make_integer_sequence<int, 12>{}, [&](auto Q_) { F0[decltype(Q_)::value] = rd(Q_, fa[0], fb[0]); });
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < nk - 2; ++kt) ktile(std::integral_constant<int, 0>{}, kt);
+    ktile(std::integral_constant<int, 1>{}, nk - 2);
+    ktile(std::integral_constant<int, 2>{}, nk - 1);
+    __syncthreads();
+
+    // ---- epilogue: 32 x 32 sub-tiles through a per-wave fp32 scratch (aliases stage 1), 16-byte row-contiguous stores
+    float* sc_f = reinterpret_cast<float*>(smem + STAGE) + wave * (32 * PF);
+    const long long cb = (long long)bz * d.strideC;
+    const int h_rr = lane >> 2, h_c8 = (lane & 3) * 8;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int si = st >> 2, jj = st & 3;
+      const int row0 = m0 + wm * 64 + si * 32, col0 = n0 + wn * 128 + jj * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc_f[mfma_row(r, hf) * PF + l31] = (st < 4 ? acc[0][jj][r] : acc[1][jj][r]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int row = row0 + h_rr + 16 * c, col = col0 + h_c8;
+        const float4 a = *reinterpret_cast<const float4*>(sc_f + (h_rr + 16 * c) * PF + h_c8);
+        const float4 b = *reinterpret_cast<const float4*>(sc_f + (h_rr + 16 * c) * PF + h_c8 + 4);
+        if (row < M && col < N) {
+          float* q = Cg + cb + (long long)row * d.ldc + col;
+          *reinterpret_cast<float4*>(q) = a;
+          *reinterpret_cast<float4*>(q + 4) = b;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+  }
+}
+
+// CIPS_X3_KMV3=0 keeps the round-2 schedule
+bool km_v3_on() {                      // read per call: scripts/bench_km.py and the tests flip it inside one process
+  const char* e = getenv("CIPS_X3_KMV3");
+  return !(e && atoi(e) == 0);
+}
+
 }  // namespace
 
 // Grouped entry: descs[0..ngroups) must agree in M, N, K, batch, leading dimensions and strides; only the operand
@@ -283,9 +515,13 @@ extern "C" int cips_gemm_bf16x3_km_grouped(const cips_gemm_x3_desc* descs, int n
     if (ncu <= 0) ncu = 256;
     ncu = (ncu / 8) * 8;
     (void)hipFuncSetAttribute((const void*)gemm_bf16x3_km_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_km_v3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
   }
   const int grid = g.total < ncu ? g.total : ncu;
-  hipLaunchKernelGGL(gemm_bf16x3_km_wide_kernel<false>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
+  if (km_v3_on() && d->K >= 2 * BK)
+    hipLaunchKernelGGL(gemm_bf16x3_km_v3_kernel<false>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(gemm_bf16x3_km_wide_kernel<false>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
   return CIPS_CHECK_LAUNCH();
 }
 
@@ -323,8 +559,12 @@ extern "C" int cips_conv2d_x3_wgrad(const cips_conv_wgrad_desc* c, cips_stream_t
     if (ncu <= 0) ncu = 256;
     ncu = (ncu / 8) * 8;
     (void)hipFuncSetAttribute((const void*)gemm_bf16x3_km_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_km_v3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
   }
   const int grid = g.total < ncu ? g.total : ncu;
-  hipLaunchKernelGGL(gemm_bf16x3_km_wide_kernel<true>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
+  if (km_v3_on() && g.cv.ktiles / g.cv.nchunks >= 2)          // every chunk has at least two k-tiles
+    hipLaunchKernelGGL(gemm_bf16x3_km_v3_kernel<true>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(gemm_bf16x3_km_wide_kernel<true>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
   return CIPS_CHECK_LAUNCH();
 }

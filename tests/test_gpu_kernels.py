@@ -580,6 +580,18 @@ def test_gemm_bf16x3_kmajor_wide(M, N, K, batch):
     print(f"bf16x3 k-major wide {M}x{N}x{K}x{batch}: rel err vs fp64 {e:.3e}")
     assert torch.isfinite(C).all() and e < 3e-5
     assert torch.equal(C, C2)
+    # the round-2 schedule of the same tile (CIPS_X3_KMV3=0): same MFMA order per accumulator, bit-identical output
+    import os
+    os.environ["CIPS_X3_KMV3"] = "0"
+    lib.cips_gemm_bf16x3_set_wide(2)
+    try:
+        C3 = torch.full((batch, M, N), float("nan"), device=d)
+        ops.gemm_x3_km(Ap, Bp, M, N, K, M, N, batch, K * M, K * N, C3)
+        torch.cuda.synchronize()
+    finally:
+        lib.cips_gemm_bf16x3_set_wide(-1)
+        os.environ.pop("CIPS_X3_KMV3", None)
+    assert torch.equal(C, C3)
 
 
 def test_gemm_bf16x3_kmajor_grouped():
