@@ -74,6 +74,7 @@ class GemmX3Desc(C.Structure):
         ("mask_out", vp), ("add", vp), ("rgb_g", vp), ("rgb_w", vp), ("C_unmasked", vp), ("mask", vp),
         ("act", i32), ("slope", f32), ("res_hi", vp), ("res_lo", vp), ("gate_bits", i32),
         ("torgb_w", vp), ("torgb_part", vp),
+        ("addp_hi", vp), ("addp_lo", vp), ("addp_gate", vp), ("addp_gain", f32),
     ]
 
 
@@ -114,6 +115,7 @@ SIGNATURES = {
     "cips_gemm_f32": (i32, [C.POINTER(GemmDesc), vp]),
     "cips_gemm_bf16x3": (i32, [C.POINTER(GemmX3Desc), vp]),
     "cips_gemm_bf16x3_fuses_torgb": (i32, [C.POINTER(GemmX3Desc)]),
+    "cips_gemm_bf16x3_takes_addp": (i32, [C.POINTER(GemmX3Desc)]),
     "cips_torgb_finish": (i32, [vp, i32, vp, vp, i64, i32, vp]),
     "cips_equal_linear_scratch": (i64, [i32, i32, i32, i32]),
     "cips_equal_linear": (i32, [i32, vp, vp, vp, f32, f32, vp, vp, i32, i32, i32, vp]),

@@ -657,7 +657,7 @@ extern "C" int cips_image_to_u8(const float* x, unsigned char* out, int B, int C
   return CIPS_CHECK_LAUNCH();
 }
 
-extern "C" int cips_version(void) { return 3; }
+extern "C" int cips_version(void) { return 4; }
 extern "C" const char* cips_arch(void) { return "gfx950"; }
 
 extern "C" int cips_fused_bias_act(const float* x, const float* bias, const float* refer, float* y,

@@ -784,6 +784,7 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
     }
   }
   if (d->torgb_w) return (int)hipErrorNotSupported;       // only the v3 kernel folds ToRGB in: never drop it silently
+  if (d->addp_hi) return (int)hipErrorNotSupported;       // ... and only it takes the addend as gated planes
   if (g_wide >= 2 || (g_wide == 1 && big)) {
     const int rc = cips_gemm_bf16x3_wide(d, stream);
     if (rc != (int)hipErrorNotSupported) return rc;
@@ -843,11 +844,20 @@ extern "C" int cips_gemm_bf16x3_fuses_torgb(const cips_gemm_x3_desc* d) {
   return cips_gemm_bf16x3_v3_accepts(d) == 0 ? 1 : 0;
 }
 
+extern "C" int cips_gemm_bf16x3_takes_addp(const cips_gemm_x3_desc* d) {
+  if (!d || !d->addp_hi) return 0;
+  if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }
+  if (g_v3 < 0) { const char* e = getenv("CIPS_X3_V3"); g_v3 = e ? atoi(e) : 1; }
+  const bool big = d->N >= 256 && d->M >= 256 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 256;
+  if (!(g_v3 && g_wide != 3 && (g_wide >= 2 || (g_wide == 1 && big)))) return 0;
+  return cips_gemm_bf16x3_v3_accepts(d) == 0 ? 1 : 0;
+}
+
 extern "C" int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t stream) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || !d->C) return (int)hipErrorInvalidValue;
   if ((d->K & 31) || (d->M & 7) || (d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
     return (int)hipErrorInvalidValue;
-  if (d->P_hi || d->T_hi || d->mask || d->add || d->rgb_g || d->C_unmasked || d->mask_out || d->res_hi || d->act)
+  if (d->P_hi || d->T_hi || d->mask || d->add || d->addp_hi || d->rgb_g || d->C_unmasked || d->mask_out || d->res_hi || d->act)
     return (int)hipErrorNotSupported;            // the K-major form has the plain fp32 epilogue only
   // square-ish outputs filling the chip with 256x256 tiles: the wide kernel (a single problem is a group of one)
   if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }

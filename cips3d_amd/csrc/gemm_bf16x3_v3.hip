@@ -76,7 +76,10 @@ __device__ __forceinline__ constexpr int mfma_b(int m) { return (m >> 3) == 1 ? 
 // RGBF: ToRGB forward folded in (descriptor fields torgb_w / torgb_part): per row and 128-column block the three partial
 // dot products of the final values with the ToRGB weights, accumulated over the wave's four column sub-blocks in
 // registers, reduced over the four lanes of a row with two DPP adds and stored as one float4 per row.
-template <bool HAS_ADD, bool HAS_MASK, bool HAS_RES, bool FAST, bool DBG = false, bool RGBF = false>
+// ADDP: the addend (HAS_ADD) arrives as the split planes of a gated tensor plus the bit plane of that gate (descriptor fields
+// addp_*): value = (hi + lo) * (bit ? 1 : addp_gain), same bytes in as the fp32 addend, and no C_unmasked copy is needed by
+// the next layer.
+template <bool HAS_ADD, bool HAS_MASK, bool HAS_RES, bool FAST, bool DBG = false, bool RGBF = false, bool ADDP = false>
 __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cips_gemm_x3_desc& d = g.d;
@@ -204,13 +207,22 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
     auto RS = [](int hs) -> int { return hs >> 2; };
     auto uoffC = [&](int hs) -> long long { return (long long)(((RS(hs) >> 1) * 32 + (RS(hs) & 1) * 16)) * d.ldc + JJ(hs) * 32; };
     auto uoffP = [&](int hs) -> long long { return (long long)(((RS(hs) >> 1) * 32 + (RS(hs) & 1) * 16)) * d.ldp + JJ(hs) * 32; };
-    struct Pre { float4 add[HAS_ADD ? 2 : 1]; float gg[HAS_ADD ? 3 : 1]; unsigned mask; uint4 rh, rl; };
+    struct Pre { float4 add[(HAS_ADD && !ADDP) ? 2 : 1]; float gg[HAS_ADD ? 3 : 1]; unsigned mask, amask; uint4 rh, rl; };      // rh / rl: residual planes (HAS_RES) or the planes addend (ADDP)
     const bool has_rgb = HAS_ADD && d.rgb_g != nullptr;
     auto prefetch = [&](int hs, Pre& p) {
       if constexpr (HAS_ADD) {
-        const char* q = (const char*)(d.add + cbase + uoffC(hs));
-        p.add[0] = *reinterpret_cast<const float4*>(q + eC * 4u);
-        p.add[1] = *reinterpret_cast<const float4*>(q + eC * 4u + 16);
+        if constexpr (ADDP) {
+          const char* qh = (const char*)((const u16*)d.addp_hi + pbase + uoffP(hs));
+          const char* ql = (const char*)((const u16*)d.addp_lo + pbase + uoffP(hs));
+          p.rh = *reinterpret_cast<const uint4*>(qh + eP * 2u);
+          p.rl = *reinterpret_cast<const uint4*>(ql + eP * 2u);
+          const unsigned char* q = (const unsigned char*)d.addp_gate + ((pbase + uoffP(hs)) >> 3);
+          p.amask = q[eP >> 3];
+        } else {
+          const char* q = (const char*)(d.add + cbase + uoffC(hs));
+          p.add[0] = *reinterpret_cast<const float4*>(q + eC * 4u);
+          p.add[1] = *reinterpret_cast<const float4*>(q + eC * 4u + 16);
+        }
         if (has_rgb) {
           const int row = m0 + wm * 64 + (RS(hs) >> 1) * 32 + (RS(hs) & 1) * 16 + h_rr;
           const float* gp = d.rgb_g + ((long long)bz * d.M + row) * 3;
@@ -332,8 +344,22 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
       Pre& cur = pre[hs % NPF];
       const long long uc = uoffC(hs), up = uoffP(hs);
       if constexpr (HAS_ADD) {
-        y[0] += cur.add[0].x; y[1] += cur.add[0].y; y[2] += cur.add[0].z; y[3] += cur.add[0].w;
-        y[4] += cur.add[1].x; y[5] += cur.add[1].y; y[6] += cur.add[1].z; y[7] += cur.add[1].w;
+        if constexpr (ADDP) {
+          const unsigned wh[4] = {cur.rh.x, cur.rh.y, cur.rh.z, cur.rh.w}, wl[4] = {cur.rl.x, cur.rl.y, cur.rl.z, cur.rl.w};
+          const unsigned am = cur.amask;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v0 = __uint_as_float(wh[e] << 16) + __uint_as_float(wl[e] << 16);
+            const float v1 = __uint_as_float(wh[e] & 0xffff0000u) + __uint_as_float(wl[e] & 0xffff0000u);
+            const int s0 = ((int)(am << (31 - 2 * e))) >> 31, s1 = ((int)(am << (30 - 2 * e))) >> 31;
+            const float t0 = v0 * d.addp_gain, t1 = v1 * d.addp_gain;
+            y[2 * e] += __int_as_float((s0 & __float_as_int(v0)) | (~s0 & __float_as_int(t0)));
+            y[2 * e + 1] += __int_as_float((s1 & __float_as_int(v1)) | (~s1 & __float_as_int(t1)));
+          }
+        } else {
+          y[0] += cur.add[0].x; y[1] += cur.add[0].y; y[2] += cur.add[0].z; y[3] += cur.add[0].w;
+          y[4] += cur.add[1].x; y[5] += cur.add[1].y; y[6] += cur.add[1].z; y[7] += cur.add[1].w;
+        }
         if (has_rgb) {                                       // rank-3 term: + g[row][0..2] . rgb_w[0..2][col..col+8]
           {
             const int col = n0 + wn * 128 + (hs & 3) * 32 + q2 * 8;
@@ -453,15 +479,15 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
 
 }  // namespace
 
-template <bool A, bool Mk, bool R, bool FAST, bool DBG = false, bool RGBF = false>
+template <bool A, bool Mk, bool R, bool FAST, bool DBG = false, bool RGBF = false, bool ADDP = false>
 static void launch_v3f(const VArgs& g, int grid, hipStream_t stream) {
   static bool attr = false;
   CIPS_PER_DEVICE(attr, false);
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_v3_kernel<A, Mk, R, FAST, DBG, RGBF>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16x3_v3_kernel<A, Mk, R, FAST, DBG, RGBF, ADDP>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x3_v3_kernel<A, Mk, R, FAST, DBG, RGBF>), dim3(grid), dim3(512), SMEM_BYTES, stream, g);
+  hipLaunchKernelGGL((gemm_bf16x3_v3_kernel<A, Mk, R, FAST, DBG, RGBF, ADDP>), dim3(grid), dim3(512), SMEM_BYTES, stream, g);
 }
 template <bool A, bool Mk, bool R>
 static void launch_v3(const VArgs& g, int grid, hipStream_t stream) {
@@ -471,6 +497,9 @@ static void launch_v3(const VArgs& g, int grid, hipStream_t stream) {
   const bool fast = d.P_hi != nullptr && d.C == nullptr && (fwd || bwd) && (A || d.C_unmasked == nullptr);
   if constexpr (!A && !Mk) {
     if (d.torgb_w) { launch_v3f<A, Mk, R, true, false, true>(g, grid, stream); return; }     // the entry point checked `fast`
+  }
+  if constexpr (A && Mk && !R) {
+    if (d.addp_hi) { launch_v3f<A, Mk, R, true, false, false, true>(g, grid, stream); return; }   // likewise
   }
   if (fast && g.dbg) launch_v3f<A, Mk, R, true, true>(g, grid, stream);
   else if (fast) launch_v3f<A, Mk, R, true>(g, grid, stream);
@@ -483,8 +512,12 @@ static int v3_accepts(const cips_gemm_x3_desc* d) {
   if ((d->M % BM) || (d->N % BN) || (d->K % (2 * BK))) return (int)hipErrorNotSupported;
   if ((d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7)) return (int)hipErrorInvalidValue;
   if (d->T_hi || (d->ldc & 3) || (d->strideC & 3) || (d->ldp & 31) || (d->strideP & 31)) return (int)hipErrorNotSupported;
-  const bool a = d->add != nullptr, m = d->mask != nullptr, r = d->res_hi != nullptr;
+  const bool a = d->add != nullptr || d->addp_hi != nullptr, m = d->mask != nullptr, r = d->res_hi != nullptr;
   if ((a && !m) || (r && (a || m))) return (int)hipErrorNotSupported;
+  if (d->addp_hi) {      // planes addend: the backward flavours' compile-time epilogue only
+    if (d->add || !d->addp_lo || !d->addp_gate || !(d->act == 0 && !d->mask_out && d->P_hi && !d->C)) return (int)hipErrorNotSupported;
+    if (((uintptr_t)d->addp_hi & 15) || ((uintptr_t)d->addp_lo & 15)) return (int)hipErrorNotSupported;
+  }
   if ((m && !(d->gate_bits & 1)) || (d->mask_out && !(d->gate_bits & 2))) return (int)hipErrorNotSupported;   // bit planes only
   if (d->rgb_g && !a) return (int)hipErrorNotSupported;
   if (d->mask_out && ((uintptr_t)d->mask_out & 3)) return (int)hipErrorNotSupported;                         // dword stores of the bit plane
@@ -503,7 +536,7 @@ extern "C" int cips_gemm_bf16x3_v3_accepts(const cips_gemm_x3_desc* d) { return 
 // every shape / epilogue it has no code for.
 extern "C" int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t stream) {
   { const int rc = v3_accepts(d); if (rc) return rc; }
-  const bool a = d->add != nullptr, m = d->mask != nullptr, r = d->res_hi != nullptr;
+  const bool a = d->add != nullptr || d->addp_hi != nullptr, m = d->mask != nullptr, r = d->res_hi != nullptr;
   VArgs g = {};
   g.d = *d;
   g.tiles_m = d->M / BM;

@@ -889,7 +889,7 @@ class Planes:
 
 def _x3_desc(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, T=None, ldt=0, strideT=0,
              mask_out=None, add=None, rgb_g=None, rgb_w=None, C_unmasked=None, mask=None, act=0, res=None, gate_bits=0,
-             torgb=None):
+             torgb=None, addp=None):
     d = GemmX3Desc()
     d.A_hi, d.A_lo, d.B_hi, d.B_lo = _p(A.hi), _p(A.lo), _p(Bm.hi), _p(Bm.lo)
     d.M, d.N, d.K, d.lda, d.ldb = M, N, K, lda, ldb
@@ -906,7 +906,16 @@ def _x3_desc(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, 
     d.gate_bits = gate_bits        # bit 0: `mask` is a uint8 bit plane (M, N/8); bit 1: `mask_out` is written as one
     if torgb is not None:          # (T (3, N), partials (N/128, batch*M, 4)): ToRGB forward folded into the epilogue
         d.torgb_w, d.torgb_part = _p(torgb[0]), _p(torgb[1])
+    if addp is not None:           # (Planes of a gated tensor, bit plane of that gate): the addend, un-gated on the fly
+        d.addp_hi, d.addp_lo, d.addp_gate, d.addp_gain = _p(addp[0].hi), _p(addp[0].lo), _p(addp[1]), 1.0 / LRELU_SLOPE
     return d
+
+
+def gemm_x3_takes_addp(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, **epi):
+    """True when the library runs this descriptor with the planes addend (256x256-tile kernel, interior shapes)"""
+    lib = _lib.load()
+    d = _x3_desc(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, **epi)
+    return bool(lib.cips_gemm_bf16x3_takes_addp(_ct.byref(d)))
 
 
 def gemm_x3(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, **epi):
@@ -1185,6 +1194,9 @@ INR_GATE_BITS = _os.environ.get("CIPS_INR_GATE_BITS", "1") != "0"
 INR_CHUNKS = int(_os.environ.get("CIPS_INR_CHUNKS", "1"))
 # ToRGB forward folded into the epilogue of the block's second GEMM (CIPS_TORGB_FUSED=0: the separate ToRGB kernel)
 TORGB_FUSED = _os.environ.get("CIPS_TORGB_FUSED", "1") != "0"
+# Backward: the skip gradient is re-read from the previous layer's GATED planes (un-gated on the fly with that gate's bit
+# plane) instead of from a separate fp32 copy the previous GEMM would have to write (CIPS_INR_ADDP=0: the fp32 copy)
+INR_ADDP = _os.environ.get("CIPS_INR_ADDP", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -1375,22 +1387,34 @@ class InrHeadX3Function(torch.autograd.Function):
             k = nblocks - 1
             gP, gT = Planes.empty(nb, n, width, device=dev), PT(width)
             Dout = None
+            # the skip gradient D (un-gated) is either kept as an fp32 copy next to the gated planes every GEMM writes
+            # for its successors, or — when every layer has bit-plane gates and the 256x256-tile kernel takes the shapes —
+            # recovered from those planes by the consumer (INR_ADDP): no copy written, same bytes read
+            addp = INR_ADDP and km and all(saved[j]["bits"] for j in range(nblocks))
+            if addp:
+                for j in range(1, nblocks):
+                    if saved[j]["skip"]:
+                        cj_in, cj_out = blocks[j][0].shape
+                        gq = Planes.empty(1, 8, 8, device=dev)
+                        addp = addp and gemm_x3_takes_addp(gq, gq, n, cj_in, cj_out, cj_out, cj_out, nb, n * cj_out, cj_in * cj_out,
+                                                           P=gq, addp=(gq, gq.hi), mask=gq.hi, gate_bits=1)
             if k >= 3:
                 # grad wrt out_k = drgb @ T_k as a K=32 zero-padded bf16x3 GEMM (gate of a2_k fused)
                 dpad = torch.zeros(nb, n, 32, device=dev); dpad[..., :3] = drgb_c
                 dP, _ = split_planes(dpad, want_t=False)
-                Dout = torch.empty(nb, n, width, device=dev) if saved[k]["skip"] else None
+                Dout = torch.empty(nb, n, width, device=dev) if saved[k]["skip"] and not addp else None
                 gemm_x3(dP, tP, n, width, 32, 32, 32, nb, n * 32, 0, P=gP, T=gT, ldt=n, strideT=width * n,
                         C_unmasked=Dout, mask=_bsl(saved[k]["m2"], b0, b1), gate_bits=1 if saved[k]["bits"] else 0)
             else:
                 gP.hi.zero_(); gP.lo.zero_()
                 if gT is not None:
                     gT.hi.zero_(); gT.lo.zero_()
-                Dout = torch.zeros(nb, n, width, device=dev) if saved[k]["skip"] else None
+                Dout = torch.zeros(nb, n, width, device=dev) if saved[k]["skip"] and not addp else None
             for k in range(nblocks - 1, -1, -1):
                 sv = saved[k]
                 W1, s1, W2, s2 = blocks[k]
                 cin, cout = W1.shape
+                gP_in = gP              # D_{k+1} gated by a2_k's gate: the planes form of the skip gradient
                 if k >= 3:
                     rgb_parts[k][ci] = torgb_bwd_w_x3(_bsl(sv["oP"], b0, b1), drgb2)
                 # ---- mod2: gradient through the gate of a1 ----
@@ -1426,10 +1450,11 @@ class InrHeadX3Function(torch.autograd.Function):
                     gemm_x3(g1P, _bsl(sv["wb1"], b0, b1), n, cin, cout, cout, cout, nb, n * cout, cin * cout, C=dx0[b0:b1])
                 else:
                     pv = saved[k - 1]
-                    newD = torch.empty(nb, n, cin, device=dev) if pv["skip"] else None
+                    newD = torch.empty(nb, n, cin, device=dev) if pv["skip"] and not addp else None
                     gP, gT = Planes.empty(nb, n, cin, device=dev), PT(cin)
                     gemm_x3(g1P, _bsl(sv["wb1"], b0, b1), n, cin, cout, cout, cout, nb, n * cout, cin * cout, P=gP, T=gT, ldt=n,
-                            strideT=cin * n, add=Dout if sv["skip"] else None,
+                            strideT=cin * n, add=Dout if sv["skip"] and not addp else None,
+                            addp=(gP_in, _bsl(sv["m2"], b0, b1)) if sv["skip"] and addp else None,
                             rgb_g=drgb2 if k - 1 >= 3 else None, rgb_w=rgbp[2 * (k - 1 - 3)] if k - 1 >= 3 else None,
                             C_unmasked=newD, mask=_bsl(pv["m2"], b0, b1), gate_bits=1 if pv["bits"] else 0)
                     Dout = newD

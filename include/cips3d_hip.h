@@ -288,11 +288,21 @@ typedef struct cips_gemm_x3_desc {
    * bias and (optionally) the running rgb.  Only the 256x256-tile v3 kernel implements it: cips_gemm_bf16x3 returns
    * hipErrorNotSupported for any other shape (use cips_torgb_fwd_x3 on the planes then). */
   const float* torgb_w; float* torgb_part;
+  /* The addend as the split planes of a GATED tensor (ABI 4): the skip gradient of the head's backward is the previous
+   * layer's un-gated gradient D, of which that layer already wrote the gated planes P = D * (gate ? 1 : slope) for its
+   * own GEMMs.  With addp_hi / addp_lo ([M][ldp] planes, batch stride strideP) and addp_gate (the bit plane of that
+   * gate, same layout as `mask` with gate_bits bit 0) set, the epilogue adds  (hi + lo) * (bit ? 1 : addp_gain)
+   * (addp_gain = 1 / slope) in place of `add` — D is recovered to the planes' 2^-17 relative precision and the
+   * producer need not write, nor this kernel read, a separate fp32 copy (C_unmasked / add: 2 x 4 bytes per element
+   * saved).  Exclusive with `add`; needs `mask` as a bit plane; v3 kernel only (hipErrorNotSupported elsewhere). */
+  const void* addp_hi; const void* addp_lo; const void* addp_gate; float addp_gain;
 } cips_gemm_x3_desc;
 
 int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream);
 /* 1 when cips_gemm_bf16x3 would run this descriptor on the v3 kernel (the only one with the fused ToRGB partials) */
 int cips_gemm_bf16x3_fuses_torgb(const cips_gemm_x3_desc* d);
+/* 1 when cips_gemm_bf16x3 would take this descriptor's planes addend (addp_*; v3 kernel only) */
+int cips_gemm_bf16x3_takes_addp(const cips_gemm_x3_desc* d);
 /* rgb[m][c] = (accumulate ? rgb[m][c] : 0) + bias[c] + sum_j part[j][m][c];  part (nblocks, M, 4), rgb (M, 3) */
 int cips_torgb_finish(const float* part, int nblocks, const float* bias, float* rgb, long long M, int accumulate,
                       cips_stream_t stream);

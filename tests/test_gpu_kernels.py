@@ -529,6 +529,54 @@ def test_gemm_bf16x3_wide(M, N, K, batch, flavour, tile_mode):
         lib.cips_gemm_bf16x3_set_wide(-1)
 
 
+@pytest.mark.parametrize("rgb", [False, True])
+@pytest.mark.parametrize("M,N,K,batch", [(4096, 512, 512, 20), (256, 256, 64, 3), (512, 256, 128, 2)])
+def test_gemm_bf16x3_planes_addend(M, N, K, batch, rgb):
+    """The skip gradient as the gated planes of the previous layer + the bit plane of that gate (descriptor fields
+    addp_*, 256x256-tile v3 kernel): value = (hi + lo) * (bit ? 1 : 1 / slope).  Against fp64 of the same sum, and
+    against the fp32-addend flavour fed the exact un-gated tensor (the planes carry it to 2^-17 relative)."""
+    from cips3d_amd import ops, _lib
+    lib = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K + batch + 5)
+    A = torch.randn(batch, M, K, generator=g); B = torch.randn(batch, N, K, generator=g) * 0.05
+    Ap = ops.Planes(*[t.to(d) for t in _planes(A)]); Bp = ops.Planes(*[t.to(d) for t in _planes(B)])
+    D = torch.randn(batch, M, N, generator=g)                               # the previous layer's un-gated gradient
+    pg = torch.randn(batch, M, N, generator=g) > 0                          # ... its gate
+    gated = D * torch.where(pg, 1.0, 0.2)
+    Dp = ops.Planes(*[t.to(d) for t in _planes(gated)])
+    pgb = _pack_bits(pg).to(d)
+    gate = torch.randn(batch, M, N, generator=g) > 0                        # this layer's gate
+    gb = _pack_bits(gate).to(d)
+    rg = torch.randn(batch * M, 3, generator=g).to(d) if rgb else None
+    rw = torch.randn(3, N, generator=g).to(d) if rgb else None
+    lib.cips_gemm_bf16x3_set_wide(2)
+    try:
+        kw = dict(mask=gb, gate_bits=1, rgb_g=rg, rgb_w=rw)
+        assert ops.gemm_x3_takes_addp(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=ops.Planes.empty(batch, M, N, device=d),
+                                      addp=(Dp, pgb), **kw)
+        P1 = ops.Planes.empty(batch, M, N, device=d)
+        P1.hi.fill_(float("nan")); P1.lo.fill_(float("nan"))
+        ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P1, addp=(Dp, pgb), **kw)
+        P0 = ops.Planes.empty(batch, M, N, device=d); CU = torch.empty(batch, M, N, device=d)
+        ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P0, add=D.to(d), C_unmasked=CU, **kw)
+        torch.cuda.synchronize()
+    finally:
+        lib.cips_gemm_bf16x3_set_wide(-1)
+    want = torch.bmm(A.double(), B.double().transpose(1, 2)) + D.double()
+    if rgb:
+        want = want + (rg.cpu().double() @ rw.cpu().double()).view(batch, M, N)
+    want = want * torch.where(gate, 1.0, 0.2).double()
+    e1, e0 = rel_err(P1.float(), want), rel_err(P0.float(), want)
+    print(f"planes addend {M}x{N}x{K}x{batch} rgb={rgb}: rel err {e1:.3e} (fp32 addend {e0:.3e})")
+    assert torch.isfinite(P1.float()).all() and e1 < 3e-5 and e1 < 2.0 * e0 + 1e-6
+    # a shape the 256x256-tile kernel does not take: refused, loudly
+    A2 = ops.Planes(Ap.hi[:, :160].contiguous(), Ap.lo[:, :160].contiguous())
+    assert not ops.gemm_x3_takes_addp(A2, Bp, 160, N, K, K, K, batch, 160 * K, N * K, P=P1, addp=(Dp, pgb), **kw)
+    with pytest.raises(RuntimeError):
+        ops.gemm_x3(A2, Bp, 160, N, K, K, K, batch, 160 * K, N * K, P=P1, addp=(Dp, pgb), **kw)
+
+
 @pytest.mark.parametrize("res", [False, True])
 @pytest.mark.parametrize("M,N,K,batch,acc", [(4096, 512, 512, 20, False), (256, 256, 64, 3, True), (300, 256, 64, 2, False)])
 def test_gemm_bf16x3_fused_torgb(M, N, K, batch, acc, res):
