@@ -474,6 +474,54 @@ __global__ __launch_bounds__(256) void torgb_bwd_x_kernel(const float* __restric
   }
 }
 
+// Split-plane form of the same: P (hi, lo planes) = (drgb @ w) * (gate bit ? 1 : slope), gate as a BIT plane (bit k&7 of byte
+// [m][k>>3]; NULL: no gate), optional fp32 copy before gating.  One lane = 8 consecutive columns: 3 scalars of drgb, one gate
+// byte, two 16-byte stores — a pure 4-bytes-per-element write stream (the round-2 path ran this rank-3 product as a K = 32
+// zero-padded bf16x3 GEMM: 138 us + two padding kernels for 268 MB of output at C2; the sums here are exact fp32).
+__global__ __launch_bounds__(256) void torgb_bwd_x_x3_kernel(const float* __restrict__ drgb, const float* __restrict__ w,
+                                                             const unsigned char* __restrict__ gate, float slope,
+                                                             float* __restrict__ out_unmasked, u16* __restrict__ ph,
+                                                             u16* __restrict__ pl, long long M, int K) {
+  const int k8 = K / 8;
+  const long long total = M * k8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / k8;
+    const int k = (int)(i - m * k8) * 8;
+    const float g0 = drgb[m * 3 + 0], g1 = drgb[m * 3 + 1], g2 = drgb[m * 3 + 2];
+    float v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4 w0 = *reinterpret_cast<const float4*>(w + k + 4 * h);
+      const float4 w1 = *reinterpret_cast<const float4*>(w + K + k + 4 * h);
+      const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * K + k + 4 * h);
+      v[4 * h + 0] = fmaf(g0, w0.x, fmaf(g1, w1.x, g2 * w2.x));
+      v[4 * h + 1] = fmaf(g0, w0.y, fmaf(g1, w1.y, g2 * w2.y));
+      v[4 * h + 2] = fmaf(g0, w0.z, fmaf(g1, w1.z, g2 * w2.z));
+      v[4 * h + 3] = fmaf(g0, w0.w, fmaf(g1, w1.w, g2 * w2.w));
+    }
+    const long long e = m * K + k;
+    if (out_unmasked) {
+      *reinterpret_cast<float4*>(out_unmasked + e) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out_unmasked + e + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (gate) {
+      const unsigned gb = gate[e >> 3];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] *= ((gb >> q) & 1u) ? 1.f : slope;
+    }
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u16 h0 = f2bf_rne(v[2 * q]), h1 = f2bf_rne(v[2 * q + 1]);
+      const u16 l0 = f2bf_rne(v[2 * q] - __uint_as_float(((unsigned)h0) << 16)), l1 = f2bf_rne(v[2 * q + 1] - __uint_as_float(((unsigned)h1) << 16));
+      hw[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+      lw[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+    *reinterpret_cast<uint4*>(ph + e) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+    *reinterpret_cast<uint4*>(pl + e) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+  }
+}
+
 
 // ---- batched forms: every modulated-FC layer of the CIPS head in ONE launch --------------------------------
 // The per-layer kernels above are a few microseconds of work each; 18 layers x (2 + 3) launches per step cost more
@@ -890,6 +938,16 @@ extern "C" int cips_torgb_bwd_x(const float* drgb, const float* w, const float* 
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(torgb_bwd_x_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, drgb, w, add,
                      mask, slope, out_unmasked, out, M, K);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_torgb_bwd_x_x3(const float* drgb, const float* w, const void* gate_bits, float slope, float* out_unmasked,
+                                   void* p_hi, void* p_lo, long long M, int K, cips_stream_t stream) {
+  if (!drgb || !w || !p_hi || !p_lo || M <= 0 || K <= 0 || (K & 7)) return (int)hipErrorInvalidValue;
+  long long blocks = (M * (K / 8) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(torgb_bwd_x_x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, drgb, w,
+                     (const unsigned char*)gate_bits, slope, out_unmasked, (u16*)p_hi, (u16*)p_lo, M, K);
   return CIPS_CHECK_LAUNCH();
 }
 

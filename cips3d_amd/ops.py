@@ -659,6 +659,14 @@ def torgb_bwd_w(x2d, drgb2d):
     return dw, db
 
 
+def torgb_bwd_x_x3(drgb2d, w, gate_bits, out_unmasked, P):
+    """P (Planes (.., K)) = (drgb2d (M,3) @ w (3,K)) * (gate bit ? 1 : slope); out_unmasked: optional fp32 copy before gating"""
+    lib = _lib.load()
+    M, K = drgb2d.shape[0], w.shape[1]
+    check(lib.cips_torgb_bwd_x_x3(_p(drgb2d), _p(_c(w)), _p(gate_bits), LRELU_SLOPE, _p(out_unmasked), _p(P.hi), _p(P.lo), M, K,
+                                  _stream()), "cips_torgb_bwd_x_x3")
+
+
 def torgb_bwd_x(drgb2d, w, add, mask, out_unmasked, out):
     lib = _lib.load()
     M = drgb2d.shape[0]
@@ -1197,6 +1205,8 @@ TORGB_FUSED = _os.environ.get("CIPS_TORGB_FUSED", "1") != "0"
 # Backward: the skip gradient is re-read from the previous layer's GATED planes (un-gated on the fly with that gate's bit
 # plane) instead of from a separate fp32 copy the previous GEMM would have to write (CIPS_INR_ADDP=0: the fp32 copy)
 INR_ADDP = _os.environ.get("CIPS_INR_ADDP", "1") != "0"
+# the ToRGB tap's gradient into the last block's output as one streaming kernel (0: the K=32 zero-padded GEMM of round 2)
+TORGB_BWDX_STREAM = _os.environ.get("CIPS_TORGB_BWDX_STREAM", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -1398,8 +1408,14 @@ class InrHeadX3Function(torch.autograd.Function):
                         gq = Planes.empty(1, 8, 8, device=dev)
                         addp = addp and gemm_x3_takes_addp(gq, gq, n, cj_in, cj_out, cj_out, cj_out, nb, n * cj_out, cj_in * cj_out,
                                                            P=gq, addp=(gq, gq.hi), mask=gq.hi, gate_bits=1)
-            if k >= 3:
-                # grad wrt out_k = drgb @ T_k as a K=32 zero-padded bf16x3 GEMM (gate of a2_k fused)
+            if k >= 3 and km and saved[k]["bits"] and width % 8 == 0 and TORGB_BWDX_STREAM:
+                # grad wrt out_k = drgb @ T_k (rank 3), gate of a2_k fused: one streaming kernel writing the planes
+                Dout = torch.empty(nb, n, width, device=dev) if saved[k]["skip"] and not addp else None
+                torgb_bwd_x_x3(drgb2, rgbp[2 * (k - 3)], _bsl(saved[k]["m2"], b0, b1), Dout, gP)
+            elif k >= 3:
+                # ... as a K=32 zero-padded bf16x3 GEMM where the transposed planes are wanted too
+                tpad = torch.zeros(1, width, 32, device=dev); tpad[0, :, :3] = rgbp[2 * (k - 3)].t()
+                tP, _ = split_planes(tpad, want_t=False)
                 dpad = torch.zeros(nb, n, 32, device=dev); dpad[..., :3] = drgb_c
                 dP, _ = split_planes(dpad, want_t=False)
                 Dout = torch.empty(nb, n, width, device=dev) if saved[k]["skip"] and not addp else None

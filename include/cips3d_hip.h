@@ -447,6 +447,10 @@ int cips_torgb_bwd_w_x3(const void* x_hi, const void* x_lo, const float* drgb, f
  * (the LeakyReLU gate of the layer below, fused).  mask / add / out_unmasked may be NULL. */
 int cips_torgb_bwd_x(const float* drgb, const float* w, const float* add, const float* mask, float slope,
                      float* out_unmasked, float* out, long long M, int K, cips_stream_t stream);
+/* the same with split-plane output and the gate as a bit plane (bit k&7 of byte [m][k>>3]; NULL: none):
+ * p_hi / p_lo (M, K) bf16 planes of (drgb @ w) * (bit ? 1 : slope); out_unmasked: optional fp32 copy before gating.  K % 8 == 0. */
+int cips_torgb_bwd_x_x3(const float* drgb, const float* w, const void* gate_bits, float slope, float* out_unmasked,
+                        void* p_hi, void* p_lo, long long M, int K, cips_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* H5  discriminator native ops                                        */

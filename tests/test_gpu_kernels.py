@@ -529,6 +529,27 @@ def test_gemm_bf16x3_wide(M, N, K, batch, flavour, tile_mode):
         lib.cips_gemm_bf16x3_set_wide(-1)
 
 
+@pytest.mark.parametrize("M,K,gated,copy", [(4096 * 3, 512, True, False), (1000, 64, True, True), (77, 40, False, True)])
+def test_torgb_bwd_x_split_planes(M, K, gated, copy):
+    """dx = drgb @ T as split planes with the LeakyReLU gate (bit plane) of the layer below fused
+    (generator.py:949-1006 backward: the ToRGB tap's gradient into the block output)"""
+    from cips3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(M + K)
+    drgb = torch.randn(M, 3, generator=g); T = torch.randn(3, K, generator=g)
+    gate = torch.randn(M, K, generator=g) > 0
+    P = ops.Planes.empty(M, K, device=d)
+    cu = torch.full((M, K), float("nan"), device=d) if copy else None
+    ops.torgb_bwd_x_x3(drgb.to(d), T.to(d), _pack_bits(gate).to(d) if gated else None, cu, P)
+    torch.cuda.synchronize()
+    want = drgb.double() @ T.double()
+    if copy:
+        assert rel_err(cu, want) < 1e-6
+    if gated:
+        want = want * torch.where(gate, 1.0, 0.2).double()
+    assert rel_err(P.float(), want) < 1e-5
+
+
 @pytest.mark.parametrize("rgb", [False, True])
 @pytest.mark.parametrize("M,N,K,batch", [(4096, 512, 512, 20), (256, 256, 64, 3), (512, 256, 128, 2)])
 def test_gemm_bf16x3_planes_addend(M, N, K, batch, rgb):
