@@ -337,7 +337,10 @@ class CIPSNet(nn.Module):
                                    for name in names for j, m in enumerate((self.network[name].mod1, self.network[name].mod2))])
         for k, name in enumerate(names):
             blk = self.network[name]
-            params += [blk.mod1.weight[0], mods[2 * k], blk.mod2.weight[0], mods[2 * k + 1]]
+            # (1, in, out) -> (in, out) as a VIEW: indexing with [0] makes autograd materialise a zero-filled (1, in, out)
+            # buffer and copy the gradient into it, 18 x (fill + 1 MiB copy) per step
+            w1, w2 = blk.mod1.weight, blk.mod2.weight
+            params += [w1.view(w1.shape[1], w1.shape[2]), mods[2 * k], w2.view(w2.shape[1], w2.shape[2]), mods[2 * k + 1]]
         for idx, name in enumerate(names):
             if idx >= 3:
                 params += [self.to_rgbs[name].linear.weight, self.to_rgbs[name].linear.bias]

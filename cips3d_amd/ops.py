@@ -1382,12 +1382,6 @@ class InrHeadX3Function(torch.autograd.Function):
         dx0 = torch.empty(B, n, cin0, device=dev)
         ranges = _chunk_ranges(B)
         rgb_parts = [[None] * len(ranges) for _ in range(nblocks)]
-        tpad = None
-        if nblocks - 1 >= 3:
-            T = rgbp[2 * (nblocks - 1 - 3)]
-            tpad = torch.zeros(1, width, 32, device=dev); tpad[0, :, :3] = T.t()
-            tP, _ = split_planes(tpad, want_t=False)
-
         def run(b0, b1):
             nb = b1 - b0
             ci = [r[0] for r in ranges].index(b0)

@@ -24,10 +24,16 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
 ev = prof.events()
 cnt = collections.Counter()
 for e in ev:
-    n = e.name
-    if ("copy" in n.lower() or "Memcpy" in n or "fill" in n.lower() or "clone" in n or "zero" in n) and e.device_type.name == "CPU":
-        shp = str(e.input_shapes)[:60]
-        st = [s for s in (e.stack or []) if "cips3d_amd" in s or "bench" in s or "find_copies" in s]
-        cnt[(n, shp, st[0][-70:] if st else "-")] += 1
-for (n, shp, st), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:45]:
-    print(f"{c:4d}  {n:28s} {shp:60s} {st}")
+    if e.device_type.name != "CPU" or not e.kernels:
+        continue
+    kn = [k.name for k in e.kernels]
+    tag = "memcpy" if any("copyBuffer" in k or "Memcpy" in k for k in kn) else "fill" if any("FillFunctor" in k for k in kn) else None
+    if tag is None:
+        continue
+    chain, q = [], e.cpu_parent
+    while q is not None:
+        chain.append(q.name[:48]); q = q.cpu_parent
+    cnt[(tag, e.name, str(e.input_shapes)[:50], " < ".join(chain[:4]))] += 1
+for (tag, n, shp, ch), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:60]:
+    print(f"{c:4d} {tag:6s} {n:22s} {shp:50s} {ch}")
+print("total", sum(cnt.values()))
