@@ -100,20 +100,22 @@ def gemm_roofline(dev, b, n, mode):
     oP = ops.Planes.empty(b, n, 512, device=dev)
     bits = torch.empty(b, n, 64, device=dev, dtype=torch.uint8)
     gate = (torch.rand(b, n, 64, device=dev) * 256).to(torch.uint8)
-    add = torch.randn(b, n, 512, device=dev)
-    cu = torch.empty(b, n, 512, device=dev)
     rg = torch.randn(b * n, 3, device=dev)
     rw = torch.randn(3, 512, device=dev)
     G = lambda **kw: ops.gemm_x3(xP, wP, n, 512, 512, 512, 512, b, n * 512, 512 * 512, P=oP, **kw)
     # (name, launches per G fwd+bwd step at 9 blocks, callable, algorithmic HBM bytes per launch)
     nbits = b * n * 64
+    part = torch.empty(4, b * n, 4, device=dev)          # ToRGB partials of the fused forward flavours (N / 128 blocks)
     flav = [
-        ("fwd: lrelu, gate bits out, planes out  <ADD0,MASK0,RES0>", 13, lambda: G(act=1, mask_out=bits, gate_bits=2),
+        ("fwd: lrelu, gate bits out, planes out  <ADD0,MASK0,RES0>", 11, lambda: G(act=1, mask_out=bits, gate_bits=2),
          2 * act_b + w_b + nbits),
-        ("fwd + residual planes  <0,0,1>", 5, lambda: G(act=1, res=xP, mask_out=bits, gate_bits=2), 3 * act_b + w_b + nbits),
-        ("dX: gate bits in, planes out  <0,1,0>", 13, lambda: G(mask=gate, gate_bits=1), 2 * act_b + w_b + nbits),
-        ("dX + skip addend + ToRGB term + unmasked copy + gate  <1,1,0>", 5,
-         lambda: G(add=add, rgb_g=rg, rgb_w=rw, C_unmasked=cu, mask=gate, gate_bits=1), 4 * act_b + w_b + nbits),
+        ("fwd + ToRGB partials  <0,0,0,RGBF>", 1, lambda: G(act=1, mask_out=bits, gate_bits=2, torgb=(rw, part)),
+         2 * act_b + w_b + nbits + part.numel() * 4),
+        ("fwd + residual planes + ToRGB partials  <0,0,1,RGBF>", 5,
+         lambda: G(act=1, res=xP, mask_out=bits, gate_bits=2, torgb=(rw, part)), 3 * act_b + w_b + nbits + part.numel() * 4),
+        ("dX: gate bits in, planes out  <0,1,0>", 12, lambda: G(mask=gate, gate_bits=1), 2 * act_b + w_b + nbits),
+        ("dX + skip addend (previous layer's gated planes, un-gated on the fly) + ToRGB term + gate  <1,1,0,ADDP>", 5,
+         lambda: G(addp=(xP, gate), rgb_g=rg, rgb_w=rw, mask=gate, gate_bits=1), 3 * act_b + w_b + 2 * nbits),
     ]
     rows, tot_t, tot_f = [], 0.0, 0.0
     for name, count, fn, bytes_ in flav:
@@ -125,7 +127,7 @@ def gemm_roofline(dev, b, n, mode):
         tot_f += count * flops
     ach = tot_f / tot_t / 1e12
     r = {"bound": "mfma", "kernel": "gemm_bf16x3_v3_kernel family (modfc 512x512 layer GEMMs of the CIPS head, 256x256 tiles): "
-                                    "launch-count-weighted over the four epilogue flavours of the step",
+                                    "launch-count-weighted over the five epilogue flavours of the step",
          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
          "traffic": None, "launch_us": round(tot_t / sum(f[1] for f in flav) * 1e6, 1), "flops_per_launch": flops,
          "hbm_frac": round(sum(f[1] * f[3] for f in flav) / tot_t / 1e12 / HBM_PEAK_TBS, 4),

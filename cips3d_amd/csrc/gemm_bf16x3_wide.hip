@@ -469,6 +469,208 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
   }  // persistent tile loop
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3: the implicit-GEMM convolution under the two-register-set schedule of gemm_bf16x3_v3.hip (the 12 fragments of
+// k-step j+1 are read between the MFMAs of k-step j; one barrier per k-tile, four MFMAs into its second k-step; the DMA of
+// k-tile t+2 follows that barrier).  Same tile, LDS image, gather addressing (make_src / prep_b above) and MFMA order per
+// accumulator as the CONV instantiation of the kernel above: bit-identical outputs.  A convolution's contraction is long
+// (9 C / 32 k-tiles), so tiles do not overlap here: k-tiles 0 and 1 are requested at the tile start.
+__device__ __forceinline__ constexpr bool cq_is_a(int q) { return q == 0 || q == 5 || q == 6 || q == 11; }
+__device__ __forceinline__ constexpr int cq_off(int q) {
+  return q == 0 ? OFF_ALO : q == 5 ? OFF_ALO + 32 * ROWB : q == 6 ? OFF_AHI : q == 11 ? OFF_AHI + 32 * ROWB
+       : q <= 4 ? OFF_BHI + (q - 1) * 32 * ROWB : OFF_BLO + (q - 7) * 32 * ROWB;
+}
+__device__ __forceinline__ constexpr int cm_a(int m) { return (m >> 3) == 0 ? (((m >> 2) & 1) ? 5 : 0) : (((m >> 2) & 1) ? 11 : 6); }
+__device__ __forceinline__ constexpr int cm_b(int m) { return (m >> 3) == 1 ? 7 + (m & 3) : 1 + (m & 3); }
+
+__global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const cips_gemm_x3_desc& d = g.d;
+  const int tid = threadIdx.x;
+  const int lane0 = tid & 63;
+  const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = uw, wm = wave >> 1, wn = wave & 1;
+  const int M = d.M, N = d.N;
+  const int nk_all = d.K / BK;
+  const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
+  const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  auto chunk_kt0 = [&](int kc) -> int { return (int)((long long)kc * nk_all / ksplit); };
+
+  for (int tseq = blockIdx.x; tseq < g.total; tseq += gridDim.x) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int l31 = lane & 31, hf = lane >> 5;
+    int tm, tn, bz, kc;
+    {
+      const int nx = 8;
+      int q = g.total / nx, r = g.total % nx;
+      int xcd = tseq % nx, idx = tseq / nx;
+      int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      const int bid = base + idx;
+      tn = bid % g.tiles_n;
+      tm = (bid / g.tiles_n) % g.tiles_m;
+      const int bk = bid / (g.tiles_n * g.tiles_m);
+      kc = bk % ksplit;
+      bz = bk / ksplit;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbase = chunk_kt0(kc) * BK;
+    const int nk = chunk_kt0(kc + 1) - chunk_kt0(kc);          // >= 2 (host)
+    // ---- sources: weights (A) row-major [O][kh*kw*C]; pixels (B) gathered per tap from the NHWC planes of image bz
+    const u16* Ahi = (const u16*)d.A_hi + (long long)m0 * d.lda + kbase;
+    const u16* Alo = (const u16*)d.A_lo + (long long)m0 * d.lda + kbase;
+    const u16* Bhi = (const u16*)d.B_hi + (long long)bz * g.cv.img_stride;
+    const u16* Blo = (const u16*)d.B_lo + (long long)bz * g.cv.img_stride;
+    const unsigned zero_rel = (unsigned)((g.cv.zero_elem - (long long)bz * g.cv.img_stride) * 2);
+    unsigned offA[2], offB[2], chunk[2];
+    int iy0[2], ix0[2];
+    {
+      const int drow = lane >> 2, dslot = lane & 3;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = (uw + 8 * p) * 16 + drow;
+        const int kcsw = dslot ^ ((row >> 2) & 3);
+        const int ra = (row < M - m0) ? row : (M - m0 - 1), rb = (row < N - n0) ? row : (N - n0 - 1);
+        offA[p] = (unsigned)(ra * d.lda + kcsw * 8) * 2u;
+        const int pix = n0 + rb, oy = pix / g.cv.Wo, ox = pix - oy * g.cv.Wo;
+        iy0[p] = oy * g.cv.stride - g.cv.pad;
+        ix0[p] = ox * g.cv.stride - g.cv.pad;
+        chunk[p] = (unsigned)kcsw * 16u;
+      }
+    }
+    auto prep_b = [&](int k0) {                                // refresh the two per-lane B offsets for k-tile k0
+      const int kk = k0 + kbase;
+      const int tap = kk / g.cv.C, c0 = kk - tap * g.cv.C;
+      const int ky = tap / g.cv.kw, kx = tap - ky * g.cv.kw;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int iy = iy0[p] + ky, ix = ix0[p] + kx;
+        const bool ok = (unsigned)iy < (unsigned)g.cv.H && (unsigned)ix < (unsigned)g.cv.W;
+        offB[p] = (ok ? (unsigned)(((iy * g.cv.W + ix) * g.cv.C + c0) * 2) : zero_rel) + chunk[p];
+      }
+    };
+    auto dma = [&](const u16* plane_k, unsigned off, unsigned la) {
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(plane_k), "s"(la) : "memory");
+    };
+    auto dma_piece = [&](int pc, int k0, unsigned st) {        // uses offB of the last prep_b
+      const int pp = pc >> 2, which = pc & 3;
+      const unsigned la = sbase + st + (unsigned)((uw + 8 * pp) * 16 * ROWB);
+      if (which == 0) dma(Ahi + k0, offA[pp], la + OFF_AHI);
+      else if (which == 1) dma(Alo + k0, offA[pp], la + OFF_ALO);
+      else if (which == 2) dma(Bhi, offB[pp], la + OFF_BHI);
+      else dma(Blo, offB[pp], la + OFF_BLO);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int csw = (l31 >> 2) & 3;
+    const unsigned fa0 = sbase + (wm * 64 + l31) * ROWB + ((hf ^ csw) << 4), fa1 = sbase + (wm * 64 + l31) * ROWB + (((2 + hf) ^ csw) << 4);
+    const unsigned fb0 = sbase + (wn * 128 + l31) * ROWB + ((hf ^ csw) << 4), fb1 = sbase + (wn * 128 + l31) * ROWB + (((2 + hf) ^ csw) << 4);
+    bf16x8 F0[12], F1[12];
+
+    auto ktile = [&](auto MODE_, int kt) {                     // MODE 0 steady, 1 next-to-last, 2 last
+      constexpr int MODE = decltype(MODE_)::value;
+      const unsigned cur = (unsigned)(kt & 1) * STAGE, nxt = STAGE - cur;
+      unsigned a1 = fa1 + cur, b1 = fb1 + cur, a0n = fa0 + nxt, b0n = fb0 + nxt;
+      asm volatile("" : "+v"(a1), "+v"(b1), "+v"(a0n), "+v"(b0n));
+      if constexpr (MODE == 0) prep_b((kt + 2) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for(std::make_integer_sequence<int, 24>{}, [&](auto M_) {
+        constexpr int m = decltype(M_)::value;
+        acc[(m >> 2) & 1][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F0[cm_a(m)], F0[cm_b(m)], acc[(m >> 2) & 1][m & 3], 0, 0, 0);
+        if constexpr ((m & 1) == 0) {
+          constexpr int q = m >> 1;
+          F1[q] = LDS_B128((cq_is_a(q) ? a1 : b1) + cq_off(q));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      static_for(std::make_integer_sequence<int, 24>{}, [&](auto M_) {
+        constexpr int m = decltype(M_)::value;
+        acc[(m >> 2) & 1][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F1[cm_a(m)], F1[cm_b(m)], acc[(m >> 2) & 1][m & 3], 0, 0, 0);
+        if constexpr (m == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (MODE == 0) {
+          if constexpr (m >= 4 && m <= 18 && (m & 1) == 0) dma_piece((m - 4) >> 1, (kt + 2) * BK, cur);
+        }
+        if constexpr (MODE <= 1) {
+          if constexpr (m >= 5 && m <= 15 && (m & 1) == 1) {
+            constexpr int q = m - 5;
+            F0[q] = LDS_B128((cq_is_a(q) ? a0n : b0n) + cq_off(q));
+            F0[q + 1] = LDS_B128((cq_is_a(q + 1) ? a0n : b0n) + cq_off(q + 1));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+
+    prep_b(0);
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) dma_piece(pc, 0, 0);
+    prep_b(BK);
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) dma_piece(pc, BK, STAGE);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 12; ++q) F0[q] = LDS_B128((cq_is_a(q) ? fa0 : fb0) + cq_off(q));
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < nk - 2; ++kt) ktile(std::integral_constant<int, 0>{}, kt);
+    ktile(std::integral_constant<int, 1>{}, nk - 2);
+    ktile(std::integral_constant<int, 2>{}, nk - 1);
+    __syncthreads();
+
+    // ---- epilogue: bias + FusedLeakyReLU (unsplit launches), fp32 rows of 8 through the per-wave scratch (stage 1)
+    const long long cb = ((long long)kc * d.batch + bz) * d.strideC;
+    float* sc_f = reinterpret_cast<float*>(smem + STAGE + wave * SCR_WAVE);
+    const int h_rr = lane >> 2, h_c8 = (lane & 3) * 8;
+    float cbias[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (g.cv.bias) {
+#pragma unroll
+      for (int si = 0; si < 2; ++si)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int row = m0 + wm * 64 + si * 32 + h_rr + 16 * c;
+          cbias[si][c] = g.cv.bias[row < M ? row : M - 1];
+        }
+    }
+    static_for(std::make_integer_sequence<int, 8>{}, [&](auto ST) {
+      constexpr int st = decltype(ST)::value, si = st >> 2, jj = st & 3;
+      const int row0 = m0 + wm * 64 + si * 32, col0 = n0 + wn * 128 + jj * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc_f[mfma_row(r, hf) * PF + l31] = acc[si][jj][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int row = row0 + h_rr + 16 * c, col = col0 + h_c8;
+        const float4 a = *reinterpret_cast<const float4*>(sc_f + (h_rr + 16 * c) * PF + h_c8);
+        const float4 b = *reinterpret_cast<const float4*>(sc_f + (h_rr + 16 * c) * PF + h_c8 + 4);
+        float y[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (g.cv.bias) {
+          const float bv = cbias[si][c];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] += bv;
+        }
+        if (g.cv.act) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = lrelu(y[e], g.cv.slope) * g.cv.act_scale;
+        }
+        if (row < M && col < N) {
+          float* q = d.C + cb + (long long)row * d.ldc + col;
+          *reinterpret_cast<float4*>(q) = make_float4(y[0], y[1], y[2], y[3]);
+          *reinterpret_cast<float4*>(q + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    });
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 // Internal entry (called by cips_gemm_bf16x3 when the shape and the epilogue qualify): same descriptor,
@@ -550,7 +752,16 @@ extern "C" int cips_conv2d_x3(const cips_conv_x3_desc* c, cips_stream_t stream) 
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
   g.dbg = 0;
-  launch_wide<false, false, false, true>(g, wide_grid(g.total), (hipStream_t)stream);
+  bool v3 = (K / 32) / ks >= 2;                 // every chunk has at least two k-tiles
+  { const char* e = getenv("CIPS_X3_CONVV3"); if (e && atoi(e) == 0) v3 = false; }      // read per call (A/B inside one process)
+  if (v3) {
+    static bool attr = false;
+    CIPS_PER_DEVICE(attr, false);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv2d_x3_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES); attr = true; }
+    hipLaunchKernelGGL(conv2d_x3_v3_kernel, dim3(wide_grid(g.total)), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
+  } else {
+    launch_wide<false, false, false, true>(g, wide_grid(g.total), (hipStream_t)stream);
+  }
   if (ks > 1) {
     const long long n4 = (long long)c->B * c->O * N / 4;        // N % 8 == 0
     const long long blocks = (n4 + 255) / 256;
