@@ -1448,11 +1448,34 @@ class InrHeadX3Function(torch.autograd.Function):
                         gemm_x3_km_grouped([(a1P, gP, part2), (xP, g1P, part1)], cout, cout, nk_, cout, cout,
                                            nb * ksp, nk_ * cout, nk_ * cout)
                     else:
-                        gemm_x3_km(a1P, gP, cout, cout, nk_, cout, cout, nb * ksp, nk_ * cout, nk_ * cout, part2)
-                        gemm_x3_km(xP, g1P, cin, cout, nk_, cin, cout, nb * ksp, nk_ * cin, nk_ * cout, part1)
+                        # the block's square problem alone is half a chip of 256 x 256 tiles: two pixel halves fill it
+                        ksp2 = ksp
+                        while nb * ksp2 * ((cout + 255) // 256) ** 2 < 192 and n % (2 * ksp2 * 32) == 0 and n // (2 * ksp2) >= 512:
+                            ksp2 *= 2
+                        if ksp2 != ksp:
+                            part2 = torch.empty(nb * ksp2, cout, cout, device=dev)
+                        nk2 = n // ksp2
+                        gemm_x3_km(a1P, gP, cout, cout, nk2, cout, cout, nb * ksp2, nk2 * cout, nk2 * cout, part2)
+                        if ksp2 != ksp:
+                            torch.sum(part2.view(nb, ksp2, cout, cout), dim=1, out=gwb2)
+                            part2 = gwb2
+                        # a narrow first layer (cin = 32: one row tile, 2 column tiles per image = 64 workgroups) streams
+                        # the whole gradient plane through a quarter of the chip: split its pixel range further
+                        ksp1 = ksp
+                        while cin <= 128 and nb * ksp1 * ((cout + 255) // 256) < 192 and n % (2 * ksp1 * 32) == 0 and n // (2 * ksp1) >= 512:
+                            ksp1 *= 2
+                        if ksp1 != ksp:
+                            part1 = torch.empty(nb * ksp1, cin, cout, device=dev)
+                        nk1 = n // ksp1
+                        gemm_x3_km(xP, g1P, cin, cout, nk1, cin, cout, nb * ksp1, nk1 * cin, nk1 * cout, part1)
+                        if ksp1 != ksp:
+                            torch.sum(part1.view(nb, ksp1, cin, cout), dim=1, out=gwb1)
+                            part1 = gwb1
                     if ksp > 1:
-                        torch.sum(part2.view(nb, ksp, cout, cout), dim=1, out=gwb2)
-                        torch.sum(part1.view(nb, ksp, cin, cout), dim=1, out=gwb1)
+                        if part2 is not gwb2:
+                            torch.sum(part2.view(nb, ksp, cout, cout), dim=1, out=gwb2)
+                        if part1 is not gwb1:
+                            torch.sum(part1.view(nb, ksp, cin, cout), dim=1, out=gwb1)
                 else:
                     gemm_x3(_bsl(sv["a1T"], b0, b1), gT, cout, cout, n, n, n, nb, cout * n, cout * n, C=gwb2)
                     gemm_x3(_bsl(sv["xT"], b0, b1), g1T, cin, cout, n, n, n, nb, cin * n, cout * n, C=gwb1)
