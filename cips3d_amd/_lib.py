@@ -154,6 +154,7 @@ SIGNATURES = {
     "cips_torgb_bwd_partials": (i32, [i64]),
     "cips_torgb_bwd_w": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
     "cips_torgb_bwd_x": (i32, [vp, vp, vp, vp, f32, vp, vp, i64, i32, vp]),
+    "cips_torgb_bwd_w_x3_batch": (i32, [vp, vp, i32, vp, vp, vp, vp, i64, i32, vp]),
     "cips_torgb_bwd_x_x3": (i32, [vp, vp, vp, f32, vp, vp, vp, i64, i32, vp]),
     "cips_fused_bias_act": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, vp]),
     "cips_diffaug": (i32, [vp] * 10 + [i32] * 8 + [vp]),

@@ -306,10 +306,13 @@ constexpr int TORGB_ROWS = 128;  // rows per partial chunk
 
 // Same for the weight gradient: partial[chunk][c][k] = sum over the chunk's 128 rows of drgb[m][c] x[m][k], K = 512.
 // 64 lanes x 8 k cover a row; the four waves take rows m0 + wave, + 4, ... (32 each), combined in wave order via LDS.
-__global__ __launch_bounds__(256) void torgb_bwd_w_partial_x3_k512_kernel(const u16* __restrict__ xh, const u16* __restrict__ xl,
-                                                                          const float* __restrict__ drgb,
+constexpr int TORGB_MAXJOBS = 8;
+struct TorgbJobs { const u16* xh[TORGB_MAXJOBS]; const u16* xl[TORGB_MAXJOBS]; };      // blockIdx.y = job: the taps of all blocks against one drgb
+__global__ __launch_bounds__(256) void torgb_bwd_w_partial_x3_k512_kernel(TorgbJobs J, const float* __restrict__ drgb,
                                                                           float* __restrict__ partial, long long M) {
   constexpr int K = 512;
+  const u16* __restrict__ xh = J.xh[blockIdx.y];
+  const u16* __restrict__ xl = J.xl[blockIdx.y];
   __shared__ float sh[3][3][K];                 // waves 1..3
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: drgb comes
   const long long m0 = (long long)blockIdx.x * TORGB_ROWS;                                       // through scalar loads
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256) void torgb_bwd_w_partial_x3_k512_kernel(const 
     }
   }
   __syncthreads();
-  float* out = partial + (long long)blockIdx.x * 4 * K;
+  float* out = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 * K;
   if (wave == 0) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -428,6 +431,9 @@ __global__ __launch_bounds__(256) void torgb_bwd_w_reduce_kernel(const float* __
   __shared__ float red[32][9];
   const int c = threadIdx.x & 7, gi = threadIdx.x >> 3;
   const int idx = blockIdx.x * 8 + c;
+  partial += (long long)blockIdx.y * chunks * 4 * K;      // blockIdx.y = job of a batched call
+  dw += (long long)blockIdx.y * 3 * K;
+  dbias += blockIdx.y * 3;
   float acc = 0.f;
   if (idx < 3 * K + 3)
     for (int ch = gi; ch < chunks; ch += 32) acc += partial[(long long)ch * 4 * K + idx];
@@ -919,14 +925,33 @@ extern "C" int cips_torgb_bwd_w_x3(const void* x_hi, const void* x_lo, const flo
   if (M <= 0 || K <= 0 || (K & 3) || K > 512) return (int)hipErrorInvalidValue;
   int chunks = cips_torgb_bwd_partials(M);
   hipStream_t st = (hipStream_t)stream;
-  if (K == 512)
-    hipLaunchKernelGGL(torgb_bwd_w_partial_x3_k512_kernel, dim3(chunks), dim3(256), 0, st, (const u16*)x_hi, (const u16*)x_lo,
-                       drgb, partials, M);
-  else
+  if (K == 512) {
+    TorgbJobs J = {};
+    J.xh[0] = (const u16*)x_hi; J.xl[0] = (const u16*)x_lo;
+    hipLaunchKernelGGL(torgb_bwd_w_partial_x3_k512_kernel, dim3(chunks), dim3(256), 0, st, J, drgb, partials, M);
+  } else
     hipLaunchKernelGGL(torgb_bwd_w_partial_kernel<true>, dim3(chunks), dim3(256), 0, st, x_hi, x_lo, drgb, partials,
                        M, K);
   hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 7) / 8), dim3(256), 0, st, partials, dw,
                      dbias, chunks, K);
+  return CIPS_CHECK_LAUNCH();
+}
+
+// the ToRGB taps of several blocks (same M, K = 512) against one drgb in two launches: partials (njobs, chunks, 4, K),
+// dw (njobs, 3, K), dbias (njobs, 3)
+extern "C" int cips_torgb_bwd_w_x3_batch(const void* const* x_hi, const void* const* x_lo, int njobs, const float* drgb,
+                                         float* partials, float* dw, float* dbias, long long M, int K, cips_stream_t stream) {
+  if (!x_hi || !x_lo || njobs <= 0 || M <= 0) return (int)hipErrorInvalidValue;
+  if (njobs > TORGB_MAXJOBS || K != 512) return (int)hipErrorNotSupported;
+  TorgbJobs J = {};
+  for (int i = 0; i < njobs; ++i) {
+    if (!x_hi[i] || !x_lo[i]) return (int)hipErrorInvalidValue;
+    J.xh[i] = (const u16*)x_hi[i]; J.xl[i] = (const u16*)x_lo[i];
+  }
+  const int chunks = cips_torgb_bwd_partials(M);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(torgb_bwd_w_partial_x3_k512_kernel, dim3(chunks, njobs), dim3(256), 0, st, J, drgb, partials, M);
+  hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 7) / 8, njobs), dim3(256), 0, st, partials, dw, dbias, chunks, K);
   return CIPS_CHECK_LAUNCH();
 }
 

@@ -1187,6 +1187,26 @@ def torgb_bwd_w_x3(xp, drgb2d):
     return dw, db
 
 
+def torgb_bwd_w_x3_batch(xps, drgb2d):
+    """the ToRGB weight / bias gradients of several taps (Planes of one shape) against one drgb: list of (dw (3, K), db (3,)).
+    Two launches for all of them when K = 512 (<= 8 taps), else one pair per tap."""
+    lib = _lib.load()
+    K = xps[0].hi.shape[-1]
+    M = xps[0].hi.numel() // K
+    n = len(xps)
+    if K != 512 or n > 8 or n < 2:
+        return [torgb_bwd_w_x3(xp, drgb2d) for xp in xps]
+    chunks = lib.cips_torgb_bwd_partials(M)
+    dev = drgb2d.device
+    part = torch.empty(n, chunks, 4, K, device=dev)
+    dw = torch.empty(n, 3, K, device=dev)
+    db = torch.empty(n, 3, device=dev)
+    hi = (_ct.c_void_p * n)(*[_p(xp.hi) for xp in xps])
+    lo = (_ct.c_void_p * n)(*[_p(xp.lo) for xp in xps])
+    check(lib.cips_torgb_bwd_w_x3_batch(hi, lo, n, _p(drgb2d), _p(part), _p(dw), _p(db), M, K, _stream()), "cips_torgb_bwd_w_x3_batch")
+    return [(dw[i], db[i]) for i in range(n)]
+
+
 # LeakyReLU gates of the head kept as bit planes (1 bit per activation, written by the forward GEMMs' epilogues) instead
 # of bf16 planes: 2.5 GB less HBM traffic per C2 step.  CIPS_INR_GATE_BITS=0: bf16 gate planes / sign of the hi plane.
 INR_GATE_BITS = _os.environ.get("CIPS_INR_GATE_BITS", "1") != "0"
@@ -1420,13 +1440,16 @@ class InrHeadX3Function(torch.autograd.Function):
                 if gT is not None:
                     gT.hi.zero_(); gT.lo.zero_()
                 Dout = torch.zeros(nb, n, width, device=dev) if saved[k]["skip"] and not addp else None
+            # ToRGB weight / bias gradients of all taps: they need only the saved block outputs and drgb
+            taps = list(range(3, nblocks))
+            if taps:
+                for k_, res_ in zip(taps, torgb_bwd_w_x3_batch([_bsl(saved[k_]["oP"], b0, b1) for k_ in taps], drgb2)):
+                    rgb_parts[k_][ci] = res_
             for k in range(nblocks - 1, -1, -1):
                 sv = saved[k]
                 W1, s1, W2, s2 = blocks[k]
                 cin, cout = W1.shape
                 gP_in = gP              # D_{k+1} gated by a2_k's gate: the planes form of the skip gradient
-                if k >= 3:
-                    rgb_parts[k][ci] = torgb_bwd_w_x3(_bsl(sv["oP"], b0, b1), drgb2)
                 # ---- mod2: gradient through the gate of a1 ----
                 g1P, g1T = Planes.empty(nb, n, cout, device=dev), PT(cout)
                 gemm_x3(gP, _bsl(sv["wb2"], b0, b1), n, cout, cout, cout, cout, nb, n * cout, cout * cout, P=g1P, T=g1T, ldt=n,

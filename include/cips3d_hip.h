@@ -443,6 +443,10 @@ int cips_torgb_fwd_x3(const void* x_hi, const void* x_lo, const float* w, const 
                       long long M, int K, int accumulate, cips_stream_t stream);
 int cips_torgb_bwd_w_x3(const void* x_hi, const void* x_lo, const float* drgb, float* partials, float* dw,
                         float* dbias, long long M, int K, cips_stream_t stream);
+/* the taps of up to 8 blocks (same M; K = 512, else hipErrorNotSupported) against one drgb in two launches:
+ * x_hi / x_lo: host arrays of njobs device plane pointers; partials (njobs, chunks, 4, K); dw (njobs, 3, K); dbias (njobs, 3) */
+int cips_torgb_bwd_w_x3_batch(const void* const* x_hi, const void* const* x_lo, int njobs, const float* drgb,
+                              float* partials, float* dw, float* dbias, long long M, int K, cips_stream_t stream);
 /* dx (M,K) = drgb (M,3) @ w (3,K) [+ add]; optional copy before masking; out = dx * (mask>0 ? 1 : slope)
  * (the LeakyReLU gate of the layer below, fused).  mask / add / out_unmasked may be NULL. */
 int cips_torgb_bwd_x(const float* drgb, const float* w, const float* add, const float* mask, float slope,

@@ -902,6 +902,14 @@ def test_torgb_x3_forward_and_weight_gradient(M, K):
     assert rel_err(db, drgb.double().sum(0)) < 2e-6
     dw2, db2 = ops.torgb_bwd_w_x3(xP, drgb.to(d))
     assert torch.equal(dw, dw2) and torch.equal(db, db2)          # fixed combine order
+    # several taps against one drgb in two launches (K = 512; else the per-tap pair): the same numbers, bit for bit
+    x3 = torch.randn(1, M, K, generator=g)
+    yP, _ = ops.split_planes(x3.to(d), want_t=False)
+    res = ops.torgb_bwd_w_x3_batch([xP, yP, xP], drgb.to(d))
+    dwy, dby = ops.torgb_bwd_w_x3(yP, drgb.to(d))
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][0], dw) and torch.equal(res[0][1], db) and torch.equal(res[2][0], dw)
+    assert torch.equal(res[1][0], dwy) and torch.equal(res[1][1], dby)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float64, torch.float32])
