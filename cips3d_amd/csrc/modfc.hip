@@ -729,14 +729,18 @@ __global__ __launch_bounds__(256) void modfc_prep_bwd_s_batch_kernel(BwdJobs J, 
 // three times (c, dW, ds); here the column sums c read it once with 16-byte lanes and ONE further pass produces both
 // dW (sum over images, registers) and ds (sum over columns, one wave reduction per image) — two reads instead of three.
 // A block is 64 columns x 16 row groups, every lane owns 4 consecutive columns.
+struct ColJobs {                       // one table for both uses: G == nullptr selects the demodulation sums
+  const float* W[MAXJOBS]; const float* s[MAXJOBS]; const float* G[MAXJOBS]; float* out[MAXJOBS];
+  int in_dim[MAXJOBS], out_dim[MAXJOBS];
+};
 template <bool WITH_G>
-__global__ __launch_bounds__(256) void modfc_colsum4_batch_kernel(PrepJobs P, BwdJobs J, int B, float eps) {
+__global__ __launch_bounds__(256) void modfc_colsum4_batch_kernel(ColJobs J, int B, float eps) {
   __shared__ float4 red[16][17];
   const int job = blockIdx.z, b = blockIdx.y;
-  const int in_dim = WITH_G ? J.in_dim[job] : P.in_dim[job], out_dim = WITH_G ? J.out_dim[job] : P.out_dim[job];
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
   if (blockIdx.x * 64 >= out_dim) return;
-  const float* __restrict__ W = WITH_G ? J.W[job] : P.W[job];
-  const float* __restrict__ sb = (WITH_G ? J.s[job] : P.s[job]) + (long long)b * in_dim;
+  const float* __restrict__ W = J.W[job];
+  const float* __restrict__ sb = J.s[job] + (long long)b * in_dim;
   const float* __restrict__ Gb = WITH_G ? J.G[job] + (long long)b * in_dim * out_dim : nullptr;
   const int c = threadIdx.x & 15, kg = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + 4 * c;
@@ -761,8 +765,8 @@ __global__ __launch_bounds__(256) void modfc_colsum4_batch_kernel(PrepJobs P, Bw
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int g = 0; g < 16; ++g) { const float4 v = red[g][c]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-    if (WITH_G) *reinterpret_cast<float4*>(J.cbuf[job] + (long long)b * out_dim + n) = t;
-    else *reinterpret_cast<float4*>(P.demod[job] + (long long)b * out_dim + n) =
+    if (WITH_G) *reinterpret_cast<float4*>(J.out[job] + (long long)b * out_dim + n) = t;
+    else *reinterpret_cast<float4*>(J.out[job] + (long long)b * out_dim + n) =
         make_float4(rsqrtf(t.x + eps), rsqrtf(t.y + eps), rsqrtf(t.z + eps), rsqrtf(t.w + eps));
   }
 }
@@ -1001,9 +1005,11 @@ extern "C" int cips_modfc_prep_x3_batch(const cips_modfc_prep_job* jobs, int njo
   static int planes64 = -1, fused = -1;
   if (planes64 < 0) { const char* e = getenv("CIPS_MODFC_PLANES64"); planes64 = (e && atoi(e) == 0) ? 0 : 1; }
   if (fused < 0) { const char* e = getenv("CIPS_MODFC_VEC4"); fused = (e && atoi(e) == 0) ? 0 : 1; }
-  if (vec4 && fused)
-    hipLaunchKernelGGL(modfc_colsum4_batch_kernel<false>, dim3((max_out + 63) / 64, B, njobs), dim3(256), 0, st, J, BwdJobs{}, B, eps);
-  else
+  if (vec4 && fused) {
+    ColJobs Cj = {};
+    for (int i = 0; i < njobs; ++i) { Cj.W[i] = J.W[i]; Cj.s[i] = J.s[i]; Cj.out[i] = J.demod[i]; Cj.in_dim[i] = J.in_dim[i]; Cj.out_dim[i] = J.out_dim[i]; }
+    hipLaunchKernelGGL(modfc_colsum4_batch_kernel<false>, dim3((max_out + 63) / 64, B, njobs), dim3(256), 0, st, Cj, B, eps);
+  } else
     hipLaunchKernelGGL(modfc_demod_batch_kernel, dim3((max_out + 31) / 32, B, njobs), dim3(256), 0, st, J, B, eps);
   if (wide && planes64)
     hipLaunchKernelGGL(modfc_planes_batch64_kernel, dim3((max_out + 63) / 64, (max_in + 63) / 64, B * njobs), dim3(256), 0, st, J, B);
@@ -1033,7 +1039,9 @@ extern "C" int cips_modfc_prep_bwd_batch(const cips_modfc_bwd_job* jobs, int njo
   static int fused = -1;
   if (fused < 0) { const char* e = getenv("CIPS_MODFC_VEC4"); fused = (e && atoi(e) == 0) ? 0 : 1; }
   if (vec4 && fused) {
-    hipLaunchKernelGGL(modfc_colsum4_batch_kernel<true>, dim3((max_out + 63) / 64, B, njobs), dim3(256), 0, st, PrepJobs{}, J, B, 0.f);
+    ColJobs Cj = {};
+    for (int i = 0; i < njobs; ++i) { Cj.W[i] = J.W[i]; Cj.s[i] = J.s[i]; Cj.G[i] = J.G[i]; Cj.out[i] = J.cbuf[i]; Cj.in_dim[i] = J.in_dim[i]; Cj.out_dim[i] = J.out_dim[i]; }
+    hipLaunchKernelGGL(modfc_colsum4_batch_kernel<true>, dim3((max_out + 63) / 64, B, njobs), dim3(256), 0, st, Cj, B, 0.f);
     if (max_out <= 512)
       hipLaunchKernelGGL(modfc_prep_bwd_ws_batch_kernel<2>, dim3((max_in + 3) / 4, njobs), dim3(256), 0, st, J, B);
     else

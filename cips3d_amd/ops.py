@@ -919,6 +919,21 @@ def _x3_desc(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, 
     return d
 
 
+_ADDP_OK = {}
+
+
+def _addp_shape_ok(n, cin, cout, nb, dev):
+    """does the library take the planes addend at this shape?  (a property of the shape and of the process-wide kernel
+    switches: asked once per shape with stand-in pointers — the query reads only shapes, flags and pointer alignment)"""
+    key = (n, cin, cout, nb, dev.index)
+    ok = _ADDP_OK.get(key)
+    if ok is None:
+        gq = Planes.empty(1, 8, 8, device=dev)
+        ok = _ADDP_OK[key] = gemm_x3_takes_addp(gq, gq, n, cin, cout, cout, cout, nb, n * cout, cin * cout, P=gq,
+                                                addp=(gq, gq.hi), mask=gq.hi, gate_bits=1)
+    return ok
+
+
 def gemm_x3_takes_addp(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, **epi):
     """True when the library runs this descriptor with the planes addend (256x256-tile kernel, interior shapes)"""
     lib = _lib.load()
@@ -1419,9 +1434,7 @@ class InrHeadX3Function(torch.autograd.Function):
                 for j in range(1, nblocks):
                     if saved[j]["skip"]:
                         cj_in, cj_out = blocks[j][0].shape
-                        gq = Planes.empty(1, 8, 8, device=dev)
-                        addp = addp and gemm_x3_takes_addp(gq, gq, n, cj_in, cj_out, cj_out, cj_out, nb, n * cj_out, cj_in * cj_out,
-                                                           P=gq, addp=(gq, gq.hi), mask=gq.hi, gate_bits=1)
+                        addp = addp and _addp_shape_ok(n, cj_in, cj_out, nb, dev)
             if k >= 3 and km and saved[k]["bits"] and width % 8 == 0 and TORGB_BWDX_STREAM:
                 # grad wrt out_k = drgb @ T_k (rank 3), gate of a2_k fused: one streaming kernel writing the planes
                 Dout = torch.empty(nb, n, width, device=dev) if saved[k]["skip"] and not addp else None
