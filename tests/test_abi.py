@@ -140,3 +140,21 @@ def test_entry_points_validate_arguments_before_touching_the_device():
     assert lib.cips_torgb_fwd(None, None, None, None, 16, 30, 0, None) == INVALID       # K not a multiple of 4
     assert lib.cips_fused_bias_act(None, buf, None, None, 16, 0, 1, 3, 0, 0.2, 1.0, None) == INVALID   # bias without its size
     assert lib.cips_fused_bias_act(None, None, None, None, 0, 0, 0, 3, 0, 0.2, 1.0, None) == 0          # empty tensor: no-op
+    # round-3 entry points
+    assert lib.cips_torgb_bwd_x_x3(None, None, None, 0.2, None, None, None, 16, 64, None) == INVALID    # no operands
+    assert lib.cips_torgb_bwd_x_x3(buf, buf, None, 0.2, None, buf, buf, 16, 60, None) == INVALID        # K not a multiple of 8
+    assert lib.cips_torgb_bwd_w_x3_batch(None, None, 2, None, None, None, None, 128, 512, None) == INVALID
+    ptrs = (ctypes.c_void_p * 9)(*[ctypes.cast(buf, ctypes.c_void_p).value] * 9)
+    assert lib.cips_torgb_bwd_w_x3_batch(ptrs, ptrs, 9, None, None, None, None, 128, 512, None) == UNSUPPORTED   # more than 8 taps
+    assert lib.cips_torgb_bwd_w_x3_batch(ptrs, ptrs, 2, None, None, None, None, 128, 256, None) == UNSUPPORTED   # K != 512
+    # the planes addend (ABI 4) is taken by the 256 x 256-tile kernel only: the query says no for anything else, and the
+    # GEMM entry point refuses instead of dropping it
+    e = _lib.GemmX3Desc()
+    e.M, e.N, e.K, e.lda, e.ldb, e.batch, e.ldp, e.strideP, e.gate_bits = 160, 256, 64, 64, 64, 4, 256, 160 * 256, 1
+    pv = ctypes.cast(buf, ctypes.c_void_p)
+    e.A_hi = e.A_lo = e.B_hi = e.B_lo = e.P_hi = e.P_lo = e.mask = e.addp_hi = e.addp_lo = e.addp_gate = pv
+    e.addp_gain = 5.0
+    assert lib.cips_gemm_bf16x3_takes_addp(ctypes.byref(e)) == 0                                      # 160 rows: not a v3 shape
+    assert lib.cips_gemm_bf16x3(ctypes.byref(e), None) == UNSUPPORTED
+    e.addp_hi = None
+    assert lib.cips_gemm_bf16x3_takes_addp(ctypes.byref(e)) == 0                                      # nothing to take
