@@ -144,6 +144,7 @@ SIGNATURES = {
     "cips_modfc_prep_bwd_batch": (i32, [C.POINTER(ModfcBwdJob), i32, i32, vp]),
     "cips_opt_chunk": (i32, []),
     "cips_opt_step": (i32, [vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]),
+    "cips_camera_pose": (i32, [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, i32, vp]),
     "cips_grouped_linear_max_jobs": (i32, []),
     "cips_grouped_linear_fwd": (i32, [C.POINTER(GlinJob), i32, i32, vp]),
     "cips_grouped_linear_scratch": (i64, [C.POINTER(GlinJob), i32, i32]),

@@ -362,6 +362,55 @@ __global__ __launch_bounds__(256) void rownorm_bwd_affine_kernel(const float* __
   dgamma[c] = a; dbeta[c] = b;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Camera pose of a training batch in ONE launch (exp/comm/comm_utils.py:451-581: sample_camera_positions for the
+// 'gaussian' / 'normal' / 'uniform' distributions + create_cam2world_matrix with the (0, 1, 0) up vector): from the raw
+// draws to pitch, yaw, the camera origin and cam2world.  As torch ops this is ~45 launches of one-wave kernels on (b, 1)
+// and (b, 3) tensors per step, each a ~5 us node of the captured graph.  The arithmetic follows the reference's operation
+// order with separately rounded multiplies / adds (no fma contraction), so the result agrees with the op-by-op form to
+// the last bits of sinf / cosf.
+__global__ __launch_bounds__(64) void camera_pose_kernel(const float* __restrict__ th_raw, const float* __restrict__ ph_raw,
+                                                         int uniform, float hs, float hm, float vs, float vm,
+                                                         float phi_lo, float phi_hi, float* __restrict__ pitch_yaw,
+                                                         float* __restrict__ origin, float* __restrict__ c2w, int B) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= B) return;
+  float th, ph;
+  if (uniform) {                      // (u - 0.5) * 2 * stddev + mean
+    th = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(th_raw[i], 0.5f), 2.f), hs), hm);
+    ph = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(ph_raw[i], 0.5f), 2.f), vs), vm);
+  } else {                            // g * stddev + mean
+    th = __fadd_rn(__fmul_rn(th_raw[i], hs), hm);
+    ph = __fadd_rn(__fmul_rn(ph_raw[i], vs), vm);
+  }
+  ph = fminf(fmaxf(ph, phi_lo), phi_hi);
+  const float sp = sinf(ph), cp = cosf(ph), st = sinf(th), ct = cosf(th);
+  const float ox = __fmul_rn(sp, ct), oy = cp, oz = __fmul_rn(sp, st);          // r = 1
+  auto norm3 = [](float x, float y, float z) { return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z))); };
+  // forward = normalize(-origin), normalised once more inside create_cam2world_matrix
+  float n = norm3(-ox, -oy, -oz);
+  float fx = -ox / n, fy = -oy / n, fz = -oz / n;
+  n = norm3(fx, fy, fz);
+  fx /= n; fy /= n; fz /= n;
+  // left = normalize(cross((0,1,0), f)) = normalize((f_z, 0, -f_x)); up = normalize(cross(f, left))
+  float lx = fz, ly = 0.f, lz = -fx;
+  n = norm3(lx, ly, lz);
+  lx /= n; ly /= n; lz /= n;
+  float ux = __fsub_rn(__fmul_rn(fy, lz), __fmul_rn(fz, ly));
+  float uy = __fsub_rn(__fmul_rn(fz, lx), __fmul_rn(fx, lz));
+  float uz = __fsub_rn(__fmul_rn(fx, ly), __fmul_rn(fy, lx));
+  n = norm3(ux, uy, uz);
+  ux /= n; uy /= n; uz /= n;
+  pitch_yaw[2 * i] = ph; pitch_yaw[2 * i + 1] = th;
+  origin[3 * i] = ox; origin[3 * i + 1] = oy; origin[3 * i + 2] = oz;
+  float* m = c2w + 16 * i;            // trans @ rot: columns (-left, up, -forward, origin)
+  m[0] = -lx; m[1] = ux; m[2] = -fx; m[3] = ox;
+  m[4] = -ly; m[5] = uy; m[6] = -fy; m[7] = oy;
+  m[8] = -lz; m[9] = uz; m[10] = -fz; m[11] = oz;
+  m[12] = 0.f; m[13] = 0.f; m[14] = 0.f; m[15] = 1.f;
+}
+
 }  // namespace
 
 extern "C" int cips_grouped_linear_max_jobs(void) { return GL_MAX; }
@@ -554,4 +603,14 @@ extern "C" int cips_equal_linear(int mode, const float* a, const float* b, const
     d.A = a; d.B = b; d.C = out; d.M = O; d.N = K; d.K = B; d.lda = O; d.ldb = K; d.ldc = K; d.a_kmajor = 1;
   }
   return cips_gemm_f32(&d, stream);
+}
+
+extern "C" int cips_camera_pose(const float* theta_raw, const float* phi_raw, int uniform, float h_stddev, float h_mean,
+                                float v_stddev, float v_mean, float* pitch_yaw, float* origin, float* cam2world, int B,
+                                cips_stream_t stream) {
+  if (!theta_raw || !phi_raw || !pitch_yaw || !origin || !cam2world || B <= 0) return (int)hipErrorInvalidValue;
+  const float lo = 1e-5f, hi = (float)(3.14159265358979323846 - 1e-5);
+  hipLaunchKernelGGL(camera_pose_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, theta_raw, phi_raw, uniform,
+                     h_stddev, h_mean, v_stddev, v_mean, lo, hi, pitch_yaw, origin, cam2world, B);
+  return CIPS_CHECK_LAUNCH();
 }

@@ -609,21 +609,27 @@ class GeneratorNerfINR(nn.Module):
 
         # ---------------- camera (O(b) host math) ----------------
         with torch.no_grad():
-            if need_cam:
-                theta, phi = cam_angles(th_raw, ph_raw) if simple_cam else (th_raw, ph_raw)
-                origin, pitch = camera_origin_from_angles(theta, phi)
-                yaw = theta
-                forward_vector = _normalize(-origin)
+            pitch_yaw_fused = None
+            if need_cam and simple_cam and ops.CAMERA_HIP and th_raw.is_cuda and not (staged and up_vector is not None):
+                # draws -> pitch, yaw, origin, cam2world in one launch (the ~45 one-wave torch kernels of the op-by-op form
+                # below are 0.2 ms of a captured step)
+                pitch_yaw_fused, origin, cam2world = ops.camera_pose(th_raw, ph_raw, mode == 'uniform', h_stddev, h_mean,
+                                                                     v_stddev, v_mean)
+                pitch, yaw = pitch_yaw_fused[:, 0:1], pitch_yaw_fused[:, 1:2]
             else:
-                origin = camera_pos
-                pitch = yaw = torch.zeros(b, 1, device=device)
-                forward_vector = _normalize(camera_lookup)
-            # reference quirk kept: only the staged branch of whole_grad_forward hands `up_vector` on
-            # (generator.py:1437 vs :1481-1497); the one-shot branch always uses (0, 1, 0)
-            cam2world = create_cam2world_matrix(forward_vector, origin, up_vector=up_vector if staged else None)
-            xg = torch.linspace(-1, 1, W, device=device)
-            yg = torch.linspace(1, -1, H, device=device)
-            zg = torch.linspace(ray_start, ray_end, S, device=device)
+                if need_cam:
+                    theta, phi = cam_angles(th_raw, ph_raw) if simple_cam else (th_raw, ph_raw)
+                    origin, pitch = camera_origin_from_angles(theta, phi)
+                    yaw = theta
+                    forward_vector = _normalize(-origin)
+                else:
+                    origin = camera_pos
+                    pitch = yaw = torch.zeros(b, 1, device=device)
+                    forward_vector = _normalize(camera_lookup)
+                # reference quirk kept: only the staged branch of whole_grad_forward hands `up_vector` on
+                # (generator.py:1437 vs :1481-1497); the one-shot branch always uses (0, 1, 0)
+                cam2world = create_cam2world_matrix(forward_vector, origin, up_vector=up_vector if staged else None)
+            xg, yg, zg = ops.pixel_grids(W, H, S, ray_start, ray_end, device)
             zc = float((-torch.ones(1) / np.tan((2 * math.pi * fov / 360) / 2)).item())
             # non-hierarchical sampling of whole images: rays + SIREN + composite fused in one kernel that walks the
             # samples along each ray (ops.RayMarchFunction); no (b,n,S,3) points, no per-sample features in HBM
@@ -633,7 +639,7 @@ class GeneratorNerfINR(nn.Module):
             gen_rays = hierarchical_sample and (not part) and ops.march_available()
             if not fused and not gen_rays:
                 points, z_vals, dirs = ops.rays_fwd(xg, yg, zg, zc, cam2world, jitter.reshape(b, n, S), b, H, W, S)
-            ray_origins = cam2world[:, :3, 3].contiguous()       # every ray starts at the camera
+            ray_origins = origin if pitch_yaw_fused is not None else cam2world[:, :3, 3].contiguous()       # every ray starts at the camera
 
         nerf_styles = self._nerf_styles(style_dict)
         def pipeline(points, z_vals, dirs, n, noise_c, u, noise_f, nerf_grad):
@@ -727,7 +733,7 @@ class GeneratorNerfINR(nn.Module):
 
         inr_img = inr_img.view(b, H, W, 3).permute(0, 3, 1, 2)
         inr_img = self.filters(inr_img)
-        pitch_yaw = torch.cat([pitch, yaw], -1)
+        pitch_yaw = pitch_yaw_fused if pitch_yaw_fused is not None else torch.cat([pitch, yaw], -1)
         if return_aux_img:
             aux_img = aux_img.view(b, H, W, 3).permute(0, 3, 1, 2)
             imgs = torch.cat([inr_img, aux_img])

@@ -8,6 +8,7 @@ fallback: tensors must live on a ROCm device and the extension must be built.
 import ctypes as C
 import ctypes as _ct
 import math
+import os as _os
 
 import torch
 
@@ -47,8 +48,37 @@ def _c(t):
 
 
 # --------------------------------------------------------------------------------------
-# H1 rays
+# H1 camera pose + rays
 # --------------------------------------------------------------------------------------
+CAMERA_HIP = _os.environ.get("CIPS_CAMERA_HIP", "1") != "0"     # 0: the camera pose as ~45 torch ops (comm_utils.py order)
+
+
+def camera_pose(theta_raw, phi_raw, uniform, h_stddev, h_mean, v_stddev, v_mean):
+    """raw draws (b, 1) x 2 -> pitch_yaw (b, 2), origin (b, 3), cam2world (b, 4, 4); see cips_camera_pose"""
+    lib = _lib.load()
+    dev = theta_raw.device
+    B = theta_raw.shape[0]
+    th, ph = _c(theta_raw), _c(phi_raw)
+    py = torch.empty(B, 2, device=dev); origin = torch.empty(B, 3, device=dev); c2w = torch.empty(B, 4, 4, device=dev)
+    check(lib.cips_camera_pose(_p(th), _p(ph), 1 if uniform else 0, float(h_stddev), float(h_mean), float(v_stddev),
+                               float(v_mean), _p(py), _p(origin), _p(c2w), B, _stream()), "cips_camera_pose")
+    return py, origin, c2w
+
+
+_GRIDS = {}
+
+
+def pixel_grids(W, H, S, ray_start, ray_end, device):
+    """the three linspaces of the ray set-up (constants of the geometry), built once per geometry and device"""
+    key = (W, H, S, float(ray_start), float(ray_end), str(device))
+    g = _GRIDS.get(key)
+    if g is None:
+        if len(_GRIDS) > 64:
+            _GRIDS.clear()
+        g = _GRIDS[key] = (torch.linspace(-1, 1, W, device=device), torch.linspace(1, -1, H, device=device),
+                           torch.linspace(ray_start, ray_end, S, device=device))
+    return g
+
 def rays_fwd(xg, yg, zg, zc, cam2world, jitter, B, H, W, S):
     """-> points (B,n,S,3), z (B,n,S), dirs (B,n,3); see cips_rays_fwd."""
     lib = _lib.load()

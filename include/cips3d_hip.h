@@ -456,6 +456,14 @@ int cips_torgb_bwd_x(const float* drgb, const float* w, const float* add, const 
 int cips_torgb_bwd_x_x3(const float* drgb, const float* w, const void* gate_bits, float slope, float* out_unmasked,
                         void* p_hi, void* p_lo, long long M, int K, cips_stream_t stream);
 
+/* Camera pose of a batch (exp/comm/comm_utils.py:451-581: sample_camera_positions for 'gaussian' / 'normal' (uniform = 0:
+ * angle = draw * stddev + mean) and 'uniform' (uniform = 1: (draw - 0.5) * 2 * stddev + mean), camera_origin_from_angles with
+ * r = 1, look-at-origin forward vector, create_cam2world_matrix with up = (0, 1, 0)) in one launch:
+ * theta_raw, phi_raw (B) raw draws -> pitch_yaw (B, 2) = (clamped phi, theta), origin (B, 3), cam2world (B, 4, 4). */
+int cips_camera_pose(const float* theta_raw, const float* phi_raw, int uniform, float h_stddev, float h_mean,
+                     float v_stddev, float v_mean, float* pitch_yaw, float* origin, float* cam2world, int B,
+                     cips_stream_t stream);
+
 /* ------------------------------------------------------------------ */
 /* H5  discriminator native ops                                        */
 /* ------------------------------------------------------------------ */

@@ -1016,6 +1016,39 @@ def test_hip_kernels_match_pigan_lib_second_lineage():
         assert max_rel(w, c["weights"].reshape(b * n, S)) < 1e-5
 
 
+def test_camera_pose_one_launch_matches_the_op_by_op_form():
+    """cips_camera_pose against the torch-op form of comm_utils.py:451-581 (sample_camera_positions for the gaussian and
+    uniform distributions, camera_origin_from_angles, create_cam2world_matrix), including clamped pitches, and against
+    the fp64 evaluation of the same formulas"""
+    import math
+    from cips3d_amd import ops
+    from cips3d_amd.generator import camera_origin_from_angles, create_cam2world_matrix, _normalize
+    d = dev()
+    g = torch.Generator().manual_seed(21)
+    for uniform, hs, vs in ((False, 0.3, 0.155), (True, 0.3, 0.155), (False, 3.0, 3.0)):      # the last one clamps phi
+        for b in (1, 32, 70):
+            fn = torch.rand if uniform else torch.randn
+            th_raw, ph_raw = fn(b, 1, generator=g).to(d), fn(b, 1, generator=g).to(d)
+            hm = vm = math.pi * 0.5
+            py, origin, c2w = ops.camera_pose(th_raw, ph_raw, uniform, hs, hm, vs, vm)
+            if uniform:
+                theta, phi = (th_raw - 0.5) * 2 * hs + hm, (ph_raw - 0.5) * 2 * vs + vm
+            else:
+                theta, phi = th_raw * hs + hm, ph_raw * vs + vm
+            o_ref, pitch = camera_origin_from_angles(theta, phi)
+            c_ref = create_cam2world_matrix(_normalize(-o_ref), o_ref)
+            torch.cuda.synchronize()
+            assert max_rel(py[:, 0:1], pitch) < 1e-6 and max_rel(py[:, 1:2], theta) < 1e-6
+            assert float((origin - o_ref).abs().max()) < 5e-7 and float((c2w - c_ref).abs().max()) < 1e-6
+            # fp64 of the same formulas
+            t64, p64 = theta.double().cpu(), phi.double().cpu().clamp(1e-5, math.pi - 1e-5)
+            o64 = torch.cat([p64.sin() * t64.cos(), p64.cos(), p64.sin() * t64.sin()], -1)
+            assert float((origin.cpu().double() - o64).abs().max()) < 1e-6
+            rot = c2w[:, :3, :3].cpu().double()
+            assert float((rot @ rot.transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max()) < 1e-5      # orthonormal
+            assert torch.equal(c2w[:, 3].cpu(), torch.tensor([0., 0., 0., 1.]).expand(b, 4))
+
+
 def test_mapping_networks_on_hip_match_torch_modules():
     """The two z -> style mapping MLPs (multi_head_mapping.py:130-153) on the HIP kernels (PixelNorm / LayerNorm /
     LeakyReLU row kernels + grouped linear) against the same modules evaluated op by op by torch in fp64: styles and
