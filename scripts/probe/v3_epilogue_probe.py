@@ -31,14 +31,13 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 CASES = [
     ("base", {}),
-    ("column block innermost (dbg 16)", {"CIPS_X3_V3DBG": "16"}),
-    ("column block innermost + nt stores (dbg 20)", {"CIPS_X3_V3DBG": "20"}),
-    ("base again", {}),
-    ("column block innermost (dbg 16)", {"CIPS_X3_V3DBG": "16"}),
-    ("column block innermost + nt stores (dbg 20)", {"CIPS_X3_V3DBG": "20"}),
+    ("non-temporal stores (dbg 4)", {"CIPS_X3_V3DBG": "4"}),
+    ("stores into one L2-resident window (dbg 2)", {"CIPS_X3_V3DBG": "2"}),
+    ("epilogue without its stores (dbg 1)", {"CIPS_X3_V3DBG": "1"}),
     ("skip epilogue (dbg 8)", {"CIPS_X3_V3DBG": "8"}),
-    ("base 3", {}),
-    ("column block innermost (dbg 16)", {"CIPS_X3_V3DBG": "16"}),
+    ("2 start phases, skew 20000 cycles", {"CIPS_X3_V3SKEW": "20000", "CIPS_X3_V3PHASES": "2"}),
+    ("half-chip grid", {"CIPS_X3_V3GRID": "128"}),
+    ("base again", {}),
 ]
 KEYS = ["CIPS_X3_V3DBG", "CIPS_X3_V3SKEW", "CIPS_X3_V3PHASES", "CIPS_X3_V3GRID", "CIPS_X3_V3TOUCH"]
 for name, env in CASES:
@@ -52,9 +51,3 @@ ref = {}
 for fl in F:
     F[fl](); torch.cuda.synchronize()
     ref[fl] = (oP.hi.clone(), oP.lo.clone())
-os.environ["CIPS_X3_V3DBG"] = "16"
-for fl in F:
-    oP.hi.zero_(); oP.lo.zero_()
-    F[fl](); torch.cuda.synchronize()
-    print(f"column-block-innermost variant {fl}: bit-identical {torch.equal(oP.hi, ref[fl][0]) and torch.equal(oP.lo, ref[fl][1])}")
-os.environ.pop("CIPS_X3_V3DBG", None)
