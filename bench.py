@@ -34,8 +34,8 @@ G_CFG = dict(
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--img-size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--num-steps", type=int, default=None, help="coarse samples per ray")
