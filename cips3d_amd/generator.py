@@ -507,12 +507,14 @@ class GeneratorNerfINR(nn.Module):
                     zip(z_nerf.split(b // batch_split), z_inr.split(b // batch_split))]
         return {'z_nerf': z_nerf, 'z_inr': z_inr}
 
-    def mapping_network(self, z_nerf, z_inr):
+    def mapping_network(self, z_nerf, z_inr, defer_join=False):
         style_dict = {}
         if MAPPING_SIDE_STREAM and z_inr.is_cuda and z_inr.shape[0] <= 256:
             # the two z -> style MLPs are independent chains of latency-bound launches: the INR one runs on a side stream —
-            # its forward next to the NeRF mapping, its backward (autograd keeps a node on its forward's stream) next to
-            # the NeRF path's backward.  Fork / join by stream waits, so a captured step records it as parallel branches.
+            # its forward next to the NeRF mapping (and, with defer_join, next to the ray march: forward() joins right
+            # before the INR head, the first consumer of its styles), its backward (autograd keeps a node on its forward's
+            # stream) next to the NeRF path's backward.  Fork / join by stream waits, so a captured step records it as
+            # parallel branches.
             main = torch.cuda.current_stream(z_inr.device)
             side = _side_stream(z_inr.device)
             side.wait_stream(main)
@@ -520,14 +522,23 @@ class GeneratorNerfINR(nn.Module):
                 inr = self.mapping_network_inr(z_inr)
             z_inr.record_stream(side)
             style_dict.update(self.mapping_network_nerf(z_nerf))
-            main.wait_stream(side)
             for t in inr.values():
                 t.record_stream(main)
             style_dict.update(inr)
+            self._pending_side = side
+            if not defer_join:
+                self._join_side()
             return style_dict
         style_dict.update(self.mapping_network_nerf(z_nerf))
         style_dict.update(self.mapping_network_inr(z_inr))
         return style_dict
+
+    def _join_side(self):
+        """the caller's stream waits for the INR mapping MLP (no-op when nothing is pending)"""
+        side = getattr(self, "_pending_side", None)
+        if side is not None:
+            torch.cuda.current_stream(side.device).wait_stream(side)
+            self._pending_side = None
 
     def generate_avg_frequencies(self, num_samples=10000, device='cuda'):
         zs = self.get_zs(num_samples)
@@ -719,6 +730,7 @@ class GeneratorNerfINR(nn.Module):
                     aux = None
             if not nerf_grad:
                 pixels_fea = pixels_fea.detach()
+            self._join_side()
             return self.inr_net(pixels_fea, style_dict), aux
 
         if fused:
@@ -731,6 +743,7 @@ class GeneratorNerfINR(nn.Module):
                                                           self.aux_to_rbg[0].bias)) if return_aux_img else None
             if not nerf_grad:
                 pixels_fea = pixels_fea.detach()
+            self._join_side()
             inr_img = self.inr_net(pixels_fea, style_dict)
         elif gen_rays:
             inr_img, aux_img = pipeline(None, None, None, n, noise_c, u, noise_f, nerf_grad)
@@ -778,7 +791,7 @@ class GeneratorNerfINR(nn.Module):
                 clamp_mode='relu', nerf_noise=0., white_back=False, last_back=False, return_aux_img=False,
                 grad_points=None, forward_points=None, **kwargs):
         """generator.py:1256-1370.  Returns (imgs (b or 2b,3,H,W), pitch_yaw (b or 2b,2))."""
-        style_dict = self.mapping_network(**zs)
+        style_dict = self.mapping_network(**zs, defer_join=not psi < 1)     # joined right before the INR head (_render)
         if psi < 1:
             avg_styles = self.generate_avg_frequencies(device=self.device)
             style_dict = self.get_truncated_freq_phase(raw_style_dict=style_dict, avg_style_dict=avg_styles,
@@ -808,7 +821,7 @@ class GeneratorNerfINR(nn.Module):
                                       nerf_noise=0., white_back=False, last_back=False, return_aux_img=False,
                                       grad_points=None, forward_points=None, up_vector=None, **kwargs):
         """generator.py:1828-1951 (explicit camera; pitch/yaw are zeros)."""
-        style_dict = self.mapping_network(**zs)
+        style_dict = self.mapping_network(**zs, defer_join=not psi < 1)     # joined right before the INR head (_render)
         if psi < 1:
             avg_styles = self.generate_avg_frequencies(device=self.device)
             style_dict = self.get_truncated_freq_phase(raw_style_dict=style_dict, avg_style_dict=avg_styles,
@@ -830,7 +843,7 @@ class GeneratorNerfINR_freeze_NeRF(GeneratorNerfINR):
         self.mapping_network_nerf.load_state_dict(G_ema.mapping_network_nerf.state_dict())
         self.aux_to_rbg.load_state_dict(G_ema.aux_to_rbg.state_dict())
 
-    def mapping_network(self, z_nerf, z_inr):
+    def mapping_network(self, z_nerf, z_inr, defer_join=False):
         style_dict = {}
         if MAPPING_SIDE_STREAM and z_inr.is_cuda and z_inr.shape[0] <= 256:       # see GeneratorNerfINR.mapping_network
             main = torch.cuda.current_stream(z_inr.device)
@@ -841,10 +854,12 @@ class GeneratorNerfINR_freeze_NeRF(GeneratorNerfINR):
             z_inr.record_stream(side)
             with torch.no_grad():
                 style_dict.update(self.mapping_network_nerf(z_nerf))
-            main.wait_stream(side)
             for t in inr.values():
                 t.record_stream(main)
             style_dict.update(inr)
+            self._pending_side = side
+            if not defer_join:
+                self._join_side()
             return style_dict
         with torch.no_grad():
             style_dict.update(self.mapping_network_nerf(z_nerf))
