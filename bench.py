@@ -453,7 +453,9 @@ def main():
         line["allreduce"] = {"ms_median": round(med, 4), "ms_min": round(ts[0], 4), "ms_max": round(ts[-1], 4),
                              "bytes_per_rank": int(ar_bytes[0]),
                              "bus_GBps": round(ar_bytes[0] * 2 * (world - 1) / world / (med * 1e-3) / 1e9, 2) if med > 0 else None,
-                             "frac_of_step": round(med / ms, 4)}
+                             # both terms from this rank's own stream events (median all-reduce / median step)
+                             "step_ms_median_events": round(per_step.get("median", ms), 4),
+                             "frac_of_step": round(med / max(per_step.get("median", ms), 1e-9), 4)}
     if rank == 0 and world == 1 and not a.no_full_step:
         try:
             line["full_step"] = full_gan_step(dev, b, img, 12, steps=4, warmup=2)

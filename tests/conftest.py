@@ -117,3 +117,17 @@ class ReplayDraws:
         torch.rand, torch.randint = self._rand, self._randint
         if exc[0] is None:
             assert next(self._it, None) is None, "recorded draws left over"
+
+
+# Collection order of the GPU set (the driver runs `pytest -x -m gpu`): kernel parity first, then the operator / module /
+# golden-fixture tests, then whole-step tests, and everything that spawns processes or runs bench.py LAST — a late flake
+# in a functional test must never blank the parity rows again.
+_ORDER = ["test_gpu_kernels", "test_gpu_generator", "test_gpu_discriminator", "test_gpu_optim", "test_gpu_eval_path",
+          "test_gpu_real_configs", "test_gpu_train_step", "test_gpu_ddp"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(it):
+        mod = os.path.splitext(os.path.basename(str(it.fspath)))[0]
+        return _ORDER.index(mod) if mod in _ORDER else (len(_ORDER) if mod.startswith("test_gpu") else -1)
+    items.sort(key=key)          # stable: order inside a file is kept
