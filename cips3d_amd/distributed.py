@@ -7,13 +7,16 @@ in the CPU tests), restricted to the parameters that actually received a gradien
 (~0.2 % of G — SinStyleMod.norm.*, to_rgbs 4/8/16 — never do; generator.py:444-445, :1139).
 
 `GradAllReducer` is the steady-state form: which parameters take part is agreed between the ranks
-once (a tiny MAX all-reduce of a presence vector, the same exchange DDP's find_unused_parameters
-does per step) and reused while this rank's own presence pattern stays the same, so a training
-step issues, per bucket, one concatenation, one all-reduce and one multi-tensor copy-back — no
-host synchronisation and no per-parameter launches (the G step is ~21 ms on an MI355X; 170
-per-tensor copies plus a `.tolist()` would cost > 5 % of it)."""
+on EVERY call by a tiny MAX all-reduce of a presence vector (the exchange DDP's
+find_unused_parameters does per step); the bucket plan is rebuilt — locally, from the agreed
+union, so identically on every rank — only when that union or this rank's own pattern changed.
+On a GPU the presence exchange runs on its own control stream: the host is ahead of the device
+when `__call__` runs (the step's backward, or its hipGraph replay, is still executing), so the
+exchange and the host's read of its result complete under the step's own kernels and the main
+stream is never synchronised.  A training step then issues, per bucket, one concatenation, one
+all-reduce and one multi-tensor copy-back — no per-parameter launches (the G step is ~16 ms on an
+MI355X; 170 per-tensor copies would cost > 5 % of it)."""
 import contextlib
-import weakref
 
 import torch
 import torch.distributed as dist
@@ -26,13 +29,13 @@ class GradAllReducer:
     same parameter list.  A parameter whose grad is None on this rank receives the others' mean
     if any rank has one, and stays None if no rank has (find_unused_parameters semantics).
 
-    Contract (that of DDP's static_graph): the set of parameters with a gradient may differ from
-    rank to rank, but when it changes it changes on every rank in the same step — it is a function
-    of the step's configuration (aux image on/off, frozen NeRF, which loss), not of the data.  Each
-    rank re-plans when ITS pattern changes, and the re-plan is a collective.  The contract is
-    checked, cheaply: every bucket carries one extra element, a checksum of the plan it was packed
-    with; the reduced value is compared on the host one call later (through an event that has
-    long completed by then), so diverging ranks raise instead of silently mixing gradients.
+    The set of parameters with a gradient may differ from rank to rank and may change on any subset
+    of the ranks in any step (round 4: the re-plan decision is no longer rank-local — every rank
+    enters the same presence exchange on every call and derives the same plan from its result, so
+    no rank can issue a bucket SUM against a peer's re-plan collective).  Defence in depth: every
+    bucket carries one extra element, a checksum of the plan it was packed with; the reduced value
+    is compared on the host one call later (through an event that has long completed by then), so
+    ranks that were constructed with different parameter lists raise instead of mixing gradients.
 
     Parameters are NOT filtered by `requires_grad` (train.py:335-336, 441-442 toggle it on G and D
     every step): what takes part is decided per call by which gradients exist."""
@@ -74,18 +77,34 @@ class GradAllReducer:
                 p.register_post_accumulate_grad_hook(self._on_grad)
                 if frozen:
                     p.requires_grad_(False)
-        self._grad_refs = None   # weak references to the gradient tensors left behind by the last call (see __call__)
+        self._ctl = None         # control stream of the presence exchange (GPU)
+        self._streams = []       # per bucket: the streams its gradients were produced on in the current backward (hooks)
         self._local = None       # this rank's presence pattern the cached plan was built for
         self._union = None       # the agreed pattern (union over ranks): what `.grad is not None` looks like after a call
         self._buckets = None     # list of lists of parameters (the union over ranks, bucketed)
         self._sig = 0.0
         self._pending = None     # (event, pinned host tensor, expected) of the previous call's plan check
 
-    def _plan(self, local):
+    def _agree(self, local):
+        """the union over ranks of the presence patterns: one MAX all-reduce of len(params) bytes, entered by EVERY rank
+        on EVERY call.  GPU: issued and read back on a control stream that depends on nothing the main stream holds, so
+        the host's wait ends when the tiny collective does, not when the step's kernels do."""
         dev = self.params[0].device
-        present = torch.tensor([1.0 if f else 0.0 for f in local], device=dev)
-        dist.all_reduce(present, op=dist.ReduceOp.MAX, group=self.group)
-        flags = [f > 0 for f in present.tolist()]
+        if dev.type == "cuda":
+            if self._ctl is None:
+                self._ctl = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(self._ctl):
+                present = torch.tensor([1 if f else 0 for f in local], dtype=torch.int32, device=dev)
+                dist.all_reduce(present, op=dist.ReduceOp.MAX, group=self.group)
+                flags = present.tolist()                     # synchronises the control stream only
+        else:
+            present = torch.tensor([1 if f else 0 for f in local], dtype=torch.int32)
+            dist.all_reduce(present, op=dist.ReduceOp.MAX, group=self.group)
+            flags = present.tolist()
+        return tuple(f > 0 for f in flags)
+
+    def _plan(self, local, flags):
+        """bucket plan for the agreed union `flags` — a pure function of (flags, this rank's `local`): no collective"""
         used = [p for p, f in zip(self.params, flags) if f]
         if self.overlap:
             used = used[::-1]                    # backward produces the last layers' gradients first
@@ -117,6 +136,7 @@ class GradAllReducer:
 
     def _reset_step(self):
         self._arrived = [0] * len(self._buckets or [])
+        self._streams = [set() for _ in (self._buckets or [])]
         self._next = 0
         self._inflight = []
         self._dirty = False
@@ -136,6 +156,10 @@ class GradAllReducer:
             self._dirty = True               # a gradient the plan does not expect from this rank: handled in __call__
             return
         self._arrived[b] += 1
+        if p.grad is not None and p.grad.is_cuda:
+            # autograd runs a node on its forward's stream (the INR mapping network's is a side stream, generator.py):
+            # the gradients of one bucket may come from several streams, and they only join when backward() returns
+            self._streams[b].add(torch.cuda.current_stream(p.grad.device))
         before = self._next
         self._issue_ready()
         self._early += self._next - before
@@ -156,10 +180,18 @@ class GradAllReducer:
         if dev.type == "cuda":
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
+            # every stream a gradient of this bucket was produced on (one event on the last hook's stream let
+            # the concatenation read a gradient still being written on another stream)
+            producers = set(self._streams[b]) if b < len(self._streams) else set()
+            producers.add(torch.cuda.current_stream(dev))
+            evs = []
+            for st in producers:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                evs.append(ev)
             with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)        # the gradients of this bucket are complete on the producing stream
+                for ev in evs:
+                    self._side.wait_event(ev)    # the gradients of this bucket are complete on their producing streams
                 sig = torch.full((1,), self._sig_for(grads[0].dtype), device=dev, dtype=grads[0].dtype)
                 flat = torch.cat([g.reshape(-1) for g in grads] + [sig])
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -215,17 +247,12 @@ class GradAllReducer:
         if self.overlap and self._buckets is not None:
             return self._finish_overlapped(world)
         local = tuple(p.grad is not None for p in self.params)
-        # a change of the local pattern (another loss, a frozen sub-net) re-plans; see the contract above.  A caller
-        # that did not reset the gradients to None (zero_grad(set_to_none=False), gradient accumulation) shows the
-        # agreed union pattern on every rank: same plan, no re-plan.  That shortcut is taken only when the gradient
-        # tensors ARE the ones the last call left behind (then every rank sees the union, so the decision is the same
-        # everywhere); a rank whose freshly produced pattern merely happens to equal the old union re-plans like its
-        # peers whose pattern changed — the re-plan is a collective, all ranks or none must enter it.
-        kept = self._grad_refs is not None and local == self._union and all(
-            (not f) or (r is not None and r() is p.grad) for p, f, r in zip(self.params, self._union, self._grad_refs))
-        if local != self._local and not kept:
+        # every rank enters the presence exchange, every call; the plan follows from its result alone.  (A caller that
+        # leaves gradients in place — zero_grad(set_to_none=False) — shows the previous union on every rank: same plan.)
+        union = self._agree(local)
+        if union != self._union or local != self._local:
             self._check_pending(block=True)
-            self._plan(local)
+            self._plan(local, union)
         nbytes = 0
         sigs, wants = [], []
         for bucket in self._buckets:
@@ -247,7 +274,6 @@ class GradAllReducer:
             sigs.append(flat[off:off + 1])
             wants.append(self._sig_for(flat.dtype))
         self._record_sigs(sigs, wants)
-        self._grad_refs = [None if p.grad is None else weakref.ref(p.grad) for p in self.params]
         if self.overlap:
             self._reset_step()
         return nbytes
@@ -274,14 +300,16 @@ class GradAllReducer:
         local = tuple(i in self._seen for i in range(len(self.params)))
         self.last_launched_early = self._early
         self._issue_ready(force=True)             # same bucket order on every rank, whatever arrived
+        # the presence exchange comes AFTER the forced pass: the number of buckets the hooks issued early differs from
+        # rank to rank, the sequence "all buckets of the old plan, then the exchange" does not
+        union = self._agree(local)
         nbytes, sigs, wants = self._drain(world)
         self._record_sigs(sigs, wants)
-        changed = local != self._local
-        if changed:
-            # (contract: every rank sees a change in the same step)  Parameters of the old plan are reduced; agree on the
-            # new union and reduce the parameters that were not part of the old one
+        if union != old_union or local != self._local:
+            # the parameters of the old plan are reduced; the ones new to the union (the same set on every rank: both
+            # unions are agreed values) are reduced now, and the next backward runs under the new plan
             self._check_pending(block=True)
-            self._plan(local)
+            self._plan(local, union)
             extra = [p for p, was, now in zip(self.params, old_union, self._union) if now and not was]
             if extra:
                 for p in extra:

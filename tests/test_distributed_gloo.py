@@ -273,3 +273,94 @@ def test_overlapped_bucket_allreduce_equals_classic_world2_gloo():
             assert (a is None) == (b is None)
             if a is not None:
                 assert torch.equal(torch.from_numpy(a), torch.from_numpy(b))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one-sided pattern changes: the re-plan decision must be collective
+# ------------------------------------------------------------------------------------------------------------------
+_SIDE_USE = {0: (False, False), 1: (False, False), 2: (True, False), 3: (False, False), 4: (False, True), 5: (True, True),
+             6: (True, False)}     # step -> (rank 0 uses `side`, rank 1 uses `side`)
+
+
+def _one_sided_local_grads(rank, step):
+    torch.manual_seed(0)
+    net = _Net()
+    x = torch.randn(32, 16, generator=torch.Generator().manual_seed(1000 + 10 * step + rank))
+    net(x, _SIDE_USE[step][rank]).square().mean().backward()
+    return [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+
+
+def _one_sided_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cips3d_amd.distributed import GradAllReducer
+    out = {}
+    for mode in ("classic", "overlap"):
+        torch.manual_seed(0)
+        net = _Net()
+        params = list(net.parameters())
+        red = GradAllReducer(params, bucket_mb=0.002, overlap=(mode == "overlap"))
+        steps = []
+        for step in sorted(_SIDE_USE):
+            for p in params:
+                p.grad = None
+            x = torch.randn(32, 16, generator=torch.Generator().manual_seed(1000 + 10 * step + rank))
+            net(x, _SIDE_USE[step][rank]).square().mean().backward()
+            red()
+            red._check_pending(block=True)
+            steps.append([None if p.grad is None else p.grad.clone().numpy() for p in params])
+        out[mode] = steps
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pattern_change_on_one_rank_only_replans_collectively_world2_gloo():
+    """Only ONE rank's presence pattern changes (steps 2, 4, 6) — a data-dependent branch, a rank-local skipped loss: before
+    round 4 the changed rank entered the re-plan's MAX all-reduce while its peer issued a bucket SUM (mismatched collectives:
+    an exception over gloo, a hang over RCCL).  Now every rank enters the presence exchange on every call: both forms give the
+    two-rank mean with an absent gradient counted as zero, identically on both ranks, and a parameter that no rank produced a
+    gradient for is None (classic) or zero (overlap: it was part of the plan the backward ran under)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    res = None
+    for _attempt in range(3):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_one_sided_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = {}
+        try:
+            for _ in range(world):
+                r, out = q.get(timeout=120)        # a hang (mismatched collectives) fails here, not at the suite's timeout
+                res[r] = out
+            for p in procs:
+                p.join(timeout=60)
+        except Exception:
+            res = None
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+        if res is not None and len(res) == world and all(p.exitcode == 0 for p in procs):
+            break
+        res = None
+    assert res is not None, "ranks hung or died: the re-plan decision was not collective"
+    for step in sorted(_SIDE_USE):
+        loc = [_one_sided_local_grads(r, step) for r in range(world)]
+        for i in range(len(loc[0])):
+            have = [l[i] for l in loc if l[i] is not None]
+            want = None if not have else sum(have) / world
+            for mode in ("classic", "overlap"):
+                for r in range(world):
+                    got = res[r][mode][step][i]
+                    if want is None:
+                        assert got is None or not got.any(), (mode, r, step, i)
+                        if mode == "classic":
+                            assert got is None, (mode, r, step, i)
+                    else:
+                        assert got is not None and torch.allclose(torch.from_numpy(got), want, atol=1e-7), (mode, r, step, i)
+                a, b = res[0][mode][step][i], res[1][mode][step][i]
+                assert (a is None) == (b is None) and (a is None or (a == b).all()), (mode, step, i)
