@@ -112,6 +112,7 @@ SIGNATURES = {
     "cips_resample_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, C.POINTER(RayParams), vp]),
     "cips_composite_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_composite_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "cips_debug_clamp": (i32, [vp, vp]),
     "cips_gemm_f32": (i32, [C.POINTER(GemmDesc), vp]),
     "cips_gemm_bf16x3": (i32, [C.POINTER(GemmX3Desc), vp]),
     "cips_gemm_bf16x3_fuses_torgb": (i32, [C.POINTER(GemmX3Desc)]),

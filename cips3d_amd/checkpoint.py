@@ -79,11 +79,17 @@ class Checkpointer:
     def load_state_dict_from_file(self, path, rank=0, strict=True):
         sd = torch.load(path, map_location="cpu", weights_only=False)
         # a file written as {'model': state_dict} / {'state_dict': state_dict} (common wrappers) loads too
+        # — but only when exactly ONE candidate key is present: a file holding both 'generator' and 'G_ema' names two
+        # networks, and picking one silently (with strict=False nothing would complain) loads the wrong one
         if isinstance(sd, dict) and sd and not any(torch.is_tensor(v) for v in sd.values()):
-            for key in ("model", "state_dict", "G_ema", "generator"):
-                if isinstance(sd.get(key), dict):
-                    sd = sd[key]
-                    break
+            cands = [k for k in ("model", "state_dict", "G_ema", "generator") if isinstance(sd.get(k), dict)]
+            if len(cands) > 1:
+                raise KeyError(f"{path}: several state dicts in one file ({cands}; keys: {list(sd.keys())}) — "
+                               f"pass the one to load, e.g. torch.load(path)['{cands[0]}']")
+            if cands:
+                if rank == 0:
+                    print(f"Checkpointer: loading the state dict under key '{cands[0]}' of {path}")
+                sd = sd[cands[0]]
         res = self.model.load_state_dict(sd, strict=strict)
         from .discriminator import invalidate_weight_cache
         invalidate_weight_cache(self.model)

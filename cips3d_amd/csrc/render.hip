@@ -180,7 +180,19 @@ struct CompArgs {
   float *dfeat_c, *dsig_c, *dfeat_f, *dsig_f;
   long long R;
   int S, E, clamp_mode, flags;
+  // debug hook (cips_debug_clamp): the relu clamp's branch per (ray, sorted position), supplied / recorded
+  const unsigned char* clamp_pin;
+  unsigned char* clamp_rec;
 };
+
+// relu(sigma + noise) with the branch taken from a supplied decision (the other branch's linear extension), so that two
+// evaluations whose pre-activations differ by rounding differentiate the SAME function (tests only; pigan_utils.py:246-252)
+__device__ __forceinline__ bool clamp_pass(const CompArgs& a, float x, long long idx, bool store) {
+  bool pass = x > 0.f;
+  if (a.clamp_pin) pass = a.clamp_pin[idx] != 0;
+  if (a.clamp_rec && store) a.clamp_rec[idx] = pass ? 1 : 0;
+  return pass;
+}
 
 __device__ __forceinline__ const float* feat_row(const CompArgs& a, long long ray, int i) {
   // i indexes torch.cat([fine, coarse]) when a fine set exists
@@ -234,7 +246,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a) {
     const float delta = (k + 1 < E) ? (zall[ord[k + 1]] - zk) : 1e10f;
     float sg = sall[i];
     if (a.noise) sg += a.noise[ray * E + k] * a.noise_std;
-    al[k] = 1.f - expf(-delta * clamp_density(sg, a.clamp_mode));
+    float dens = clamp_density(sg, a.clamp_mode);
+    if ((a.clamp_pin || a.clamp_rec) && a.clamp_mode == 0) dens = clamp_pass(a, sg, ray * E + k, active) ? sg : 0.f;
+    al[k] = 1.f - expf(-delta * dens);
   }
   __syncthreads();
 
@@ -333,7 +347,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a) {
   double T = 1.0;
   for (int k = 0; k < E; ++k) {
     const float delta = (k + 1 < E) ? (zall[k + 1] - zall[k]) : 1e10f;
-    const float dens = clamp_density(xs[k], a.clamp_mode);
+    float dens = clamp_density(xs[k], a.clamp_mode);
+    if (a.clamp_pin && a.clamp_mode == 0) dens = a.clamp_pin[ray * E + k] ? xs[k] : 0.f;
     const float alpha = 1.f - expf(-delta * dens);
     const float Tf = (float)T;
     wsum += alpha * Tf;
@@ -369,9 +384,15 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a) {
     if ((k % SEG) == sub && active) {
       const float delta = (k + 1 < E) ? (zall[k + 1] - zall[k]) : 1e10f;
       const float x = xs[k];
-      const float dens = clamp_density(x, a.clamp_mode);
+      float dens = clamp_density(x, a.clamp_mode);
+      float dgrad = clamp_density_grad(x, a.clamp_mode);
+      if (a.clamp_pin && a.clamp_mode == 0) {
+        const bool pass = a.clamp_pin[ray * E + k] != 0;
+        dens = pass ? x : 0.f;
+        dgrad = pass ? 1.f : 0.f;
+      }
       // d alpha / d dens = delta * exp(-delta*dens)
-      *dsg = dalpha * (delta * expf(-delta * dens)) * clamp_density_grad(x, a.clamp_mode);
+      *dsg = dalpha * (delta * expf(-delta * dens)) * dgrad;
     }
   }
 }
@@ -383,6 +404,19 @@ inline int rays_per_block_for(size_t bytes_per_ray) {
 }
 
 }  // namespace
+
+// Debug hook (tests): while set, every composite / fused-march launch takes the relu clamp's branch of sample (ray, sorted
+// position k) from pin[ray*E + k] (0 = clamped) and/or writes the branch it took to rec[ray*E + k].  Process-global and not
+// thread-safe by design: set, launch, reset (cips3d_amd.ops.clamp_debug does exactly that).
+namespace cips_dbg {
+const unsigned char* clamp_pin = nullptr;
+unsigned char* clamp_rec = nullptr;
+}
+extern "C" int cips_debug_clamp(const unsigned char* pin, unsigned char* rec) {
+  cips_dbg::clamp_pin = pin;
+  cips_dbg::clamp_rec = rec;
+  return 0;
+}
 
 extern "C" int cips_rays_fwd(const float* xg, const float* yg, const float* zg, float zc,
                              const float* cam2world, const float* jitter, float* points, float* z,
@@ -427,6 +461,7 @@ extern "C" int cips_composite_fwd(const float* feat_c, const float* sig_c, const
   a.noise = noise; a.noise_std = noise_std; a.fea = fea; a.depth = depth; a.weights = weights;
   a.order = order; a.zsorted = zsorted; a.R = R; a.S = S; a.E = feat_f ? 2 * S : S;
   a.clamp_mode = clamp_mode; a.flags = flags;
+  a.clamp_pin = cips_dbg::clamp_pin; a.clamp_rec = cips_dbg::clamp_rec;
   size_t per_ray = (size_t)4 * a.E * sizeof(float);
   int rpb = rays_per_block_for(per_ray);
   int blocks = (R + rpb - 1) / rpb;
@@ -445,6 +480,7 @@ extern "C" int cips_composite_bwd(const float* feat_c, const float* sig_c, const
   a.noise = noise; a.noise_std = noise_std; a.order_in = order; a.dfea = dfea;
   a.dfeat_c = dfeat_c; a.dsig_c = dsig_c; a.dfeat_f = dfeat_f; a.dsig_f = dsig_f;
   a.R = R; a.S = S; a.E = feat_f ? 2 * S : S; a.clamp_mode = clamp_mode; a.flags = flags;
+  a.clamp_pin = cips_dbg::clamp_pin; a.clamp_rec = nullptr;
   size_t per_ray = (size_t)6 * a.E * sizeof(float);
   int rpb = rays_per_block_for(per_ray);
   int blocks = (R + rpb - 1) / rpb;

@@ -37,6 +37,11 @@
 #include "raygen.h"
 #include <cstdlib>
 
+namespace cips_dbg {          // debug hook of the relu clamp (cips_debug_clamp, render.hip)
+extern const unsigned char* clamp_pin;
+extern unsigned char* clamp_rec;
+}
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -865,9 +870,12 @@ struct MarchArgs {
   float *weights;            // (B, n, S) or NULL
   float *feat, *sigma, *zout;   // per-sample outputs (B, P, 32), (B, P), (B, P) or NULL
   int B, rays_per_wg;
+  const unsigned char* clamp_pin;   // debug hook (cips_debug_clamp, render.hip): relu branch per (ray, sample) supplied /
+  unsigned char* clamp_rec;         // recorded; both NULL outside tests
 };
 
-template <bool HW>
+
+template <bool HW, bool DBG>
 __global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
   extern __shared__ __attribute__((aligned(1024))) uchar smem[];
   const int b = blockIdx.y;
@@ -924,7 +932,13 @@ __global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
       // ---- composite (pigan_utils.py:239-258): alpha = 1 - exp(-delta * clamp(sigma + noise)), w = alpha * T ----
       const float delta = (s + 1 < S) ? (zn - zs) : 1e10f;
       const float sg = a.noise ? sig + nse * a.noise_std : sig;
-      const float dens = (a.clamp_mode == 1) ? ((sg > 20.f) ? sg : log1pf(expf(sg))) : fmaxf(sg, 0.f);
+      float dens = (a.clamp_mode == 1) ? ((sg > 20.f) ? sg : log1pf(expf(sg))) : fmaxf(sg, 0.f);
+      if (DBG && a.clamp_mode == 0) {      // the debug instantiation only: the production kernel's code is untouched
+        bool pass = sg > 0.f;
+        if (a.clamp_pin) pass = a.clamp_pin[rs + s] != 0;
+        if (a.clamp_rec && valid && hf == 0) a.clamp_rec[rs + s] = pass ? 1 : 0;
+        dens = pass ? sg : 0.f;
+      }
       const float alpha = 1.f - expf(-delta * dens);
       const float w = alpha * (float)T;
       T *= (double)(1.f - alpha + 1e-10f);
@@ -1209,6 +1223,7 @@ extern "C" int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_par
   if (rc) return rc;
   a.noise = noise; a.noise_std = noise_std; a.clamp_mode = clamp_mode; a.flags = flags;
   a.fea = fea; a.depth = depth; a.weights = weights; a.feat = feat; a.sigma = sigma; a.zout = z; a.B = B;
+  a.clamp_pin = cips_dbg::clamp_pin; a.clamp_rec = cips_dbg::clamp_rec;
   // a workgroup's 8 waves take 32 rays each: 256-ray chunks keep all of them busy; halve only for small images
   a.rays_per_wg = 256;
   const int n = a.rg.n;
@@ -1217,14 +1232,20 @@ extern "C" int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_par
   static bool attr_set = false;
   CIPS_PER_DEVICE(attr_set, false);
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  if (w->trig_mode == 1)
-    hipLaunchKernelGGL(siren_march_x3_kernel<true>, grid, dim3(512), smem, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(siren_march_x3_kernel<false>, grid, dim3(512), smem, (hipStream_t)stream, a);
+  const bool dbg = a.clamp_pin || a.clamp_rec;
+  if (w->trig_mode == 1) {
+    if (dbg) hipLaunchKernelGGL((siren_march_x3_kernel<true, true>), grid, dim3(512), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((siren_march_x3_kernel<true, false>), grid, dim3(512), smem, (hipStream_t)stream, a);
+  } else {
+    if (dbg) hipLaunchKernelGGL((siren_march_x3_kernel<false, true>), grid, dim3(512), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((siren_march_x3_kernel<false, false>), grid, dim3(512), smem, (hipStream_t)stream, a);
+  }
   return CIPS_CHECK_LAUNCH();
 }
 

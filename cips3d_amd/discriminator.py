@@ -334,6 +334,12 @@ def _cached(w, scale, kind, build):
     """build(w_eff) -> operand for `kind`, memoised on (parameter, version, scale)"""
     if not (_WCACHE_ON and isinstance(w, nn.Parameter)):
         return build(w if scale == 1.0 else w * scale)
+    if w.is_cuda and torch.cuda.is_current_stream_capturing():
+        # hipGraph capture (ADVICE r3): a replay runs no Python and never bumps `_version`, so cached planes would go
+        # stale against the captured optimizer's updates, and planes built here live in the graph's private pool —
+        # build them inside the capture (every replay rebuilds them from the current weights) and keep nothing
+        with torch.no_grad():
+            return build(w.detach() if scale == 1.0 else w.detach() * scale)
     slot = _WCACHE.get(id(w))                              # entries die with the Parameter object
     if slot is None or slot[0]() is not w:
         key_id = id(w)
@@ -903,20 +909,26 @@ def _diffaug_hip(x, parts):
 
 def DiffAugment(x, policy='', channels_first=True):
     """exp/cips3d/models/diffaug.py:9-85 (color, translation, cutout) as one fused HIP operator with its adjoint
-    (cips_diffaug).  Policies are the reference's stage names in the reference's order (any subsequence of
-    color,translation,cutout: what its configs use); the product has no CPU path."""
+    (cips_diffaug).  Policies are the reference's stage names, applied in the order listed like the reference does
+    (color,translation,cutout and its subsequences — what the configs use — as one launch); no CPU path."""
     if not policy:
         return x
     parts = tuple(policy.split(','))
-    if any(p not in _POLICY_ORDER for p in parts) or list(parts) != [p for p in _POLICY_ORDER if p in parts]:
-        raise ValueError(f"DiffAugment policy {policy!r}: stages must be a subsequence of {','.join(_POLICY_ORDER)}")
+    if any(p not in _POLICY_ORDER for p in parts):
+        raise ValueError(f"DiffAugment policy {policy!r}: unknown stage (known: {','.join(_POLICY_ORDER)})")
+    # the canonical order (what the reference's configs use) is ONE fused launch; any other order or a repeated stage
+    # runs the reference's way — stage by stage in the order listed (diffaug.py:13-16), each stage one launch of the
+    # same operator, draws in the reference's order
+    runs = [parts] if list(parts) == [p for p in _POLICY_ORDER if p in parts] else [(p,) for p in parts]
     if not x.is_cuda or x.dim() != 4:
         raise RuntimeError("DiffAugment runs on the HIP operator only: a 4-d GPU batch is required")
     if not channels_first:
         x = x.permute(0, 3, 1, 2)
     if x.shape[1] > 4:
         raise RuntimeError("DiffAugment: at most 4 channels (images)")
-    y = _diffaug_hip(x, parts)
+    y = x
+    for run in runs:
+        y = _diffaug_hip(y, run)
     if not channels_first:
         y = y.permute(0, 2, 3, 1)
     return y.contiguous()

@@ -406,7 +406,7 @@ def camera_origin_from_angles(theta, phi, r=1.0):
 def _truncated_normal(shape, device):
     """comm_utils.py:441-448: per element the first of four standard-normal draws that lies in (-2, 2) (the first
     draw if none does)."""
-    tmp = torch.empty(tuple(shape) + (4,), device=device).normal_()
+    tmp = torch.randn(tuple(shape) + (4,), device=device)      # = empty().normal_(): the same draws
     ok = (tmp < 2) & (tmp > -2)
     first = ok.max(-1, keepdim=True)[1]
     return tmp.gather(-1, first).squeeze(-1)
@@ -805,15 +805,21 @@ class GeneratorNerfINR(nn.Module):
     def _forward_styles(self, style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                         h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise, white_back,
                         last_back, return_aux_img, forward_points, rand_override=None, grad_points=None, **cam):
-        if forward_points is not None:
-            with torch.no_grad():
-                return self._render(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
-                                    h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise,
-                                    white_back, last_back, return_aux_img, forward_points=forward_points,
-                                    rand_override=rand_override, **cam)
-        return self._render(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean,
-                            v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise, white_back, last_back,
-                            return_aux_img, rand_override=rand_override, grad_points=grad_points, **cam)
+        try:
+            if forward_points is not None:
+                with torch.no_grad():
+                    return self._render(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                                        h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise,
+                                        white_back, last_back, return_aux_img, forward_points=forward_points,
+                                        rand_override=rand_override, **cam)
+            return self._render(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean,
+                                v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise, white_back, last_back,
+                                return_aux_img, rand_override=rand_override, grad_points=grad_points, **cam)
+        finally:
+            # a deferred INR-mapping side stream is joined on EVERY exit (no-op after _render's own join): an exception
+            # before the INR head must not leave the fork open — the main stream would never wait for it, and a
+            # hipGraph capture would end with an unjoined stream
+            self._join_side()
 
     def forward_camera_pos_and_lookup(self, zs, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                                       h_mean, v_mean, hierarchical_sample, camera_pos, camera_lookup, psi=1,

@@ -73,10 +73,14 @@ def pixel_grids(W, H, S, ray_start, ray_end, device):
     key = (W, H, S, float(ray_start), float(ray_end), str(device))
     g = _GRIDS.get(key)
     if g is None:
+        g = (torch.linspace(-1, 1, W, device=device), torch.linspace(1, -1, H, device=device),
+             torch.linspace(ray_start, ray_end, S, device=device))
+        if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return g        # built inside a hipGraph capture: the tensors live in the graph's pool and hold data only
+                            # during replays — never cached for eager callers
         if len(_GRIDS) > 64:
             _GRIDS.clear()
-        g = _GRIDS[key] = (torch.linspace(-1, 1, W, device=device), torch.linspace(1, -1, H, device=device),
-                           torch.linspace(ray_start, ray_end, S, device=device))
+        _GRIDS[key] = g
     return g
 
 def rays_fwd(xg, yg, zg, zc, cam2world, jitter, B, H, W, S):
@@ -360,9 +364,14 @@ class CompositeFunction(torch.autograd.Function):
         weights = torch.empty(R, E, device=dev)
         order = torch.empty(R, E, device=dev, dtype=torch.int32)
         zs = torch.empty(R, E, device=dev)
-        check(lib.cips_composite_fwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
-                                     float(noise_std), _p(fea), _p(depth), _p(weights), _p(order), _p(zs),
-                                     R, S, clamp_mode, flags, _stream()), "cips_composite_fwd")
+        pin, rec = _clamp_debug_forward(R, E, clamp_mode, dev)
+        with _clamp_hook(pin, rec):
+            check(lib.cips_composite_fwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
+                                         float(noise_std), _p(fea), _p(depth), _p(weights), _p(order), _p(zs),
+                                         R, S, clamp_mode, flags, _stream()), "cips_composite_fwd")
+        if rec is not None and CLAMP_REC is not None:
+            CLAMP_REC.append(rec.reshape(R, E))
+        ctx.clamp_mask = rec                      # the branches this forward took: the backward takes the same ones
         ctx.save_for_backward(feat_c, sig_c, z_c, feat_f, sig_f, z_f, noise, order)
         ctx.meta = (float(noise_std), clamp_mode, flags, hier)
         ctx.mark_non_differentiable(depth, weights, order, zs)
@@ -379,9 +388,10 @@ class CompositeFunction(torch.autograd.Function):
         dsig_c = torch.empty_like(sig_c)
         dfeat_f = torch.empty_like(feat_f) if hier else None
         dsig_f = torch.empty_like(sig_f) if hier else None
-        check(lib.cips_composite_bwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
-                                     noise_std, _p(order), _p(dfea), _p(dfeat_c), _p(dsig_c), _p(dfeat_f),
-                                     _p(dsig_f), R, S, clamp_mode, flags, _stream()), "cips_composite_bwd")
+        with _clamp_hook(ctx.clamp_mask, None):
+            check(lib.cips_composite_bwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
+                                         noise_std, _p(order), _p(dfea), _p(dfeat_c), _p(dsig_c), _p(dfeat_f),
+                                         _p(dsig_f), R, S, clamp_mode, flags, _stream()), "cips_composite_bwd")
         return dfeat_c, dsig_c, None, dfeat_f, dsig_f, None, None, None, None, None
 
 
@@ -615,8 +625,13 @@ class RayMarchFunction(torch.autograd.Function):
         z = torch.empty(B, n * S, device=dev) if train else None
         sw = _siren_struct(t)
         rp = _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S)
-        check(lib.cips_march_fwd_x3(C.byref(sw), C.byref(rp), _p(noise), float(noise_std), clamp_mode, flags, _p(fea),
-                                    _p(depth), None, _p(feat), _p(sigma), _p(z), B, _stream()), "cips_march_fwd_x3")
+        pin, rec = _clamp_debug_forward(B * n, S, clamp_mode, dev)
+        with _clamp_hook(pin, rec):
+            check(lib.cips_march_fwd_x3(C.byref(sw), C.byref(rp), _p(noise), float(noise_std), clamp_mode, flags, _p(fea),
+                                        _p(depth), None, _p(feat), _p(sigma), _p(z), B, _stream()), "cips_march_fwd_x3")
+        if rec is not None and CLAMP_REC is not None:
+            CLAMP_REC.append(rec.reshape(B * n, S))
+        ctx.clamp_mask = rec
         if train:
             ctx.save_for_backward(xg, yg, zg, cam2world, jitter, noise, feat, sigma, z, *[t[k] for k in _SIREN_NAMES])
         ctx.geom = geom
@@ -634,9 +649,10 @@ class RayMarchFunction(torch.autograd.Function):
         dfea = _c(dfea)
         dfeat = torch.empty_like(feat)
         dsig = torch.empty_like(sigma)
-        check(lib.cips_composite_bwd(_p(feat), _p(sigma), _p(z), None, None, None, _p(noise), float(noise_std), None,
-                                     _p(dfea), _p(dfeat), _p(dsig), None, None, R, S, clamp_mode, flags, _stream()),
-              "cips_composite_bwd")
+        with _clamp_hook(ctx.clamp_mask, None):
+            check(lib.cips_composite_bwd(_p(feat), _p(sigma), _p(z), None, None, None, _p(noise), float(noise_std), None,
+                                         _p(dfea), _p(dfeat), _p(dsig), None, None, R, S, clamp_mode, flags, _stream()),
+                  "cips_composite_bwd")
         rp = _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S)
         grads = _siren_backward(t, dfeat, dsig, B, n * S, rays=rp)
         return (None,) * 7 + grads
@@ -721,6 +737,61 @@ GATE_REC = None
 # iterator of such tensors) replaces them — parity tests compare gradients for the SAME sample placement.
 FINE_Z_PIN = None
 FINE_Z_REC = None
+
+
+# The third discontinuity: relu(sigma + nerf_noise * eps) in fancy_integration (pigan_utils.py:246-252).  The reference trains
+# its first 5 000 steps with nerf_noise 1 -> 0 (train.py:325-327); a pre-activation within rounding of 0 takes either
+# branch, and the two gradients of the sigma head (sums of d sigma with heavy cancellation) move by a finite amount per
+# flipped sample.  CLAMP_PIN: iterator of uint8 tensors (R, E) (R rays, E sorted positions; 0 = clamped, else the linear
+# branch), one per composite / fused-march forward in call order — forward AND backward then take the branch from it.
+# CLAMP_REC: list receiving the branches each forward actually took.
+CLAMP_PIN = None
+CLAMP_REC = None
+
+
+class clamp_debug:
+    """with clamp_debug(pin=[mask, ...] or None, rec=list or None): ...   (tests only)"""
+
+    def __init__(self, pin=None, rec=None):
+        self.pin, self.rec = pin, rec
+
+    def __enter__(self):
+        global CLAMP_PIN, CLAMP_REC
+        self.old = (CLAMP_PIN, CLAMP_REC)
+        CLAMP_PIN = iter(self.pin) if self.pin is not None else None
+        CLAMP_REC = self.rec
+        return self
+
+    def __exit__(self, *exc):
+        global CLAMP_PIN, CLAMP_REC
+        CLAMP_PIN, CLAMP_REC = self.old
+
+
+class _clamp_hook:
+    """sets the library's process-global clamp hook around ONE launch (cips_debug_clamp); a no-op unless debugging"""
+
+    def __init__(self, pin, rec):
+        self.pin, self.rec = pin, rec
+
+    def __enter__(self):
+        if self.pin is not None or self.rec is not None:
+            check(_lib.load().cips_debug_clamp(_p(self.pin), _p(self.rec)), "cips_debug_clamp")
+
+    def __exit__(self, *exc):
+        if self.pin is not None or self.rec is not None:
+            _lib.load().cips_debug_clamp(None, None)
+
+
+def _clamp_debug_forward(R, E, clamp_mode, dev):
+    """-> (pin, rec) for one composite forward of R rays x E positions: both None outside clamp_debug / for softplus"""
+    if (CLAMP_PIN is None and CLAMP_REC is None) or clamp_mode != 0:
+        return None, None
+    pin = None
+    if CLAMP_PIN is not None:
+        pin = next(CLAMP_PIN).to(device=dev, dtype=torch.uint8).reshape(-1).contiguous()
+        if pin.numel() != R * E:
+            raise ValueError(f"clamp_debug: pinned mask of {pin.numel()} entries for {R} rays x {E} positions")
+    return pin, torch.empty(R * E, dtype=torch.uint8, device=dev)
 
 
 class resample_debug:

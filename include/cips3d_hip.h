@@ -219,6 +219,14 @@ int cips_composite_bwd(const float* feat_c, const float* sig_c, const float* z_c
                        float* dfeat_c, float* dsig_c, float* dfeat_f, float* dsig_f,
                        int R, int S, int clamp_mode, int flags, cips_stream_t stream);
 
+/* Debug hook for parity tests (no reference counterpart; pigan_utils.py:246-252 is the clamp it pins):
+ * relu(sigma + nerf_noise * eps) is a discontinuity of the gradient — two evaluations whose pre-activations differ
+ * by rounding may take different branches.  While `pin` is set, every cips_composite_fwd / cips_composite_bwd /
+ * cips_march_fwd_x3 launch takes the branch of sample (ray, sorted position k) from pin[ray*E + k] (0 = clamped,
+ * else the linear branch); while `rec` is set the forward launches write the branch they took to rec[ray*E + k].
+ * Process-global, not thread-safe: set, launch, reset with (NULL, NULL). */
+int cips_debug_clamp(const unsigned char* pin, unsigned char* rec);
+
 /* ------------------------------------------------------------------ */
 /* generic batched fp32 GEMM on v_mfma_f32_32x32x2_f32 with fused epilogues */
 /* the workhorse under H4 (bmm in exp/comm/models/mod_conv_fc.py:489),  */

@@ -195,7 +195,46 @@ def siren(sd, points, w_nerf, prefix="siren."):
 # H3 — exp/pigan/pigan_utils.py:164-209 (sample_pdf), :212-273 (fancy_integration),
 #       exp/dev/nerf_inr/models/generator_nerf_inr.py:537-598, generator.py:1733-1752
 # ----------------------------------------------------------------------------------------
-def integrate(rgb_sigma, z, noise, noise_std, dim_rgb=32, clamp_mode="relu", last_back=False, white_back=False):
+class ClampTape:
+    """Test infrastructure, like GateTape: the branch relu(sigma + nerf_noise * eps) took per (image, ray, sorted position)
+    in the differentiable composite (pigan_utils.py:246-252).  pin=None records (x > 0); else an iterable of bool / uint8
+    tensors (b, n, E[, 1]) replayed in call order: relu(x) becomes x * pinned, the pinned branch's linear extension."""
+
+    def __init__(self, pin=None):
+        self.rec = []
+        self.preact = []
+        self._pin = iter(pin) if pin is not None else None
+
+    def relu(self, x):
+        self.preact.append(x.detach())
+        if self._pin is None:
+            self.rec.append((x > 0).detach())
+            return F.relu(x)
+        g = next(self._pin).to(x.device).reshape(x.shape) != 0
+        self.rec.append(g)
+        return x * g.to(x.dtype)
+
+
+_CLAMP_TAPE = [None]
+
+
+class clamp_tape:
+    """with clamp_tape(tape): the FINAL composite of every generator forward below (not the no-grad coarse composite that
+    only feeds the resampler — the fine-sample placement has its own pin, fine_z_pin) goes through `tape`."""
+
+    def __init__(self, tape):
+        self.tape = tape
+
+    def __enter__(self):
+        self.old = _CLAMP_TAPE[0]
+        _CLAMP_TAPE[0] = self.tape
+        return self.tape
+
+    def __exit__(self, *exc):
+        _CLAMP_TAPE[0] = self.old
+
+
+def integrate(rgb_sigma, z, noise, noise_std, dim_rgb=32, clamp_mode="relu", last_back=False, white_back=False, tape=None):
     """rgb_sigma (b,n,E,33), z (b,n,E,1), noise (b,n,E,1) raw randn -> rgb (b,n,32), depth, weights."""
     rgbs, sig = rgb_sigma[..., :dim_rgb], rgb_sigma[..., dim_rgb:]
     d = z[:, :, 1:] - z[:, :, :-1]
@@ -204,7 +243,7 @@ def integrate(rgb_sigma, z, noise, noise_std, dim_rgb=32, clamp_mode="relu", las
     if clamp_mode == "softplus":
         a = 1 - torch.exp(-d * F.softplus(sig + nz))
     elif clamp_mode == "relu":
-        a = 1 - torch.exp(-d * F.relu(sig + nz))
+        a = 1 - torch.exp(-d * (tape.relu(sig + nz) if tape is not None else F.relu(sig + nz)))
     else:
         raise AssertionError("Need to choose clamp mode")
     shifted = torch.cat([torch.ones_like(a[:, :, :1]), 1 - a + 1e-10], -2)
@@ -332,7 +371,7 @@ def _points_forward(sd, w_nerf, w_inr, pts, z, origins, dirs, b, n, S, hierarchi
     else:
         all_o, all_z, idx, fz, fp, book, fine = coarse, z, None, None, None, None, None
     fea, depth, weights = integrate(all_o, all_z, noise_f, nerf_noise, clamp_mode=clamp_mode, last_back=last_back,
-                                    white_back=white_back)
+                                    white_back=white_back, tape=_CLAMP_TAPE[0])
     inr = inr_head(sd, fea, w_inr)
     aux = None
     if return_aux_img:

@@ -38,7 +38,9 @@ def test_diffaugment_product_has_no_torch_restatement():
     with pytest.raises(RuntimeError):
         dm.DiffAugment(torch.zeros(1, 3, 8, 8), policy="color")           # CPU tensor
     with pytest.raises(ValueError):
-        dm.DiffAugment(torch.zeros(1, 3, 8, 8), policy="cutout,color")    # not the reference's stage order
+        dm.DiffAugment(torch.zeros(1, 3, 8, 8), policy="cutout,colour")   # unknown stage name
+    with pytest.raises(RuntimeError):
+        dm.DiffAugment(torch.zeros(1, 3, 8, 8), policy="cutout,color")    # any order of known stages is a policy; CPU is not
     assert dm.DiffAugment(torch.zeros(1, 3, 8, 8), policy="") is not None
 
 

@@ -219,6 +219,74 @@ def test_overlapped_gradient_buckets_on_gpu_equal_classic():
             assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
 
 
+def test_overlap_bucket_waits_for_every_stream_its_gradients_were_produced_on(monkeypatch):
+    """with the INR mapping MLP on a side stream the gradients of one bucket come from two streams, and autograd
+    joins them only when backward() returns — a bucket issued from a hook must wait for ALL of them, not for the stream the
+    last hook happened to run on.  One process, the collective replaced by a stub (x2 in place on the issuing stream = the
+    SUM over two identical ranks), so the stream ordering is the only thing under test: parameter `a` is used on a side
+    stream behind a ~50 ms spin kernel in its backward, parameter `b` on the main stream and its hook fires last."""
+    from cips3d_amd import distributed as dmod
+    d = torch.device("cuda:0")
+
+    class _Work:
+        def wait(self):
+            return True
+
+    class _Dist:
+        ReduceOp = dist.ReduceOp
+        calls = []
+
+        @staticmethod
+        def is_available(): return True
+        @staticmethod
+        def is_initialized(): return True
+        @staticmethod
+        def get_world_size(group=None): return 2
+
+        @staticmethod
+        def all_reduce(t, op=None, group=None, async_op=False):
+            _Dist.calls.append((tuple(t.shape), str(op)))
+            if op == dist.ReduceOp.SUM:
+                t.mul_(2)
+            return _Work()
+
+    monkeypatch.setattr(dmod, "dist", _Dist)
+
+    class _Slow(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            torch.cuda._sleep(100_000_000)        # ~50 ms on the stream of the forward (the side stream)
+            return g * 3.0
+
+    a = torch.nn.Parameter(torch.ones(1 << 16, device=d))
+    b = torch.nn.Parameter(torch.ones(1 << 16, device=d))
+    red = dmod.GradAllReducer([a, b], bucket_mb=64.0, overlap=True)
+    side = torch.cuda.Stream()
+    n_streams = []
+    for step in range(3):                          # step 0 plans (classic path); steps 1-2 issue from hooks
+        a.grad = b.grad = None
+        main = torch.cuda.current_stream()
+        yb = (b * 2.0).sum()                       # created first: its backward runs last
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ya = _Slow.apply(a * 5.0).sum()
+        main.wait_stream(side)
+        (ya + yb).backward()
+        if step:
+            n_streams.append(len(red._streams[0]))
+        red()
+        torch.cuda.synchronize()
+        assert torch.equal(a.grad, torch.full_like(a, 15.0)), (step, float(a.grad[0]))
+        assert torch.equal(b.grad, torch.full_like(b, 2.0)), (step, float(b.grad[0]))
+        if step:
+            assert red.last_launched_early == 1    # the bucket WAS issued from the hooks, during backward
+    assert all(n >= 1 for n in n_streams)
+
+
 def test_bench_two_ranks_gloo_functional_run_reports_the_exchange():
     """`bench.py --gpus 2` as the driver launches N > 1 runs (self-spawned torch.distributed.run ranks), here over gloo with
     both ranks on the box's one GPU (CIPS_BENCH_BACKEND=gloo: a functional check, never a measurement): the JSON line must

@@ -201,6 +201,39 @@ def test_diffaugment_hip_operator_matches_reference_golden():
     assert abs(o1 - o0) <= 1e-5 * abs(o0) and max_rel(g1, g0) < 1e-5 and abs(w1 - w0) <= 1e-4 * abs(w0), (o1, o0, w1, w0)
 
 
+@pytest.mark.parametrize("policy", ["translation,color", "cutout,color,translation", "cutout,translation", "color,color"])
+def test_diffaugment_applies_stages_in_the_order_listed(policy):
+    """diffaug.py:13-16 applies the stages in the order the policy lists them (the product only took subsequences
+    of color,translation,cutout): a non-canonical order runs stage by stage on the same operator, with the reference's draw
+    order — output and input gradient against the oracle's op-by-op form on the same draws."""
+    from conftest import ReplayDraws
+    from cips3d_amd import discriminator as dm
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77)
+    b, h, w = 3, 20, 24
+    x = torch.randn(b, 3, h, w, generator=g)
+    g0 = torch.randn(b, 3, h, w, generator=g)
+    draws = []
+    for st in policy.split(","):
+        if st == "color":
+            draws += [("rand", torch.rand(b, 1, 1, 1, generator=g)) for _ in range(3)]
+        elif st == "translation":
+            sx, sy = int(h * 0.125 + 0.5), int(w * 0.125 + 0.5)
+            draws += [("randint", torch.randint(-sx, sx + 1, (b, 1, 1), generator=g)), ("randint", torch.randint(-sy, sy + 1, (b, 1, 1), generator=g))]
+        else:
+            ch, cw = int(h * 0.2 + 0.5), int(w * 0.2 + 0.5)
+            draws += [("randint", torch.randint(0, h + (1 - ch % 2), (b, 1, 1), generator=g)),
+                      ("randint", torch.randint(0, w + (1 - cw % 2), (b, 1, 1), generator=g))]
+    xr = x.clone().requires_grad_(True)
+    yr = orc.diff_augment(xr, iter(t for _, t in draws), policy)
+    gr, = torch.autograd.grad((yr * g0).sum(), xr)
+    xd = x.to(d).requires_grad_(True)
+    with ReplayDraws(draws):
+        y = dm.DiffAugment(xd, policy=policy)
+    gx, = torch.autograd.grad((y * g0.to(d)).sum(), xd)
+    assert max_rel(y, yr) < 1e-6 and max_rel(gx, gr) < 1e-6, (policy, max_rel(y, yr), max_rel(gx, gr))
+
+
 def test_diffaug_sums_at_256_match_oracle():
     """the per-image sums of cips_diffaug are reduced in 32 slices per image: brightness / contrast means at 256 x 256
     against the oracle's op-by-op restatement (CPU) with the same draws"""
@@ -356,3 +389,85 @@ def test_equal_linear_hip_forward_backward_double_backward(B, K, O, bias, act):
     assert max_rel(gw_pen, gw_penr) < 1e-5, max_rel(gw_pen, gw_penr)
     for a, b in zip(grads, gradsr):
         assert max_rel(a, b) < 1e-5, max_rel(a, b)
+
+
+def test_d_step_captured_in_a_hipgraph_replays_like_eager():
+    """A D step (forward, R1 double-backward, FusedClipAdamEMA) captured once and replayed three times gives the parameters
+    of three eager steps (the weight-plane cache was keyed on the parameter version, which a replay never bumps —
+    replays would have convolved with the planes of the captured step's weights —, and planes built during a capture were
+    stored in the global cache although they live in the graph's private pool).  After the replays an EAGER forward on the
+    replay-updated weights must also see the current weights."""
+    from cips3d_amd import discriminator as dmod
+    from cips3d_amd.discriminator import Discriminator_MultiScale_Aux
+    from cips3d_amd.optim import FusedClipAdamEMA
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, 3, 16, 16, generator=g).to(d) for _ in range(4)]
+
+    def make():
+        torch.manual_seed(11)
+        D = Discriminator_MultiScale_Aux(**D_CFG).to(d)
+        opt = FusedClipAdamEMA(list(D.parameters()), lr=2e-3, betas=(0.0, 0.999), max_norm=10.0, capture_slots=2)
+        return D, opt
+
+    def d_step(D, opt, x_static):
+        x = x_static.detach().requires_grad_(True)
+        out, _, _ = D(x, alpha=1.0, use_aux_disc=False)
+        gr, = torch.autograd.grad(outputs=out.sum(), inputs=x, create_graph=True)
+        loss = torch.nn.functional.softplus(-out).mean() + 5.0 * gr.flatten(1).pow(2).sum(1).mean()
+        loss.backward()
+        opt.step()
+
+    def grads_to_static_zero(D):
+        for p in D.parameters():
+            p.grad = torch.zeros_like(p)          # static gradient buffers: backward accumulates into them
+
+    # eager twin: warm-up step on xs[0], then three steps
+    De, oe = make()
+    for i in range(4):
+        grads_to_static_zero(De)
+        d_step(De, oe, xs[i])
+    torch.cuda.synchronize()
+    # captured: the same warm-up eagerly (on a side stream, as torch asks), then ONE capture, replayed on xs[1..3]
+    Dg, og = make()
+    x_static = xs[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        grads_to_static_zero(Dg)
+        d_step(Dg, og, x_static)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for p in Dg.parameters():
+        p.grad.zero_()
+    graph = torch.cuda.CUDAGraph()
+    n_cache_before = sum(len(v[1]) for v in dmod._WCACHE.values())
+    snap = [p.detach().clone() for p in Dg.parameters()]
+    with torch.cuda.graph(graph):
+        for p in Dg.parameters():
+            p.grad.zero_()
+        d_step(Dg, og, x_static)
+    # nothing built during the capture may have entered the global cache (the planes live in the graph's pool)
+    assert sum(len(v[1]) for v in dmod._WCACHE.values()) <= n_cache_before
+    for p, s_ in zip(Dg.parameters(), snap):
+        assert torch.equal(p.detach(), s_)        # capture does not execute
+    for i in (1, 2, 3):
+        x_static.copy_(xs[i])
+        graph.replay()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for (n, a), b in zip(De.named_parameters(), Dg.parameters()):
+        if a.grad is None or not float(a.grad.abs().max()):
+            continue
+        # Adam with beta1 = 0 moves an element by about +-lr per step whatever the gradient's size: tensors are tight,
+        # single elements only bounded (tests/test_gpu_train_step.py) — both runs execute the same kernels on the same
+        # inputs here, so they agree far below that
+        err = float((a - b).abs().max())
+        worst = max(worst, err)
+        assert err <= 1e-6 + 1e-5 * float(a.abs().max()), (n, err)
+    # an eager forward after the replays: its planes must come from the CURRENT weights (the version counter did not move)
+    dmod.invalidate_weight_cache(Dg)              # documented duty of a caller that replays an optimizer step
+    with torch.no_grad():
+        oe_, _, _ = De(xs[0], alpha=1.0, use_aux_disc=False)
+        og_, _, _ = Dg(xs[0], alpha=1.0, use_aux_disc=False)
+    assert max_rel(og_, oe_) < 1e-5, (max_rel(og_, oe_), worst)

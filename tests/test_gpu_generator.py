@@ -363,3 +363,34 @@ def test_generator_camera_distributions_run():
                     assert torch.allclose(py, torch.full_like(py, math.pi / 2))
         with pytest.raises(AssertionError):
             G(zs, **kw)
+
+
+def test_camera_distributions_values_on_gpu_match_reference_golden(monkeypatch):
+    """the non-gaussian camera modes were only checked for finiteness on the GPU.  Here every mode of
+    comm_utils.sample_camera_positions runs with device = cuda:0 — all arithmetic on the GPU — on the reference's own draws:
+    torch.rand / torch.randn are redirected to draw from the seeded CPU generator (as the reference did when the fixture was
+    minted) and move the draw to the device.  Origin, pitch, yaw against tests/golden/camera_cases.pt."""
+    import random
+    from cips3d_amd.generator import sample_camera_positions
+    d = torch.device("cuda:0")
+    rand0, randn0 = torch.rand, torch.randn
+
+    def on_cpu(fn):
+        def f(*a, **k):
+            dev = k.pop("device", None)
+            t = fn(*a, **k)
+            return t.to(dev) if dev is not None else t
+        return f
+
+    monkeypatch.setattr(torch, "rand", on_cpu(rand0))
+    monkeypatch.setattr(torch, "randn", on_cpu(randn0))
+    seen = set()
+    for c in load_golden("camera_cases"):
+        torch.manual_seed(c["seed"]); random.seed(c["seed"])
+        o, phi, theta = sample_camera_positions(d, bs=5, r=1.3, horizontal_stddev=0.3, vertical_stddev=0.155,
+                                                horizontal_mean=1.4, vertical_mean=1.7, mode=c["mode"])
+        assert o.is_cuda and phi.is_cuda and theta.is_cuda
+        e = max(max_rel(o, c["origin"]), max_rel(phi, c["phi"]), max_rel(theta, c["theta"]))
+        assert e < 2e-6, (c["mode"], e)
+        seen.add(c["mode"])
+    assert {"uniform", "hybrid", "truncated_gaussian", "spherical_uniform"} <= seen, seen

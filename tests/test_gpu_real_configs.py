@@ -75,13 +75,14 @@ def test_c2_full_batch_forward_vs_oracle(S, hier):
     print(f"C2 b=32 r64 S={S} hier={hier} (nerf_noise 0.3): worst image max_rel vs oracle {worst:.3e}")
 
 
-def _grad_compare(named_params, ref_grads, what, ref64=None):
+def _grad_compare(named_params, ref_grads, what, ref64=None, tol=None):
     """every parameter gradient against the fp32 oracle's at GRAD_TOL.  With `ref64` (the same evaluation in fp64) the bar of
     a parameter is max(GRAD_TOL, 4 x the fp32 oracle's own distance from the fp64 gradient), both measured against fp64: an
     ill-conditioned gradient is held to the reference's own accuracy, not to a tolerance its fp32 arithmetic does not meet."""
     worst = ("", 0.0, 0.0)
     loose = []
     n_used = 0
+    GRAD_TOL = tol if tol is not None else globals()["GRAD_TOL"]
     for name, p in named_params:
         r = ref_grads.get(name)
         if r is None:
@@ -216,12 +217,16 @@ def test_discriminator_real_sizes_vs_oracle(size, b, alpha):
     _grad_compare(list(Dd.named_parameters()), ref_grads, f"D {size}x{size} gradients (oracle's gates pinned)")
 
 
-def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, pin_fine=False):
+def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, pin_fine=False, pin_clamp=False, tol=None):
     """forward + every parameter gradient of `(imgs * G0).sum()` against the oracle, the oracle's LeakyReLU gates pinned.
     pin_fine: also the oracle's placement of the resampled (fine) samples — the searchsorted of the importance
     resampling is the path's second discontinuity: a cdf value within rounding of the uniform draw lands a sample in the
     neighbouring bin, and the sigma head's gradient (a sum with heavy cancellation) moves by a finite amount per such
-    sample.  The free-running placement is compared first and the differing samples are counted."""
+    sample.  The free-running placement is compared first and the differing samples are counted.
+    pin_clamp: also the branch the oracle's `relu(sigma + nerf_noise * eps)` took per sample (pigan_utils.py:246-252, the
+    third discontinuity; ops.clamp_debug / orc.clamp_tape): the free-running branches are compared first — every sample
+    whose branch differs must be ambiguous (|pre-activation| within the SIREN forward's rounding of 0) and they are counted
+    — then forward and backward run on the oracle's branches."""
     from cips3d_amd import ops
     d = torch.device("cuda:0")
     g = torch.Generator().manual_seed(seed)
@@ -230,11 +235,15 @@ def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, 
     G0 = torch.randn(nimg, 3, img, img, generator=g) / (nimg * 3 * img * img)
     Gc = seeded_generator(1234)
     tape = orc.GateTape()
-    with orc.gate_tape(tape):
+    ctape = orc.ClampTape()
+    with orc.gate_tape(tape), orc.clamp_tape(ctape if pin_clamp else None):
         ref = orc.generator_forward(dict(Gc.named_parameters()), zs, rand, img, KW["fov"], KW["ray_start"], KW["ray_end"],
                                     S, KW["h_stddev"], KW["v_stddev"], hier, nerf_noise=nerf_noise, return_aux_img=aux,
                                     keep=pin_fine)
     (ref["imgs"] * G0).sum().backward()
+    E = 2 * S if hier else S
+    ref_clamp = ctape.rec[0].reshape(b * img * img, E).to(torch.uint8) if pin_clamp else None
+    ref_pre = ctape.preact[0].reshape(b * img * img, E) if pin_clamp else None
     ref_grads = {k: p.grad for k, p in Gc.named_parameters() if p.grad is not None}
     ref_imgs = ref["imgs"].detach()
     ref_fz = ref["fine_z"].detach().reshape(b * img * img, S) if pin_fine else None
@@ -246,9 +255,10 @@ def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, 
         # with heavy cancellation) are ill-conditioned at this size — the fp32 oracle itself is 1e-3 off there.
         G64 = seeded_generator(1234).double()
         t64 = orc.GateTape(pin=tape.rec)
+        c64 = orc.ClampTape(pin=ctape.rec) if pin_clamp else None
         torch.set_default_dtype(torch.float64)
         try:
-            with orc.gate_tape(t64), orc.fine_z_pin(ref["fine_z"].detach().double()):
+            with orc.gate_tape(t64), orc.fine_z_pin(ref["fine_z"].detach().double()), orc.clamp_tape(c64):
                 r64 = orc.generator_forward(dict(G64.named_parameters()), {k: v.double() for k, v in zs.items()},
                                             {k: v.double() for k, v in rand.items()}, img, KW["fov"], KW["ray_start"], KW["ray_end"],
                                             S, KW["h_stddev"], KW["v_stddev"], hier, nerf_noise=nerf_noise, return_aux_img=aux)
@@ -257,7 +267,7 @@ def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, 
             torch.set_default_dtype(torch.float32)
         ref64 = {k: p.grad for k, p in G64.named_parameters() if p.grad is not None}
         del r64, t64
-    del ref, tape
+    del ref, tape, ctape
     Gd = seeded_generator(1234, device=d)
     if pin_fine:
         rec = []
@@ -268,15 +278,28 @@ def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, 
         print(f"{what}: free-running sample placement: {moved} of {dz.numel()} fine samples in another bin than the oracle's "
               f"({moved / dz.numel():.1e}); images max_rel {max_rel(free, ref_imgs):.3e}")
         assert moved <= 2e-3 * dz.numel() and max_rel(free, ref_imgs) < TOL
-    with ops.resample_debug(pin=[ref_fz] if pin_fine else None):
+    if pin_clamp:
+        # free-running branches on the oracle's sample placement: which samples sit on the other side of the clamp, and
+        # how close to 0 their pre-activation is (in units of the pre-activations' rms)
+        crec = []
+        with torch.no_grad(), ops.resample_debug(pin=[ref_fz] if pin_fine else None), ops.clamp_debug(rec=crec):
+            _product_forward(Gd, zs, rand, d, img, S, hier, aux=aux, nerf_noise=nerf_noise)
+        diff = crec[0].cpu() != ref_clamp
+        nflip = int(diff.sum())
+        rms = float(ref_pre.double().pow(2).mean().sqrt())
+        amb = float(ref_pre[diff].abs().max()) / rms if nflip else 0.0
+        print(f"{what}: free-running relu clamp: {nflip} of {diff.numel()} samples on the other branch than the oracle's "
+              f"({nflip / diff.numel():.1e}); largest |sigma + noise| among them {amb:.2e} x rms")
+        assert nflip <= 2e-4 * diff.numel() and amb < 2e-4, (nflip, amb)
+    with ops.resample_debug(pin=[ref_fz] if pin_fine else None), ops.clamp_debug(pin=[ref_clamp] if pin_clamp else None):
         imgs = _product_forward(Gd, zs, rand, d, img, S, hier, aux=aux, pin=pins, nerf_noise=nerf_noise)
     e = max_rel(imgs, ref_imgs)
     print(f"{what}: imgs max_rel {e:.3e}")
     assert imgs.shape == (nimg, 3, img, img) and e < TOL
     (imgs * G0.to(d)).sum().backward()
     torch.cuda.synchronize()
-    _grad_compare(list(Gd.named_parameters()), ref_grads, f"{what} gradients (oracle's gates" + (" and fine-sample placement" if pin_fine else "") + " pinned)",
-                  ref64=ref64)
+    _grad_compare(list(Gd.named_parameters()), ref_grads, f"{what} gradients (oracle's gates" + (" and fine-sample placement" if pin_fine else "")
+                  + (" and relu-clamp branches" if pin_clamp else "") + " pinned)", ref64=ref64, tol=tol)
     return len(ref_grads)
 
 
@@ -288,18 +311,25 @@ def test_c2_headline_geometry_flat_march_forward_backward_vs_oracle():
     assert n == 130, n
 
 
+def test_c2_flat_march_full_nerf_noise_clamp_pinned_forward_backward_vs_oracle():
+    """The step-0 value of the noise schedule (train.py:325-327: nerf_noise = max(0, 1 - step / 5000)): r64, S = 24 flat (the
+    fused ray-march), nerf_noise 1.0, default split-bf16 mode, an image pair.  With the oracle's relu-clamp branches pinned
+     EVERY gradient — including siren.final_layer.*, the sigma head — is inside 2e-4."""
+    n = _g_forward_backward_vs_oracle("r64 S=24 flat b=2, nerf_noise 1.0", 2, 64, 24, False, False, 1.0, 6411, pin_clamp=True,
+                                      tol=2e-4)
+    assert n >= 100, n
+
+
 def test_c3_r128_pair_forward_backward_vs_oracle():
     """C3 geometry with gradients: r128, S = 12 + 12, aux image, an image pair (the weight-gradient GEMMs contract over
-    16 384 pixels per image), nerf_noise 0 (train.py:325-327: its value after the first 5 000 steps).  The oracle's
-    LeakyReLU gates and its placement of the fine samples are pinned; bars against the fp64 evaluation (see _grad_compare).
-
-    Why not nerf_noise > 0 here: `relu(sigma + noise)` (pigan_utils.py fancy_integration) is a third discontinuity, and the
-    product's split-bf16 SIREN forward carries sigma to ~1e-5 where the oracle's fp32 carries 1e-7 — at this size a handful
-    of the 786 432 samples land on the other side of the clamp, and the sigma head's two gradients (sums of d sigma with
-    heavy cancellation) move by 2e-4 ... 6e-3 (scripts/probe/hier_grad_probe.py: 4.4e-3 / 6.6e-3 hierarchical / flat with
-    the x3 forward, 3e-4 / 6e-5 with CIPS_SIREN_FWD=f32, 2e-5 without noise in every mode; images 1e-5 throughout).  The C2
-    test above keeps nerf_noise 0.2 at its (smaller) size."""
-    _g_forward_backward_vs_oracle("C3 geometry b=2 r128 S=12+12, aux", 2, 128, 12, True, True, 0.0, 1283, pin_fine=True)
+    16 384 pixels per image), nerf_noise 0.1 (round 4; it ran at 0 before).  All three discontinuities of the path are pinned
+    to the oracle's choices — LeakyReLU gates, placement of the fine samples, and the branch of `relu(sigma + noise)`
+    (pigan_utils.py fancy_integration: the product's split-bf16 SIREN forward carries sigma to ~1e-5 where the oracle's fp32
+    carries 1e-7, so at 786 432 samples a handful land on the other side of the clamp and the sigma head's two gradients —
+    sums of d sigma with heavy cancellation — moved by 4.4e-3 free-running).  Bars against the fp64 evaluation of
+    the same network with the same three pins: max(2e-4, 4 x the fp32 oracle's own distance from fp64), see _grad_compare."""
+    _g_forward_backward_vs_oracle("C3 geometry b=2 r128 S=12+12, aux, nerf_noise 0.1", 2, 128, 12, True, True, 0.1, 1283,
+                                  pin_fine=True, pin_clamp=True, tol=2e-4)
 
 
 def _aug_draws(g, nb, size):
