@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
     ap.add_argument("--no-full-step", action="store_true",
                     help="skip the secondary measurement: one full GAN step (D step with R1 + G step + fused clip/Adam/EMA)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short extra timings of BASELINE's other geometries (C4 at 256x256, C3's per-GPU share, C2 eager)")
     ap.add_argument("--inr-mode", default=None, choices=["bf16x3", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph of the step")
     ap.add_argument("--overlap-reduce", action="store_true",
@@ -215,7 +217,16 @@ def full_gan_step(dev, b, img, S, steps=4, warmup=2, freeze=False, diffaug=False
     else:
         oG = FusedClipAdamEMA(G.parameters(), lr=2e-4, betas=(0.0, 0.999), max_norm=10.0, ema_params=G_ema.parameters())
         oD = FusedClipAdamEMA(D.parameters(), lr=2e-3, betas=(0.0, 0.999), max_norm=10.0)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.manual_seed(1234 + torch.distributed.get_rank())     # per-rank reals, latents and cameras (train.py:221)
     real = torch.rand(b, 3, img, img, device=dev) * 2 - 1
+    # N > 1 (scripts/bench_full_step.py --gpus N): the step exchanges BOTH gradient sets, like the reference's two DDP
+    # wrappers (train.py:235-236) — D's after the D backward (~150 MB, three buckets), G's after the G backward (45 MB)
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    red_bytes = {"D": 0, "G": 0}
+    if dist_on:
+        from cips3d_amd.distributed import GradAllReducer
+        red_D, red_G = GradAllReducer(list(D.parameters())), GradAllReducer(list(G.parameters()))
 
     def d_step():
         for p in G.parameters(): p.requires_grad_(False)
@@ -230,6 +241,8 @@ def full_gan_step(dev, b, img, S, steps=4, warmup=2, freeze=False, diffaug=False
         loss = (F.softplus(g_preds) + F.softplus(-r_preds) + pen).mean()
         for p in D.parameters(): p.grad = None
         loss.backward()
+        if dist_on:
+            red_bytes["D"] = red_D()
         if torch_optim:
             torch.nn.utils.clip_grad_norm_(D.parameters(), 10.0)
         oD.step()
@@ -242,6 +255,8 @@ def full_gan_step(dev, b, img, S, steps=4, warmup=2, freeze=False, diffaug=False
         loss = F.softplus(-preds).mean()
         for p in G.parameters(): p.grad = None
         loss.backward()
+        if dist_on:
+            red_bytes["G"] = red_G()
         if torch_optim:
             torch.nn.utils.clip_grad_norm_(G.parameters(), 10.0); oG.step()
             with torch.no_grad():
@@ -259,11 +274,93 @@ def full_gan_step(dev, b, img, S, steps=4, warmup=2, freeze=False, diffaug=False
         e0.record(); d_step(); e1.record(); g_step(); e2.record()
         torch.cuda.synchronize()
         tD += e0.elapsed_time(e1); tG += e1.elapsed_time(e2)
-    return {"metric": "full GAN step (D step with R1 + G step + clip/Adam/EMA), synthetic reals, eager launches",
+    extra = {}
+    if dist_on:
+        # the same initial weights and the same averaged gradients on every rank: the parameters must still be identical
+        world = torch.distributed.get_world_size()
+        sums = torch.stack([torch.stack([p.detach().double().sum() for p in net.parameters()]).sum() for net in (G, D, G_ema)])
+        allsums = [torch.zeros_like(sums) for _ in range(world)]
+        torch.distributed.all_gather(allsums, sums)
+        extra = {"ranks": world, "allreduce_bytes_D": int(red_bytes["D"]), "allreduce_bytes_G": int(red_bytes["G"]),
+                 "replicas_identical": bool(all(torch.equal(allsums[0], t) for t in allsums[1:]))}
+        b = b * world
+    return {**extra,
+            "metric": "full GAN step (D step with R1 + G step + clip/Adam/EMA), synthetic reals, eager launches",
             "img_size": img, "batch": b, "num_steps": S, "hierarchical": True, "aux": aux, "freeze_nerf": freeze,
             "diffaug": diffaug, "optimizer": "torch" if torch_optim else "fused clip+Adam+EMA", "steps": steps,
             "ms_D_step": round(tD / steps, 2), "ms_G_step": round(tG / steps, 2), "ms_step": round((tD + tG) / steps, 2),
             "img_per_s": round(b * steps / ((tD + tG) * 1e-3), 1)}
+
+
+def g_step_rate(dev, img, b, S, hier, freeze, steps, warmup, graph=True):
+    """images / s of the G forward + backward at another geometry of BASELINE.json (same step definition as the headline:
+    fresh latents, every gradient the reference populates for that generator class; hipGraph replay unless graph=False)."""
+    from cips3d_amd.generator import GeneratorNerfINR, GeneratorNerfINR_freeze_NeRF
+    torch.manual_seed(1234)
+    G = (GeneratorNerfINR_freeze_NeRF if freeze else GeneratorNerfINR)(**G_CFG, device=dev).to(dev)
+    G.device = dev
+    G0 = torch.randn(b, 3, img, img, device=dev) / (b * 3 * img * img)
+    params = list(G.parameters())
+
+    def fwd_bwd():
+        zs = G.get_zs(b)
+        for p in params:
+            p.grad = None
+        imgs, _ = G(zs, img_size=img, num_steps=S, hierarchical_sample=hier, nerf_noise=0., return_aux_img=False,
+                    grad_points=None, forward_points=None, **G_KW)
+        imgs.backward(G0)
+
+    g = None
+    if graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    fwd_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fwd_bwd()
+        except Exception as e:                      # noqa: BLE001
+            print(f"[bench] other-config capture failed ({type(e).__name__}: {e}); eager", file=sys.stderr)
+            g = None
+            torch.cuda.synchronize()
+    run = g.replay if g is not None else fwd_bwd
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    E = 2 * S if hier else S
+    return {"workload": f"r{img}, {E} SIREN evals/ray (num_steps {S}, hierarchical {hier}), batch {b}, G fwd+bwd"
+                        + (", NeRF frozen" if freeze else ""),
+            "value": round(b * steps / dt, 2), "unit": "img/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "warmup": warmup, "launch": "hipGraph replay" if g is not None else "eager"}
+
+
+def other_configs(dev, mode):
+    """BASELINE.json's other geometries in the driver-timed line (north_star: img/s "at 64^2 and 256^2"): short runs, N = 1,
+    rank 0, default numeric mode.  Each entry is guarded: a failure is reported in place and never costs the headline."""
+    legs = [("c2_eager", "C2 with eager launches (what exp/cips3d/scripts/train.py does)", dict(img=64, b=32, S=24, hier=False, freeze=False, steps=10, warmup=3, graph=False)),
+            ("c2_hier", "C2 as S = 12 + 12 resampled (ffhq_exp.yaml:169-189)", dict(img=64, b=32, S=12, hier=True, freeze=False, steps=10, warmup=3)),
+            ("c3_r128_share", "C3's per-GPU share: r128, batch 64 / 8 GPUs (ffhq_exp.yaml:190-199)", dict(img=128, b=8, S=12, hier=True, freeze=False, steps=10, warmup=3)),
+            ("c4_r256", "C4's G step: r256, E = 48, batch 4 per GPU, NeRF frozen (ffhq_exp.yaml:192-210)", dict(img=256, b=4, S=24, hier=True, freeze=True, steps=10, warmup=3)),
+            ("c4_r256_full_backward", "r256, E = 48, batch 4, gradients for the NeRF as well", dict(img=256, b=4, S=24, hier=True, freeze=False, steps=6, warmup=2))]
+    out = {}
+    for key, what, kw in legs:
+        try:
+            r = g_step_rate(dev, **kw)
+            r["what"] = what
+            out[key] = r
+        except Exception as e:                      # noqa: BLE001
+            out[key] = {"what": what, "error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    return out
 
 
 def _free_port():
@@ -461,11 +558,19 @@ def main():
             line["full_step"] = full_gan_step(dev, b, img, 12, steps=4, warmup=2)
         except Exception as e:                      # noqa: BLE001 — the secondary number must never cost the headline line
             line["full_step"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and world == 1 and not a.no_other_configs and mode == "bf16x3":
+        line["other_configs"] = other_configs(dev, mode)
     if rank == 0:
         if not a.no_roofline:
             line["roofline"] = gemm_roofline(dev, b, img * img, mode)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(img, S, a.hier)
+            try:
+                # the UNMODIFIED reference's CPU path: it exists only in the build container (/root/reference does not travel),
+                # so its timing is a tracked record written there by scripts/time_reference_cpu.py — never measured here
+                line["cpu_baseline"]["reference"] = json.load(open(os.path.join(ROOT, "profiles", "reference_cpu.json")))
+            except Exception:                       # noqa: BLE001
+                pass
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

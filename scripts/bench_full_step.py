@@ -17,10 +17,38 @@ def main():
     ap.add_argument("--diffaug", action="store_true", help="DiffAugment in D (r256 stages)")
     ap.add_argument("--no-aux", action="store_true", help="train_aux_img False (C4)")
     ap.add_argument("--torch-optim", action="store_true", help="torch clip_grad_norm_ + Adam + python EMA instead of the fused tail")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1: one rank per GPU over RCCL (CIPS_BENCH_BACKEND=gloo: functional "
+                    "check with the ranks sharing the visible devices), both gradient sets all-reduced every step")
     a = ap.parse_args()
-    from bench import full_gan_step
-    print(json.dumps(full_gan_step(torch.device("cuda:0"), a.batch, a.img_size, a.num_steps, steps=a.steps, warmup=a.warmup,
-                                   freeze=a.freeze, diffaug=a.diffaug, aux=not a.no_aux, torch_optim=a.torch_optim)))
+    import bench
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(bench._free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    backend = os.environ.get("CIPS_BENCH_BACKEND", "nccl")
+    if world > 1:
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            raise SystemExit(f"--gpus {world} needs {world} GPUs (CIPS_BENCH_BACKEND=gloo: functional check on fewer)")
+        local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world,
+                                             **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    res = bench.full_gan_step(dev, a.batch, a.img_size, a.num_steps, steps=a.steps, warmup=a.warmup,
+                              freeze=a.freeze, diffaug=a.diffaug, aux=not a.no_aux, torch_optim=a.torch_optim)
+    if world > 1:
+        res["backend"] = backend if backend == "nccl" else f"{backend} (functional check, not a measurement)"
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

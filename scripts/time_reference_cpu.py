@@ -44,8 +44,21 @@ def orc_once():
     out["imgs"].backward(torch.ones_like(out["imgs"]) / out["imgs"].numel())
     return time.time() - t0
 
+res = {}
 for name, f in (("reference (unmodified, shimmed imports)", ref_once), ("oracle (port)", orc_once)):
     f()
     ts = sorted(f() for _ in range(3))
+    res["reference" if f is ref_once else "oracle"] = {"value": round(b / ts[1], 4), "min": round(b / ts[2], 4), "max": round(b / ts[0], 4)}
     print(f"{name}: G fwd+bwd r{img} S={S} b={b} on {torch.get_num_threads()} threads: median {ts[1]:.2f} s = {b / ts[1]:.3f} img/s "
           f"(min {ts[0]:.2f} s, max {ts[2]:.2f} s)")
+
+# tracked record bench.py copies into cpu_baseline.reference (the GPU box has no /root/reference: this is the only place the
+# reference's own CPU path can be timed; the cores are the build container's, stated in the record)
+import json
+rec = {"unit": "img/s", "cores": torch.get_num_threads(), "where": "build container (not the GPU box's host)",
+       "sample": f"unmodified reference G fwd+bwd (exp/cips3d/models/generator.py via oracle/ref_shim.py), r{img}, S={S} flat, b={b}, "
+                 f"median of 3 timed iterations after one warm-up",
+       "value": res["reference"]["value"], "min": res["reference"]["min"], "max": res["reference"]["max"],
+       "oracle_same_cores": res["oracle"], "script": "scripts/time_reference_cpu.py"}
+json.dump(rec, open(os.path.join(ROOT, "profiles", "reference_cpu.json"), "w"), indent=1)
+print(json.dumps(rec))

@@ -364,3 +364,87 @@ def test_pattern_change_on_one_rank_only_replans_collectively_world2_gloo():
                         assert got is not None and torch.allclose(torch.from_numpy(got), want, atol=1e-7), (mode, r, step, i)
                 a, b = res[0][mode][step][i], res[1][mode][step][i]
                 assert (a is None) == (b is None) and (a is None or (a == b).all()), (mode, step, i)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the real parameter lists: D's ~150 MB bucket set and G's 45 MB bucket (train.py:235-236 wraps BOTH networks)
+# ------------------------------------------------------------------------------------------------------------------
+def _gd_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import D_CFG, seeded_generator, load_golden
+    from cips3d_amd.discriminator import Discriminator_MultiScale_Aux
+    from cips3d_amd.distributed import GradAllReducer
+    torch.manual_seed(3)
+    D = Discriminator_MultiScale_Aux(**D_CFG)
+    G = seeded_generator(1234)
+    g_has = {k: v is not None for k, v in load_golden("g_r16_hier")["grads"].items()}      # the reference's own pattern
+
+    def d_has(name):                     # the D step at 64x64 (alpha = 1): conv_in.64, convs.64 .. convs.8, the tail
+        parts = name.split(".")
+        if parts[1] == "conv_in":
+            return parts[2] == "64"
+        if parts[1] == "convs":
+            return int(parts[2]) <= 64
+        return True
+
+    red_d = GradAllReducer(list(D.parameters()))          # 64 MB buckets: D takes three, G one
+    red_g = GradAllReducer(list(G.parameters()))
+    out = []
+    for step in range(2):
+        rec = {}
+        for tag, net, red, has in (("D", D, red_d, d_has), ("G", G, red_g, lambda n: g_has[n])):
+            for n, p in net.named_parameters():
+                p.grad = torch.full_like(p, float(rank + 1 + step)) if has(n) else None
+            nbytes = red()
+            red._check_pending(block=True)
+            ok = all((p.grad is None) == (not has(n)) and (p.grad is None or bool((p.grad == 1.5 + step).all()))
+                     for n, p in net.named_parameters())
+            rec[tag] = (nbytes, len(red._buckets), ok, sum(p.numel() * 4 for n, p in net.named_parameters() if has(n)))
+        out.append(rec)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_generator_and_discriminator_buckets_of_the_real_networks_world2_gloo():
+    """Both exchanges of a GAN step with the REAL parameter lists: the discriminator's gradients (the
+    64x64 stage: ~147 MB in three 64 MB-limited buckets) and the generator's (45 MB, one bucket; the reference's own presence
+    pattern from the golden fixture: 130 of 172 parameters), two steps each, alternating like train.py:334-466 — every
+    reduced gradient is the two-rank mean, unused parameters stay None, and the byte counts are the networks'."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    res = None
+    for _attempt in range(3):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_gd_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = {}
+        try:
+            for _ in range(world):
+                r, out = q.get(timeout=300)
+                res[r] = out
+            for p in procs:
+                p.join(timeout=60)
+        except Exception:
+            res = None
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+        if res is not None and len(res) == world and all(p.exitcode == 0 for p in procs):
+            break
+        res = None
+    assert res is not None
+    for r in range(world):
+        for step in range(2):
+            nb_d, k_d, ok_d, want_d = res[r][step]["D"]
+            nb_g, k_g, ok_g, want_g = res[r][step]["G"]
+            assert ok_d and ok_g, (r, step)
+            assert nb_d == want_d and 120e6 < nb_d < 151e6 and k_d >= 2, (nb_d, k_d)
+            assert nb_g == want_g and 40e6 < nb_g < 50e6 and k_g == 1, (nb_g, k_g)

@@ -312,3 +312,25 @@ def test_bench_two_ranks_gloo_functional_run_reports_the_exchange():
     for k in ("ms_median", "ms_min", "ms_max", "bus_GBps", "frac_of_step", "step_ms_median_events"):
         assert isinstance(ar[k], (int, float)), k
     assert isinstance(line["ms_per_step_median"], (int, float)) and isinstance(line["value"], (int, float))
+
+
+def test_full_gan_step_two_ranks_gloo_reduces_both_gradient_sets():
+    """scripts/bench_full_step.py --gpus 2 (functional, gloo, both ranks on the box's one GPU): the full GAN step of
+    train.py:334-491 with BOTH exchanges — the discriminator's gradients after the D backward and the generator's after the G
+    backward (train.py:235-236 wraps both networks) — through GradAllReducer and the fused optimizer tail.  Byte
+    counts are the networks' at this stage, and after the steps the replicas (G, D, G_ema) are still identical on both
+    ranks: same initial weights + the same averaged gradients."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CIPS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "bench_full_step.py"), "--gpus", "2", "--img-size", "16",
+                          "--batch", "2", "--num-steps", "4", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ranks"] == 2 and line["replicas_identical"] is True
+    assert 40e6 < line["allreduce_bytes_G"] < 50e6           # 130 of 172 generator parameters
+    assert 10e6 < line["allreduce_bytes_D"] < 151e6          # the 16x16 stage of both discriminators
+    assert "functional check" in line["backend"]
