@@ -12,6 +12,11 @@ OUT = os.path.join(HERE, "lib", "libcips3d_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "gemm_bf16x3_wide.hip", "gemm_bf16x3_v3.hip", "gemm_bf16x3_km_wide.hip", "siren.hip", "siren_bwd_x3.hip", "render.hip", "modfc.hip", "disc_ops.hip", "optim.hip", "small_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+# per-source extras.  siren_bwd_x3.hip: the m-major layers of siren_bwd_x4.inc unroll 32 items x (3 MFMAs + 3 epilogue slots);
+# before unrolling every slot call carries all of its six variants, which puts the loop over clang's 16 384-instruction limit for
+# `#pragma unroll` — it then stays a loop, the accumulator / activation arrays are indexed dynamically and live in scratch
+# (1 728 bytes per lane, measured).  The limit is raised for this file only (the other sources' code generation is unchanged).
+EXTRA_FLAGS = {"siren_bwd_x3.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _stale(target, deps):
@@ -25,7 +30,7 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
     objdir = os.path.join(HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "siren_fwd_chain.inc"), os.path.join(CSRC, "raygen.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "siren_fwd_chain.inc"), os.path.join(CSRC, "siren_bwd_x4.inc"), os.path.join(CSRC, "raygen.h"),
                os.path.join(HERE, "..", "include", "cips3d_hip.h")]
     objs = []
     procs = []
@@ -34,7 +39,7 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

@@ -176,6 +176,44 @@ __device__ __forceinline__ void run_layer(LoadF load, const Act<(KS + 1) / 2>& i
   }
 }
 
+// m-major dense layer with woven side work (round 4).  scripts/probe/issue_overlap_probe.hip: with ONE wave per SIMD,
+// "MFMA, 4-6 VALU, MFMA, ..." costs max(matrix pipe, VALU issue) — 16 x (MFMA, 4 v_fma) = 528 cycles against 532 for the
+// MFMAs alone and 340 for the VALU alone — while "16 MFMA, then 64 v_fma" costs the sum (824): a wave's own VALU does hide
+// under its own MFMAs, but only when it sits BETWEEN them in program order (an MFMA waits at issue for the pipe, and
+// everything behind it waits too).  So: output tile m runs all its k-steps back to back, and after EVERY MFMA one slot
+// of `side(slot)` is emitted (slot = 3 * item + pass; the callers put tile m-1's epilogue — FiLM, sine / cosine, hi / lo
+// split — into the slots of tile m).  sched_barrier(0) pins the order.
+template <int NM, int KS, typename LoadF, typename SideF>
+__device__ __forceinline__ void run_layer_mm(LoadF load, const Act<(KS + 1) / 2>& in, f32x16 (&acc)[NM], SideF side) {
+  constexpr int NI = NM * KS, D = 2;
+  Frag ring[D + 1];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+    if (i < NI) load(i % KS, i / KS, ring[i]);
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    if (it + D < NI) load((it + D) % KS, (it + D) / KS, ring[(it + D) % (D + 1)]);
+    const int m = it / KS, s = it % KS, q = s >> 1, t = s & 1;
+    const bf16x8 bh = mk8(in.hi[q][4 * t], in.hi[q][4 * t + 1], in.hi[q][4 * t + 2], in.hi[q][4 * t + 3]);
+    const bf16x8 bl = mk8(in.lo[q][4 * t], in.lo[q][4 * t + 1], in.lo[q][4 * t + 2], in.lo[q][4 * t + 3]);
+    const Frag& f = ring[it % (D + 1)];
+    const bf16x8 ah = mk8(f.h[0], f.h[1], f.h[2], f.h[3]), al = mk8(f.l[0], f.l[1], f.l[2], f.l[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    side(3 * it);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    side(3 * it + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    side(3 * it + 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // The DS offset field is 16 bits and the carve is 160 KiB: a region base (lane base + image offset) is made
 // opaque with this so that hipcc keeps it in one register and folds only the in-region constant.
 __device__ __forceinline__ unsigned opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
@@ -225,6 +263,19 @@ __device__ __forceinline__ void layer_fwd(const LaneAddr& A, const Act<Q>& in, f
   run_layer<NM, 2 * Q>(load, in, acc);
 }
 
+template <int NM, int Q, int R, int IMG, int PLANE, typename SideF>
+__device__ __forceinline__ void layer_fwd_mm(const LaneAddr& A, const Act<Q>& in, f32x16 (&acc)[NM], SideF side) {
+  const unsigned b[2][2] = {{opaque(A.fb[0][0] + IMG), opaque(A.fb[0][1] + IMG)}, {opaque(A.fb[1][0] + IMG), opaque(A.fb[1][1] + IMG)}};
+  auto load = [&](int s, int m, Frag& f) {
+    const int c = (s >> 1) * R * 64 + m * 2048;
+    put(f.h, 0, lds_b64(b[s & 1][0] + c));
+    put(f.h, 2, lds_b64(b[s & 1][1] + c));
+    put(f.l, 0, lds_b64(b[s & 1][0] + c + PLANE));
+    put(f.l, 2, lds_b64(b[s & 1][1] + c + PLANE));
+  };
+  run_layer_mm<NM, 2 * Q>(load, in, acc, side);
+}
+
 // Transposed dense layer: acc[m] += W[k][32m + i] * in[k][pt]  (dh = W^T d), same image, transpose reads.
 // KS = k-steps (16 rows each).  The B operand's k order is the register chain's: k-step ks, element e of half
 // hf <-> row 16ks + 4hf + (e&3) + 8(e>>2).
@@ -239,6 +290,19 @@ __device__ __forceinline__ void layer_tr(const LaneAddr& A, const Act<(KS + 1) /
     put(f.l, 2, lds_tr(b[ks & 1][1] + c + 512 + PLANE));
   };
   run_layer<NM, KS>(load, in, acc);
+}
+
+template <int NM, int KS, int R, int IMG, int PLANE, typename SideF>
+__device__ __forceinline__ void layer_tr_mm(const LaneAddr& A, const Act<(KS + 1) / 2>& in, f32x16 (&acc)[NM], SideF side) {
+  const unsigned b[2][2] = {{opaque(A.tb[0][0] + IMG), opaque(A.tb[0][1] + IMG)}, {opaque(A.tb[1][0] + IMG), opaque(A.tb[1][1] + IMG)}};
+  auto load = [&](int ks, int m, Frag& f) {
+    const int c = m * R * 64 + ks * 1024;
+    put(f.h, 0, lds_tr(b[ks & 1][0] + c));
+    put(f.h, 2, lds_tr(b[ks & 1][1] + c + 512));
+    put(f.l, 0, lds_tr(b[ks & 1][0] + c + PLANE));
+    put(f.l, 2, lds_tr(b[ks & 1][1] + c + 512 + PLANE));
+  };
+  run_layer_mm<NM, KS>(load, in, acc, side);
 }
 
 // write a wave's packed activations (lane = point `row` of an R-row staging image, units of 4 features);
@@ -319,11 +383,18 @@ struct BwdX3Args {
 constexpr int GP_G1 = 0, GP_GC = H * H, GP_GF0 = GP_GC + HC * H, GP_GF1 = GP_GF0 + CF * HC, GPART = GP_GF1 + CF * HC;
 constexpr int SRED = 4 * 32 * 8 + 8;   // per wave a 32x8 tile of column sums, then 4 per-wave sums of dsigma (+ pad)
 
+// PRE: everything that only ever feeds a sine argument is stored divided by 2 pi — W1, Wc, the layer-0 packs and the FiLM
+// offsets c1 / cc — so that gain * (W h) + c comes out in REVOLUTIONS and the sine is v_fract + v_sin with no multiply
+// (the FiLM gains g1 / gc and ws stay as they are: the backward multiplies by them).  A backward that runs on these images
+// carries the factor through its linear chain and removes it where it writes its partial sums (siren_bwd_x4.inc).
+template <bool PRE = false>
 __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_weights& w, int b) {
   const int tid = threadIdx.x, nt = blockDim.x;
+  const float pre = PRE ? CIPS_INV_2PI : 1.f;
   for (int i = tid; i < H * 32; i += nt) {                  // W1: 128 rows x 32 units
     const int row = i >> 5, u = i & 31;
-    const float4 v = *reinterpret_cast<const float4*>(w.w1 + row * H + 4 * u);
+    float4 v = *reinterpret_cast<const float4*>(w.w1 + row * H + 4 * u);
+    if (PRE) { v.x *= pre; v.y *= pre; v.z *= pre; v.w *= pre; }
     uint2 ph, pl;
     split2(v.x, v.y, ph.x, pl.x); split2(v.z, v.w, ph.y, pl.y);
     const int o = img_addr<2>(row, u, H);
@@ -332,7 +403,8 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
   }
   for (int i = tid; i < HC * 32; i += nt) {                 // Wc: 64 rows x 32 units
     const int row = i >> 5, u = i & 31;
-    const float4 v = *reinterpret_cast<const float4*>(w.wc + row * H + 4 * u);
+    float4 v = *reinterpret_cast<const float4*>(w.wc + row * H + 4 * u);
+    if (PRE) { v.x *= pre; v.y *= pre; v.z *= pre; v.w *= pre; }
     uint2 ph, pl;
     split2(v.x, v.y, ph.x, pl.x); split2(v.z, v.w, ph.y, pl.y);
     const int o = img_addr<2>(row, u, HC);
@@ -357,13 +429,14 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
     float4 pk;
     pk.x = gs * w.w0[f * 3 + 0]; pk.y = gs * w.w0[f * 3 + 1]; pk.z = gs * w.w0[f * 3 + 2];
     pk.w = fmaf(g0, w.b0[f], w.p0[b * H + f]);
+    if (PRE) { pk.x *= pre; pk.y *= pre; pk.z *= pre; pk.w *= pre; }
     reinterpret_cast<float4*>(L0)[f] = pk;
     const float g1 = w.g1[b * H + f];
-    G1[f] = g1; C1[f] = fmaf(g1, w.b1[f], w.p1[b * H + f]); WS[f] = w.ws[f];
+    G1[f] = g1; C1[f] = fmaf(g1, w.b1[f], w.p1[b * H + f]) * pre; WS[f] = w.ws[f];
   }
   for (int f = tid; f < HC; f += nt) {
     const float gc = w.gc[b * HC + f];
-    GC[f] = gc; CC[f] = fmaf(gc, w.bc[f], w.pc[b * HC + f]);
+    GC[f] = gc; CC[f] = fmaf(gc, w.bc[f], w.pc[b * HC + f]) * pre;
   }
 }
 
@@ -787,6 +860,8 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_x3_kernel(BwdX3Args a) {
   }
 }
 
+#include "siren_bwd_x4.inc"
+
 
 // ------------------------------------------------------------------------------------------------------------------
 // Forward on the same split-bf16 register chain (default; CIPS_SIREN_FWD=f32 selects siren.hip's exact fp32 MFMA
@@ -1165,6 +1240,24 @@ static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points,
     hipFuncSetAttribute((const void*)siren_bwd_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     hipFuncSetAttribute((const void*)siren_bwd_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     attr_set = true;
+  }
+  // CIPS_SIREN_BWD_V4 (read per call: A/B runs flip it inside one process): the round-4 schedule (m-major layers with the
+  // epilogues woven between the MFMAs, sine arguments in revolutions); 0 = the round-1..3 kernel
+  const char* v4e = getenv("CIPS_SIREN_BWD_V4");
+  const bool v4 = !(v4e && v4e[0] == '0');
+  if (v4) {
+    static bool attr4 = false;
+    CIPS_PER_DEVICE(attr4, false);
+    if (!attr4) {
+      hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+      hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+      attr4 = true;
+    }
+    if (w->trig_mode == 1)
+      hipLaunchKernelGGL(siren_bwd_x4_kernel<true>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(siren_bwd_x4_kernel<false>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+    return CIPS_CHECK_LAUNCH();
   }
   if (w->trig_mode == 1)
     hipLaunchKernelGGL(siren_bwd_x3_kernel<true>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
