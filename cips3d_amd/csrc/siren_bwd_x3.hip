@@ -881,7 +881,7 @@ template <bool HW>
 __global__ __launch_bounds__(512) void siren_fwd_x3_kernel(FwdX3Args a) {
   extern __shared__ __attribute__((aligned(1024))) uchar smem[];
   const int b = blockIdx.y;
-  stage_weights_x3(smem, a.w, b);
+  stage_weights_x3<HW>(smem, a.w, b);
   if (threadIdx.x < CF) reinterpret_cast<float*>(smem + O_AUX)[threadIdx.x] = a.w.bf[threadIdx.x];   // bf[32] (aux image unused here)
   __syncthreads();
   const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -954,7 +954,7 @@ template <bool HW, bool DBG>
 __global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
   extern __shared__ __attribute__((aligned(1024))) uchar smem[];
   const int b = blockIdx.y;
-  stage_weights_x3(smem, a.w, b);
+  stage_weights_x3<HW>(smem, a.w, b);
   if (threadIdx.x < CF) reinterpret_cast<float*>(smem + O_AUX)[threadIdx.x] = a.w.bf[threadIdx.x];
   __syncthreads();
   const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
