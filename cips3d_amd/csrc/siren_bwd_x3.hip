@@ -36,6 +36,7 @@
 #include "../../include/cips3d_hip.h"
 #include "raygen.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace cips_dbg {          // debug hook of the relu clamp (cips_debug_clamp, render.hip)
 extern const unsigned char* clamp_pin;
