@@ -145,6 +145,8 @@ def gemm_roofline(dev, b, n, mode):
                 r["traffic"] = pm["hbm_bytes"]
                 r["traffic_algorithmic_bytes"] = pm["algorithmic_bytes"]
                 r["traffic_kernel"] = pm["kernel"]
+                r["traffic_source"] = (f"profiles/{f}: rocprofv3 --kernel-trace --pmc passes of scripts/pmc_roofline.sh on the same kernel and "
+                                       "shape (counters cannot be collected inside this run); a tracked record, not a measurement of this run")
                 break
         except Exception:
             pass
