@@ -191,3 +191,41 @@ def test_oracle_matches_pigan_lib_second_lineage():
         assert torch.equal(r["points"], c["points"]) and torch.equal(r["z"], c["z"])
         assert torch.equal(r["dirs"], c["dirs"]) and torch.equal(r["origins"], c["origins"])
         assert torch.equal(r["pitch"], c["pitch"]) and torch.equal(r["yaw"], c["yaw"])
+
+
+@pytest.mark.parametrize("tag", ["g_r8_flat_noise", "g_r8_hier_noise"])
+def test_oracle_clamp_tape_records_and_replays_the_reference_branches(tag):
+    """The relu clamp of fancy_integration (pigan_utils.py:246-252) as test instrumentation (round 4, oracle.ClampTape): on
+    the golden cases that run with nerf_noise > 0, (1) a recording tape changes nothing — images and gradients stay the
+    reference's —, (2) replaying the recorded branches (relu(x) -> x * branch) reproduces the recording run bit for bit,
+    images and every gradient, and (3) the tape sees only the FINAL composite: one record of shape (b, n, E, 1) per forward
+    (the coarse composite that feeds the resampler stays unpinned: the fine-sample placement has its own pin)."""
+    fix = load_golden(tag)
+    kw = fix["G_kwargs"]
+    assert fix["nerf_noise"] > 0
+
+    def run(tape):
+        G = seeded_generator(fix["seed"], freeze=fix["freeze"])
+        with orc.clamp_tape(tape):
+            out = orc.generator_forward(dict(G.named_parameters()), fix["zs"], fix["rand"], fix["img_size"], kw["fov"], kw["ray_start"],
+                                        kw["ray_end"], kw["num_steps"], kw["h_stddev"], kw["v_stddev"], kw["hierarchical_sample"],
+                                        nerf_noise=fix["nerf_noise"], return_aux_img=fix["aux"], freeze_nerf=fix["freeze"])
+        (out["imgs"] * fix["G0"]).sum().backward()
+        return out["imgs"].detach(), {n: (None if p.grad is None else p.grad.clone()) for n, p in G.named_parameters()}
+
+    rec = orc.ClampTape()
+    img_rec, g_rec = run(rec)
+    assert torch.equal(img_rec, run(None)[0])                                   # recording does not change the arithmetic
+    assert max_rel(img_rec, fix["imgs"]) < 1e-6
+    b, n = fix["zs"]["z_nerf"].shape[0], fix["img_size"] ** 2
+    E = kw["num_steps"] * (2 if kw["hierarchical_sample"] else 1)
+    assert len(rec.rec) == 1 and tuple(rec.rec[0].shape) == (b, n, E, 1)
+    frac = float(rec.rec[0].float().mean())
+    assert 0.0 < frac < 1.0                                                      # both branches occur: the pin is not vacuous
+    pin = orc.ClampTape(pin=[rec.rec[0].to(torch.uint8)])
+    img_pin, g_pin = run(pin)
+    assert torch.equal(img_pin, img_rec)
+    for name in g_rec:
+        assert (g_rec[name] is None) == (g_pin[name] is None), name
+        if g_rec[name] is not None:
+            assert torch.equal(g_pin[name], g_rec[name]), name
