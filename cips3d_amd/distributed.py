@@ -234,8 +234,8 @@ class GradAllReducer:
             ev.synchronize()
         self._pending = None
         if any(abs(float(v) - w) > 1e-3 for v, w in zip(host.tolist(), want)):
-            raise RuntimeError("GradAllReducer: ranks reduced with different bucket plans — the set of parameters with "
-                               "a gradient changed on some ranks only (see the class contract)")
+            raise RuntimeError("GradAllReducer: ranks reduced with different bucket plans — the reducers were constructed with "
+                               "different parameter lists, or the ranks are not calling them in step")
 
     def __call__(self):
         if not dist.is_available() or not dist.is_initialized():
