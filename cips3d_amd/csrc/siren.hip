@@ -487,7 +487,7 @@ extern "C" int cips_siren_fwd(const cips_siren_weights* w, const float* points, 
     hipFuncSetAttribute((const void*)siren_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  if (w->trig_mode == 1)
+  if ((w->trig_mode & 1))
     hipLaunchKernelGGL(siren_fwd_kernel<true>, grid, dim3(512), smem, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(siren_fwd_kernel<false>, grid, dim3(512), smem, (hipStream_t)stream, a);
@@ -519,7 +519,7 @@ extern "C" int cips_siren_bwd_data(const cips_siren_weights* w, const float* poi
     hipFuncSetAttribute((const void*)siren_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  if (w->trig_mode == 1)
+  if ((w->trig_mode & 1))
     hipLaunchKernelGGL(siren_bwd_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(siren_bwd_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);

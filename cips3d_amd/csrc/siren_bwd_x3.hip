@@ -82,6 +82,23 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
   bf16x2 l = __builtin_convertvector(r, bf16x2);
   lo = __builtin_bit_cast(unsigned, l);
 }
+// The same split on fp16 planes (x = hi + lo, 11 + 11 mantissa bits: 2^-22 relative where bf16 planes give 2^-17), for
+// operands of known range only — the forward chain's activations are sines and its weights are staged with a per-matrix
+// power-of-two scale (stage_weights_x3<PRE, true>) — fp16 has 5 exponent bits.  Same instruction count as split2.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& lo) {
+  f32x2 v = {a, b};
+  f16x2 h = __builtin_convertvector(v, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  f32x2 r = v - __builtin_convertvector(h, f32x2);
+  f16x2 l = __builtin_convertvector(r, f16x2);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+template <bool F16>
+__device__ __forceinline__ void split2t(float a, float b, unsigned& hi, unsigned& lo) {
+  if constexpr (F16) split2h(a, b, hi, lo); else split2(a, b, hi, lo);
+}
 // 32 values of a register group (tiles q0, q0+1) -> packed
 template <int Q>
 __device__ __forceinline__ void pack32(const float (&v)[32], Act<Q>& o, int q0) {
@@ -107,6 +124,13 @@ __device__ __forceinline__ f32x16 x3(f32x16 acc, bf16x8 ah, bf16x8 al, bf16x8 bh
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  return acc;
+}
+// same pass order on fp16 planes (v_mfma_f32_32x32x16_f16: the bf16 instruction's rate and fragment layout)
+__device__ __forceinline__ f32x16 x3h(f32x16 acc, u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
   return acc;
 }
 
@@ -157,7 +181,7 @@ __device__ __forceinline__ void put(unsigned (&d)[4], int i, uint2 v) { d[i] = v
 // Dense layers run as a flat list of (k-step, m-tile) items, three MFMAs each, with the A fragment of item
 // i+2 requested from LDS before the MFMAs of item i issue (ring of 3 fragments = 24 registers);
 // sched_barrier(0) pins that order — left alone, hipcc hoists hundreds of LDS reads and spills.
-template <int NM, int KS, typename LoadF>
+template <int NM, int KS, bool F16 = false, typename LoadF>
 __device__ __forceinline__ void run_layer(LoadF load, const Act<(KS + 1) / 2>& in, f32x16 (&acc)[NM]) {
   constexpr int NI = NM * KS, D = 2;
   Frag ring[D + 1];
@@ -168,12 +192,21 @@ __device__ __forceinline__ void run_layer(LoadF load, const Act<(KS + 1) / 2>& i
   for (int it = 0; it < NI; ++it) {
     if (it + D < NI) load((it + D) / NM, (it + D) % NM, ring[(it + D) % (D + 1)]);
     const int s = it / NM, m = it % NM, q = s >> 1, t = s & 1;
+    const Frag& f = ring[it % (D + 1)];
+    if constexpr (F16) {
+      const u32x4 bh = {in.hi[q][4 * t], in.hi[q][4 * t + 1], in.hi[q][4 * t + 2], in.hi[q][4 * t + 3]};
+      const u32x4 bl = {in.lo[q][4 * t], in.lo[q][4 * t + 1], in.lo[q][4 * t + 2], in.lo[q][4 * t + 3]};
+      const u32x4 ah = {f.h[0], f.h[1], f.h[2], f.h[3]}, al = {f.l[0], f.l[1], f.l[2], f.l[3]};
+      __builtin_amdgcn_sched_barrier(0);
+      acc[m] = x3h(acc[m], ah, al, bh, bl);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     const bf16x8 bh = mk8(in.hi[q][4 * t], in.hi[q][4 * t + 1], in.hi[q][4 * t + 2], in.hi[q][4 * t + 3]);
     const bf16x8 bl = mk8(in.lo[q][4 * t], in.lo[q][4 * t + 1], in.lo[q][4 * t + 2], in.lo[q][4 * t + 3]);
-    const Frag& f = ring[it % (D + 1)];
     __builtin_amdgcn_sched_barrier(0);
     acc[m] = x3(acc[m], mk8(f.h[0], f.h[1], f.h[2], f.h[3]), mk8(f.l[0], f.l[1], f.l[2], f.l[3]), bh, bl);
     __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
@@ -251,7 +284,7 @@ __device__ __forceinline__ LaneAddr lane_addr(int lane, unsigned sbase) {
 
 // Forward-orientation dense layer: acc[m] += W[32m + i][k] * in[k][pt]; W image (R rows = out features) at
 // LDS offset IMG, lo plane PLANE bytes after the hi plane.
-template <int NM, int Q, int R, int IMG, int PLANE>
+template <int NM, int Q, int R, int IMG, int PLANE, bool F16 = false>
 __device__ __forceinline__ void layer_fwd(const LaneAddr& A, const Act<Q>& in, f32x16 (&acc)[NM]) {
   const unsigned b[2][2] = {{opaque(A.fb[0][0] + IMG), opaque(A.fb[0][1] + IMG)}, {opaque(A.fb[1][0] + IMG), opaque(A.fb[1][1] + IMG)}};
   auto load = [&](int s, int m, Frag& f) {            // k-step s = 2q+t: units 8q+4t+hf and +2 of row 32m + lane
@@ -261,7 +294,7 @@ __device__ __forceinline__ void layer_fwd(const LaneAddr& A, const Act<Q>& in, f
     put(f.l, 0, lds_b64(b[s & 1][0] + c + PLANE));
     put(f.l, 2, lds_b64(b[s & 1][1] + c + PLANE));
   };
-  run_layer<NM, 2 * Q>(load, in, acc);
+  run_layer<NM, 2 * Q, F16>(load, in, acc);
 }
 
 template <int NM, int Q, int R, int IMG, int PLANE, typename SideF>
@@ -388,16 +421,67 @@ constexpr int SRED = 4 * 32 * 8 + 8;   // per wave a 32x8 tile of column sums, t
 // offsets c1 / cc — so that gain * (W h) + c comes out in REVOLUTIONS and the sine is v_fract + v_sin with no multiply
 // (the FiLM gains g1 / gc and ws stay as they are: the backward multiplies by them).  A backward that runs on these images
 // carries the factor through its linear chain and removes it where it writes its partial sums (siren_bwd_x4.inc).
-template <bool PRE = false>
+//
+// F16 (the forward kernels, round 5): the three weight images are fp16 hi / lo planes of  W * 2^k,  k per matrix such that
+// max |W| * 2^k lies in [2^13, 2^14) — every element down to 2^-17 of the largest keeps both planes normal, nothing
+// overflows (fp16 max 65504), and the products hi*hi, hi*lo, lo*hi are exact in the fp32 accumulator.  The scale leaves
+// through the consumers: G1 and GC hold gain * 2^-k (a power of two: exact), the colour head's 2^-k sits at O_AUX + 128
+// for the kernel's output fma.  Why: sigma = ws . sin(g1 (W1 h1) + c1) is the argument of two DISCONTINUOUS consumers —
+// relu(sigma + noise) in fancy_integration (pigan_utils.py:246-252) and the cdf search of sample_pdf (:164-209) — so its
+// rounding decides how many samples take another branch than the fp32 reference's.  bf16 planes carry W1 h1 to ~5e-6 of
+// its rms, fp16 planes to ~2e-7, the level of an fp32 fmaf chain, at the same three MFMAs per k-step.
+__device__ __forceinline__ float pow2_scale_for(float m, int& k) {
+  const unsigned u = __float_as_uint(m);
+  const int e = (int)((u >> 23) & 0xffu) - 127;
+  k = 13 - e;
+  if (!(m > 0.f) || e == 128) k = 0;           // all-zero, NaN or inf weights: no scaling (the result is theirs anyway)
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  return __uint_as_float((unsigned)(k + 127) << 23);
+}
+template <bool PRE = false, bool F16 = false>
 __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_weights& w, int b) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const float pre = PRE ? CIPS_INV_2PI : 1.f;
+  float s1 = 1.f, sc = 1.f, sf = 1.f, i1 = 1.f, ic = 1.f, isf = 1.f;
+  if constexpr (F16) {
+    // per-matrix max |W|: lane-local, wave (DPP) and workgroup (LDS words at the start of the not yet written W1 image)
+    float m1 = 0.f, mc = 0.f, mf = 0.f;
+    for (int i = tid; i < H * 32; i += nt) {
+      const float4 v = *reinterpret_cast<const float4*>(w.w1 + 4 * i);
+      m1 = fmaxf(fmaxf(m1, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (int i = tid; i < HC * 32; i += nt) {
+      const float4 v = *reinterpret_cast<const float4*>(w.wc + 4 * i);
+      mc = fmaxf(fmaxf(mc, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (int i = tid; i < CF * 16; i += nt) {
+      const float4 v = *reinterpret_cast<const float4*>(w.wf + 4 * i);
+      mf = fmaxf(fmaxf(mf, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    // NaN weights: fmaxf drops them here; they reach the planes (and every output) through the split below
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      m1 = fmaxf(m1, __shfl_xor(m1, o)); mc = fmaxf(mc, __shfl_xor(mc, o)); mf = fmaxf(mf, __shfl_xor(mf, o));
+    }
+    float* red = reinterpret_cast<float*>(sm + O_W1H);
+    const int wv = tid >> 6, nw = nt >> 6;
+    if ((tid & 63) == 0) { red[3 * wv] = m1; red[3 * wv + 1] = mc; red[3 * wv + 2] = mf; }
+    __syncthreads();
+    m1 = 0.f; mc = 0.f; mf = 0.f;
+    for (int i = 0; i < nw; ++i) { m1 = fmaxf(m1, red[3 * i]); mc = fmaxf(mc, red[3 * i + 1]); mf = fmaxf(mf, red[3 * i + 2]); }
+    __syncthreads();
+    int k1, kc, kf;
+    s1 = pow2_scale_for(m1 * pre, k1); sc = pow2_scale_for(mc * pre, kc); sf = pow2_scale_for(mf, kf);
+    i1 = __uint_as_float((unsigned)(127 - k1) << 23); ic = __uint_as_float((unsigned)(127 - kc) << 23);
+    isf = __uint_as_float((unsigned)(127 - kf) << 23);
+  }
   for (int i = tid; i < H * 32; i += nt) {                  // W1: 128 rows x 32 units
     const int row = i >> 5, u = i & 31;
     float4 v = *reinterpret_cast<const float4*>(w.w1 + row * H + 4 * u);
     if (PRE) { v.x *= pre; v.y *= pre; v.z *= pre; v.w *= pre; }
+    if (F16) { v.x *= s1; v.y *= s1; v.z *= s1; v.w *= s1; }
     uint2 ph, pl;
-    split2(v.x, v.y, ph.x, pl.x); split2(v.z, v.w, ph.y, pl.y);
+    split2t<F16>(v.x, v.y, ph.x, pl.x); split2t<F16>(v.z, v.w, ph.y, pl.y);
     const int o = img_addr<2>(row, u, H);
     *reinterpret_cast<uint2*>(sm + O_W1H + o) = ph;
     *reinterpret_cast<uint2*>(sm + O_W1L + o) = pl;
@@ -406,17 +490,19 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
     const int row = i >> 5, u = i & 31;
     float4 v = *reinterpret_cast<const float4*>(w.wc + row * H + 4 * u);
     if (PRE) { v.x *= pre; v.y *= pre; v.z *= pre; v.w *= pre; }
+    if (F16) { v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
     uint2 ph, pl;
-    split2(v.x, v.y, ph.x, pl.x); split2(v.z, v.w, ph.y, pl.y);
+    split2t<F16>(v.x, v.y, ph.x, pl.x); split2t<F16>(v.z, v.w, ph.y, pl.y);
     const int o = img_addr<2>(row, u, HC);
     *reinterpret_cast<uint2*>(sm + O_WCH + o) = ph;
     *reinterpret_cast<uint2*>(sm + O_WCL + o) = pl;
   }
   for (int i = tid; i < CF * 16; i += nt) {                 // Wf: 32 rows x 16 units
     const int row = i >> 4, u = i & 15;
-    const float4 v = *reinterpret_cast<const float4*>(w.wf + row * HC + 4 * u);
+    float4 v = *reinterpret_cast<const float4*>(w.wf + row * HC + 4 * u);
+    if (F16) { v.x *= sf; v.y *= sf; v.z *= sf; v.w *= sf; }
     uint2 ph, pl;
-    split2(v.x, v.y, ph.x, pl.x); split2(v.z, v.w, ph.y, pl.y);
+    split2t<F16>(v.x, v.y, ph.x, pl.x); split2t<F16>(v.z, v.w, ph.y, pl.y);
     const int o = img_addr<2>(row, u, CF);
     *reinterpret_cast<uint2*>(sm + O_WFH + o) = ph;
     *reinterpret_cast<uint2*>(sm + O_WFL + o) = pl;
@@ -433,12 +519,13 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
     if (PRE) { pk.x *= pre; pk.y *= pre; pk.z *= pre; pk.w *= pre; }
     reinterpret_cast<float4*>(L0)[f] = pk;
     const float g1 = w.g1[b * H + f];
-    G1[f] = g1; C1[f] = fmaf(g1, w.b1[f], w.p1[b * H + f]) * pre; WS[f] = w.ws[f];
+    G1[f] = F16 ? g1 * i1 : g1; C1[f] = fmaf(g1, w.b1[f], w.p1[b * H + f]) * pre; WS[f] = w.ws[f];
   }
   for (int f = tid; f < HC; f += nt) {
     const float gc = w.gc[b * HC + f];
-    GC[f] = gc; CC[f] = fmaf(gc, w.bc[f], w.pc[b * HC + f]) * pre;
+    GC[f] = F16 ? gc * ic : gc; CC[f] = fmaf(gc, w.bc[f], w.pc[b * HC + f]) * pre;
   }
+  if (F16 && tid == 0) *reinterpret_cast<float*>(sm + O_AUX + 128) = isf;
 }
 
 // phase timestamps for tuning (host passes a buffer only when CIPS_X3_PROF is set): workgroup (0,0), lane 0 of
@@ -878,16 +965,17 @@ struct FwdX3Args {
   int B, P, chunk;
 };
 
-template <bool HW>
+template <bool HW, bool F16>
 __global__ __launch_bounds__(512) void siren_fwd_x3_kernel(FwdX3Args a) {
   extern __shared__ __attribute__((aligned(1024))) uchar smem[];
   const int b = blockIdx.y;
-  stage_weights_x3<HW>(smem, a.w, b);
+  stage_weights_x3<HW, F16>(smem, a.w, b);
   if (threadIdx.x < CF) reinterpret_cast<float*>(smem + O_AUX)[threadIdx.x] = a.w.bf[threadIdx.x];   // bf[32] (aux image unused here)
   __syncthreads();
   const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uchar*)smem);
   const float bs = a.w.bs[0];
+  const float isf = F16 ? reinterpret_cast<const float*>(smem + O_AUX)[32] : 1.f;      // 2^-k of the colour head's weight image
   const int cstart = blockIdx.x * a.chunk;
   const int cend = min(cstart + a.chunk, a.P);
   for (int pbase = cstart + wave * 32; pbase < cend; pbase += 8 * 32) {
@@ -909,10 +997,10 @@ __global__ __launch_bounds__(512) void siren_fwd_x3_kernel(FwdX3Args a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 v;
-        v.x = accf[0][4 * g + 0] + bfv[8 * g + 4 * hf + 0];
-        v.y = accf[0][4 * g + 1] + bfv[8 * g + 4 * hf + 1];
-        v.z = accf[0][4 * g + 2] + bfv[8 * g + 4 * hf + 2];
-        v.w = accf[0][4 * g + 3] + bfv[8 * g + 4 * hf + 3];
+        v.x = fmaf(accf[0][4 * g + 0], isf, bfv[8 * g + 4 * hf + 0]);
+        v.y = fmaf(accf[0][4 * g + 1], isf, bfv[8 * g + 4 * hf + 1]);
+        v.z = fmaf(accf[0][4 * g + 2], isf, bfv[8 * g + 4 * hf + 2]);
+        v.w = fmaf(accf[0][4 * g + 3], isf, bfv[8 * g + 4 * hf + 3]);
         *reinterpret_cast<float4*>(fo + 8 * g) = v;
       }
       if (hf == 0) {
@@ -951,11 +1039,11 @@ struct MarchArgs {
 };
 
 
-template <bool HW, bool DBG>
+template <bool HW, bool DBG, bool F16>
 __global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
   extern __shared__ __attribute__((aligned(1024))) uchar smem[];
   const int b = blockIdx.y;
-  stage_weights_x3<HW>(smem, a.w, b);
+  stage_weights_x3<HW, F16>(smem, a.w, b);
   if (threadIdx.x < CF) reinterpret_cast<float*>(smem + O_AUX)[threadIdx.x] = a.w.bf[threadIdx.x];
   __syncthreads();
   const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -967,6 +1055,7 @@ __global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
   const int cend = min(cstart + a.rays_per_wg, n);
   const float* M = g.c2w + (long long)b * 16;
   const float* bfv = reinterpret_cast<const float*>(smem + O_AUX);
+  const float isf = F16 ? bfv[32] : 1.f;        // 2^-k of the colour head's weight image
   for (int rbase = cstart + wave * 32; rbase < cend; rbase += 8 * 32) {
     const int l31s = lane0 & 31, hfs = lane0 >> 5;
     const int ray_raw = rbase + l31s;
@@ -1004,7 +1093,7 @@ __global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
 #include "siren_fwd_chain.inc"
       float f[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) f[r] = accf[0][r] + bias[r];
+      for (int r = 0; r < 16; ++r) f[r] = fmaf(accf[0][r], isf, bias[r]);
       // ---- composite (pigan_utils.py:239-258): alpha = 1 - exp(-delta * clamp(sigma + noise)), w = alpha * T ----
       const float delta = (s + 1 < S) ? (zn - zs) : 1e10f;
       const float sg = a.noise ? sig + nse * a.noise_std : sig;
@@ -1254,13 +1343,13 @@ static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points,
       hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
       attr4 = true;
     }
-    if (w->trig_mode == 1)
+    if ((w->trig_mode & 1))
       hipLaunchKernelGGL(siren_bwd_x4_kernel<true>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
     else
       hipLaunchKernelGGL(siren_bwd_x4_kernel<false>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
     return CIPS_CHECK_LAUNCH();
   }
-  if (w->trig_mode == 1)
+  if ((w->trig_mode & 1))
     hipLaunchKernelGGL(siren_bwd_x3_kernel<true>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(siren_bwd_x3_kernel<false>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
@@ -1293,17 +1382,21 @@ static int siren_fwd_x3_launch(const cips_siren_weights* w, const float* points,
   while (a.chunk > 512 && (long long)B * ((P + a.chunk - 1) / a.chunk) < 768) a.chunk >>= 1;
   dim3 grid((P + a.chunk - 1) / a.chunk, B);
   const int smem = O_STG;            // weight images + FiLM vectors + the 4 KiB slot reused for the output bias
-  static bool attr_set = false;
-  CIPS_PER_DEVICE(attr_set, false);
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)siren_fwd_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)siren_fwd_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
-  if (w->trig_mode == 1)
-    hipLaunchKernelGGL(siren_fwd_x3_kernel<true>, grid, dim3(512), smem, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(siren_fwd_x3_kernel<false>, grid, dim3(512), smem, (hipStream_t)stream, a);
+  // trig_mode bit 0: hardware sine; bit 1 (A/B runs only): the round-1..4 bf16 operand planes instead of fp16
+  const bool hw = (w->trig_mode & 1) != 0, f16 = (w->trig_mode & 2) == 0;
+  auto go = [&](auto HW_, auto F16_) {
+    constexpr bool HW = decltype(HW_)::value, F16 = decltype(F16_)::value;
+    static bool attr_set = false;
+    CIPS_PER_DEVICE(attr_set, false);
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)siren_fwd_x3_kernel<HW, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((siren_fwd_x3_kernel<HW, F16>), grid, dim3(512), smem, (hipStream_t)stream, a);
+  };
+  using T = std::true_type; using F = std::false_type;
+  if (hw) { if (f16) go(T{}, T{}); else go(T{}, F{}); }
+  else { if (f16) go(F{}, T{}); else go(F{}, F{}); }
   return CIPS_CHECK_LAUNCH();
 }
 
@@ -1323,22 +1416,25 @@ extern "C" int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_par
   const int n = a.rg.n;
   dim3 grid((n + a.rays_per_wg - 1) / a.rays_per_wg, B);
   const int smem = O_STG;
-  static bool attr_set = false;
-  CIPS_PER_DEVICE(attr_set, false);
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
   const bool dbg = a.clamp_pin || a.clamp_rec;
-  if (w->trig_mode == 1) {
-    if (dbg) hipLaunchKernelGGL((siren_march_x3_kernel<true, true>), grid, dim3(512), smem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((siren_march_x3_kernel<true, false>), grid, dim3(512), smem, (hipStream_t)stream, a);
+  const bool hw = (w->trig_mode & 1) != 0, f16 = (w->trig_mode & 2) == 0;
+  auto go = [&](auto HW_, auto DBG_, auto F16_) {
+    constexpr bool HW = decltype(HW_)::value, DBG = decltype(DBG_)::value, F16 = decltype(F16_)::value;
+    static bool attr_set = false;
+    CIPS_PER_DEVICE(attr_set, false);
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)siren_march_x3_kernel<HW, DBG, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((siren_march_x3_kernel<HW, DBG, F16>), grid, dim3(512), smem, (hipStream_t)stream, a);
+  };
+  using T = std::true_type; using F = std::false_type;
+  if (hw) {
+    if (dbg) { if (f16) go(T{}, T{}, T{}); else go(T{}, T{}, F{}); }
+    else { if (f16) go(T{}, F{}, T{}); else go(T{}, F{}, F{}); }
   } else {
-    if (dbg) hipLaunchKernelGGL((siren_march_x3_kernel<false, true>), grid, dim3(512), smem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((siren_march_x3_kernel<false, false>), grid, dim3(512), smem, (hipStream_t)stream, a);
+    if (dbg) { if (f16) go(F{}, T{}, T{}); else go(F{}, T{}, F{}); }
+    else { if (f16) go(F{}, F{}, T{}); else go(F{}, F{}, F{}); }
   }
   return CIPS_CHECK_LAUNCH();
 }

@@ -134,6 +134,58 @@ def test_siren_forward_x3(trig, b, P, monkeypatch):
     assert e_f < 2e-4 and e_s < 2e-4
 
 
+def _siren_fp64(G, pts, style):
+    sd64 = {k: v.detach().double() for k, v in G.named_parameters()}
+    with torch.no_grad():
+        return orc.siren(sd64, pts.double(), style.double())
+
+
+@pytest.mark.parametrize("scale_w", [1.0, 37.0, 3e-4])
+def test_siren_forward_x3_sigma_is_fp32_class(scale_w, monkeypatch):
+    """Round 5: the forward chain's dense layers run on fp16 hi / lo planes with per-matrix power-of-two weight scales
+    (siren_bwd_x3.hip: stage_weights_x3<., true>).  sigma feeds two discontinuities (the relu clamp, the cdf search), so its
+    error is measured against an fp64 evaluation next to the fp32 oracle's own: the product has to be in the oracle's class
+    (<= 2x its rms distance from fp64 + 2e-7), where the bf16 planes of rounds 1-4 sat 5-10x above it.  scale_w rescales
+    W1 / Wc / Wf and compensates in the FiLM gains' biases so that the function stays in range: the images must not depend on
+    the magnitude of the weights (fp16 has 5 exponent bits; the scale is chosen per matrix in-kernel)."""
+    from cips3d_amd import ops
+    monkeypatch.setattr(ops, "SIREN_FWD_MODE", "x3")
+    b, P = 2, 4096 * 2 + 160
+    G, pts, style = _siren_inputs(11, b, P)
+    with torch.no_grad():
+        # the FiLM gain is 15 * gain_fc(style) + 30: scaling W by s and the gain layer's OUTPUT by 1/s needs the affine
+        # part too, so scale the linear's weight and bias by s and divide gain_fc's weight and (bias + 2) by s
+        for lay in (G.siren.network[1], G.siren.color_layer_sine):
+            lay.linear.weight.mul_(scale_w); lay.linear.bias.mul_(scale_w)
+            lay.gain_fc.weight.div_(scale_w); lay.gain_fc.bias.copy_((lay.gain_fc.bias + 2.0) / scale_w - 2.0)
+        G.siren.color_layer_linear[0].weight.mul_(scale_w)
+    ref64 = _siren_fp64(G, pts, style)
+    with torch.no_grad():
+        ref32 = orc.siren(dict(G.named_parameters()), pts, style)
+    Gd = G.to(dev())
+    st = style.to(dev())
+    res = {}
+    for name, trig in (("f16", 1), ("bf16", 3)):
+        old_trig, ops.TRIG_MODE = ops.TRIG_MODE, trig
+        try:
+            with torch.no_grad():
+                res[name] = Gd.siren(pts.to(dev()), {"nerf_w0": st, "nerf_w1": st, "nerf_rgb": st}).cpu().double()
+        finally:
+            ops.TRIG_MODE = old_trig
+    torch.cuda.synchronize()
+
+    def rms(a, sl):
+        return float((a[..., sl] - ref64[..., sl]).pow(2).mean().sqrt() / ref64[..., sl].pow(2).mean().sqrt())
+    sig, fea = slice(32, 33), slice(0, 32)
+    o_s, o_f = rms(ref32.double(), sig), rms(ref32.double(), fea)
+    p_s, p_f = rms(res["f16"], sig), rms(res["f16"], fea)
+    q_s, q_f = rms(res["bf16"], sig), rms(res["bf16"], fea)
+    print(f"siren fwd scale_w={scale_w}: rms error vs fp64  sigma: oracle(fp32) {o_s:.2e} fp16-planes {p_s:.2e} bf16-planes {q_s:.2e}"
+          f" | feat: oracle {o_f:.2e} fp16-planes {p_f:.2e} bf16-planes {q_f:.2e}")
+    assert p_s <= 2 * o_s + 2e-7 and p_f <= 2 * o_f + 2e-7
+    assert p_s < q_s
+
+
 @pytest.mark.parametrize("trig,mode,b,P", [(0, "x3", 2, 2048 + 96), (1, "x3", 2, 2048 + 96), (1, "x3", 3, 128 * 7 + 5),
                                              (1, "x3", 1, 4096 * 3), (0, "staged", 2, 2048 + 96), (1, "staged", 2, 2048 + 96)])
 def test_siren_backward(trig, mode, b, P, monkeypatch):

@@ -115,7 +115,7 @@ def test_c1_forward_backward_vs_oracle():
     `siren.final_layer.weight` (alone) once the SIREN forward computed its sine arguments in revolutions: a handful of
     samples took the other side of a discontinuity, which is an input of the sigma head's gradient, not an error of it."""
     n = _g_forward_backward_vs_oracle("C1 b=4 r32 S=12+12 aux, nerf_noise 0.2", 4, 32, 12, True, True, 0.2, 31, pin_fine=True,
-                                      pin_clamp=True, tol=2e-4)
+                                      pin_clamp=True, tol=2e-4, free_bar=1e-3)
     assert n == 130, n
 
 
@@ -205,7 +205,12 @@ def test_discriminator_real_sizes_vs_oracle(size, b, alpha):
     _grad_compare(list(Dd.named_parameters()), ref_grads, f"D {size}x{size} gradients (oracle's gates pinned)")
 
 
-def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, pin_fine=False, pin_clamp=False, tol=None):
+FREE_AB = None           # scripts/free_running_parity.py: [(label, ops.TRIG_MODE), ...] arms of the free-running run
+FREE_RUNNING = {}        # what -> {"final_layer.weight": e, "final_layer.bias": e, "worst": (name, e)}: scripts/free_running_parity.py
+
+
+def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, pin_fine=False, pin_clamp=False, tol=None,
+                                  free_bar=None):
     """forward + every parameter gradient of `(imgs * G0).sum()` against the oracle, the oracle's LeakyReLU gates pinned.
     pin_fine: also the oracle's placement of the resampled (fine) samples — the searchsorted of the importance
     resampling is the path's second discontinuity: a cdf value within rounding of the uniform draw lands a sample in the
@@ -214,7 +219,12 @@ def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, 
     pin_clamp: also the branch the oracle's `relu(sigma + nerf_noise * eps)` took per sample (pigan_utils.py:246-252, the
     third discontinuity; ops.clamp_debug / orc.clamp_tape): the free-running branches are compared first — every sample
     whose branch differs must be ambiguous (|pre-activation| within the SIREN forward's rounding of 0) and they are counted
-    — then forward and backward run on the oracle's branches."""
+    — then forward and backward run on the oracle's branches.
+    free_bar (round 5): after the pinned comparison the SAME step runs FREE — fine-sample placement and clamp branches are the
+    product's own; only the INR head's LeakyReLU gates stay pinned (they are the head's matter, proven in
+    test_gpu_generator.py, and one flipped gate moves the head's gradients, not the sigma head's) — and the sigma head's two
+    gradients (siren.final_layer.*: the ones the round-4 split-bf16 forward moved by 4.4e-3 at r128 / 8.1e-4 at C1) are
+    asserted against the fp32 oracle at `free_bar`; every other gradient at 10 x GRAD_TOL as a regression bound."""
     from cips3d_amd import ops
     d = torch.device("cuda:0")
     g = torch.Generator().manual_seed(seed)
@@ -291,6 +301,35 @@ def _g_forward_backward_vs_oracle(what, b, img, S, hier, aux, nerf_noise, seed, 
     torch.cuda.synchronize()
     _grad_compare(list(Gd.named_parameters()), ref_grads, f"{what} gradients (oracle's gates" + (" and fine-sample placement" if pin_fine else "")
                   + (" and relu-clamp branches" if pin_clamp else "") + " pinned)", ref64=ref64, tol=tol)
+    if free_bar is not None:
+        for label, trig in (FREE_AB or [("", None)]):
+            old_trig = ops.TRIG_MODE
+            if trig is not None:
+                ops.TRIG_MODE = trig
+            try:
+                Gd.zero_grad(set_to_none=True)
+                imgs = _product_forward(Gd, zs, rand, d, img, S, hier, aux=aux, pin=pins, nerf_noise=nerf_noise)
+                (imgs * G0.to(d)).sum().backward()
+                torch.cuda.synchronize()
+            finally:
+                ops.TRIG_MODE = old_trig
+            errs = {}
+            for name, p in Gd.named_parameters():
+                r = ref_grads.get(name)
+                if r is not None:
+                    errs[name] = float((p.grad.detach().cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-300))
+            head = {k: v for k, v in errs.items() if k.startswith("siren.final_layer.")}
+            rest = {k: v for k, v in errs.items() if k not in head}
+            wk = max(rest, key=rest.get)
+            key = what + (f" [{label}]" if label else "")
+            FREE_RUNNING[key] = {"imgs": max_rel(imgs, ref_imgs), "final_layer.weight": head["siren.final_layer.weight"],
+                                 "final_layer.bias": head["siren.final_layer.bias"], "worst_other": [wk, rest[wk]]}
+            print(f"{key}: FREE-RUNNING (gates pinned; placement and clamp the product's own): siren.final_layer.weight "
+                  f"{head['siren.final_layer.weight']:.2e}, .bias {head['siren.final_layer.bias']:.2e} (bar {free_bar:.0e}); worst other "
+                  f"gradient {rest[wk]:.2e} ({wk}); images {FREE_RUNNING[key]['imgs']:.2e}")
+            if trig is None or trig == 1:
+                assert all(v <= free_bar for v in head.values()), head
+                assert rest[wk] <= 10 * GRAD_TOL, (wk, rest[wk])
     return len(ref_grads)
 
 
@@ -320,7 +359,7 @@ def test_c3_r128_pair_forward_backward_vs_oracle():
     sums of d sigma with heavy cancellation — moved by 4.4e-3 free-running).  Bars against the fp64 evaluation of
     the same network with the same three pins: max(2e-4, 4 x the fp32 oracle's own distance from fp64), see _grad_compare."""
     _g_forward_backward_vs_oracle("C3 geometry b=2 r128 S=12+12, aux, nerf_noise 0.1", 2, 128, 12, True, True, 0.1, 1283,
-                                  pin_fine=True, pin_clamp=True, tol=2e-4)
+                                  pin_fine=True, pin_clamp=True, tol=2e-4, free_bar=1e-3)
 
 
 def _aug_draws(g, nb, size):
