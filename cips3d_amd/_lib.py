@@ -75,6 +75,7 @@ class GemmX3Desc(C.Structure):
         ("act", i32), ("slope", f32), ("res_hi", vp), ("res_lo", vp), ("gate_bits", i32),
         ("torgb_w", vp), ("torgb_part", vp),
         ("addp_hi", vp), ("addp_lo", vp), ("addp_gate", vp), ("addp_gain", f32),
+        ("kernel", i32),
     ]
 
 
@@ -102,17 +103,15 @@ SIGNATURES = {
     "cips_siren_bwd_x3_chunks": (i32, [i32, i32]),
     "cips_siren_bwd_x3_gpart": (i32, []),
     "cips_siren_bwd_x3_sred": (i32, []),
-    "cips_siren_bwd_x3_prof": (i32, [vp]),
     "cips_siren_bwd_x3": (i32, [C.POINTER(SirenWeights), vp, vp, vp, vp, vp, i32, i32, vp]),
     "cips_siren_fwd_x3_rays": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, vp, vp, i32, vp]),
     "cips_siren_bwd_x3_rays": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, vp, vp, vp, i32, vp]),
     "cips_siren_bwd_x3_finalize": (i32, [C.POINTER(SirenWeights), vp, vp, i32, i32, C.POINTER(SirenGrads), vp]),
-    "cips_march_fwd_x3": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, f32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "cips_march_fwd_x3": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, f32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "cips_siren_bwd_data": (i32, [C.POINTER(SirenWeights)] + [vp] * 14 + [i32, i32, vp]),
     "cips_resample_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, C.POINTER(RayParams), vp]),
-    "cips_composite_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "cips_composite_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "cips_debug_clamp": (i32, [vp, vp]),
+    "cips_composite_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "cips_composite_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "cips_gemm_f32": (i32, [C.POINTER(GemmDesc), vp]),
     "cips_gemm_bf16x3": (i32, [C.POINTER(GemmX3Desc), vp]),
     "cips_gemm_bf16x3_fuses_torgb": (i32, [C.POINTER(GemmX3Desc)]),
@@ -120,7 +119,6 @@ SIGNATURES = {
     "cips_torgb_finish": (i32, [vp, i32, vp, vp, i64, i32, vp]),
     "cips_equal_linear_scratch": (i64, [i32, i32, i32, i32]),
     "cips_equal_linear": (i32, [i32, vp, vp, vp, f32, f32, vp, vp, i32, i32, i32, vp]),
-    "cips_gemm_bf16x3_set_wide": (None, [i32]),
     "cips_gemm_bf16x3_km": (i32, [C.POINTER(GemmX3Desc), vp]),
     "cips_gemm_bf16x3_km_grouped": (i32, [C.POINTER(GemmX3Desc), i32, vp]),
     "cips_lrelu_bwd_bias_slices": (i32, [i32]),

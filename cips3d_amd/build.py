@@ -17,6 +17,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 # `#pragma unroll` — it then stays a loop, the accumulator / activation arrays are indexed dynamically and live in scratch
 # (1 728 bytes per lane, measured).  The limit is raised for this file only (the other sources' code generation is unchanged).
 EXTRA_FLAGS = {"siren_bwd_x3.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
+HIPCC_EXTRA = []      # scripts/probe/build_tuning.sh appends the probe-build define here; the product build passes nothing
 
 
 def _stale(target, deps):
@@ -39,7 +40,7 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + HIPCC_EXTRA + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

@@ -5,6 +5,20 @@
 
 #define CIPS_CHECK_LAUNCH() (int)hipGetLastError()
 
+// Tuning aids (phase skipping, store suppression, start-phase skew, in-kernel timestamps) produce WRONG results by design and
+// exist only in probe builds: `hipcc -DCIPS_TUNING` (scripts/probe/build_tuning.sh).  The production library compiles them
+// out — CIPS_TUNE(x) is the constant 0 — and reads no environment variable at all (tests/test_abi.py checks the binary).
+#ifdef CIPS_TUNING
+#include <stdlib.h>
+#define CIPS_TUNE(x) (x)
+static inline int cips_tune_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+#define CIPS_TUNE(x) 0
+#endif
+
+// cross-file entry points that are not part of the C-ABI (include/cips3d_hip.h): kept out of the dynamic symbol table
+#define CIPS_INTERNAL __attribute__((visibility("hidden")))
+
 // Launchers cache per-DEVICE facts in function-local statics (dynamic-LDS attribute set, CU count).  One process
 // normally drives one GPU, but nothing enforces it: a cached flag is reset whenever the calling thread's current device
 // is not the one it was set for, so a second GPU gets its own hipFuncSetAttribute / CU count.

@@ -657,7 +657,7 @@ extern "C" int cips_image_to_u8(const float* x, unsigned char* out, int B, int C
   return CIPS_CHECK_LAUNCH();
 }
 
-extern "C" int cips_version(void) { return 4; }
+extern "C" int cips_version(void) { return 5; }
 extern "C" const char* cips_arch(void) { return "gfx950"; }
 
 extern "C" int cips_fused_bias_act(const float* x, const float* bias, const float* refer, float* y,
@@ -685,16 +685,15 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
   if (minor == 1 && kernel_h == 4 && kernel_w == 4 && up_x == up_y && down_x == down_y) {
     hipStream_t st = (hipStream_t)stream;
     if (up_x == 1 && (down_x == 1 || down_x == 2)) {
-      static int tile = -1;                      // CIPS_BLUR_TILE: 0 = 4 x 4 outputs per thread, 1 = 1 x 16, 2 = 1 x 8
-      if (tile < 0) { const char* e = getenv("CIPS_BLUR_TILE"); tile = e ? atoi(e) : 1; }
-      const int eff = (tile == 1 && a.out_h < 48) ? 2 : tile;          // short planes: 1 x 8 wastes fewer rows of the last block
-      const int tw = eff == 0 ? 4 : 1, th = eff == 0 ? 4 : (eff == 2 ? 8 : 16);
-      const int bw = (a.out_w + tw - 1) / tw, bh = (a.out_h + th - 1) / th;
+      // thread tile: 1 x 16 outputs with the lanes along x (fully coalesced loads; the 4 x 4 tile of round 2 put neighbouring
+      // lanes 16 B apart and moved 12.5x the output bytes through the texture path), 1 x 8 on short planes (fewer wasted rows)
+      const int th = a.out_h < 48 ? 8 : 16;
+      const int bw = a.out_w, bh = (a.out_h + th - 1) / th;
       const long long nthreads = (long long)major * bw * bh;
       const unsigned grid = (unsigned)((nthreads + 255) / 256 < 131072 ? (nthreads + 255) / 256 : 131072);
 #define CIPS_UF(D, TW_, TH_) hipLaunchKernelGGL((upfirdn2d_direct_kernel<D, TW_, TH_>), dim3(grid), dim3(256), 0, st, a, bw, bh)
-      if (down_x == 1) { if (eff == 0) CIPS_UF(1, 4, 4); else if (eff == 2) CIPS_UF(1, 1, 8); else CIPS_UF(1, 1, 16); }
-      else { if (eff == 0) CIPS_UF(2, 4, 4); else if (eff == 2) CIPS_UF(2, 1, 8); else CIPS_UF(2, 1, 16); }
+      if (down_x == 1) { if (th == 8) CIPS_UF(1, 1, 8); else CIPS_UF(1, 1, 16); }
+      else { if (th == 8) CIPS_UF(2, 1, 8); else CIPS_UF(2, 1, 16); }
 #undef CIPS_UF
       return CIPS_CHECK_LAUNCH();
     }

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   // CU reaches its store-heavy epilogue at the same moment.  Measured neutral on MI355X: the epilogue traffic adds
   // to the main loop's time whatever the phase relation (268 MB of fp32 C cost ~75 us on top of a 205 us main
   // loop), i.e. the kernel is bound by the memory system, not by MFMA issue.
-  if (g.stagger_cycles > 0) {
+  if (CIPS_TUNE(g.stagger_cycles) > 0) {
     // 256-row form: four phases across CUs.  128-row form (two workgroups per CU): the second half of the grid
     // (the co-resident partner of workgroup b is b + #CUs) starts half a tile later, so that one workgroup's
     // store drain overlaps its partner's MFMA phase.
@@ -211,10 +211,10 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
   // front of tile kt is a COUNTED vmcnt that leaves the younger tiles' pieces outstanding
   // (cdna_hip_programming.md T3/T4: never drain to 0 in the main loop).
   constexpr int NSTAGE = CF::NSTAGE, PIECES = CF::PIECES, DIST = NSTAGE - 1;
-  const int nk = (g.dbg & 4) ? 0 : K / BK;               // bit2: epilogue only
+  const int nk = CIPS_TUNE(g.dbg & 4) ? 0 : K / BK;               // bit2: epilogue only
 #pragma unroll
   for (int t = 0; t < DIST; ++t)
-    if (t < nk && !(g.dbg & 2)) issue_tile(t, t * BK);
+    if (t < nk && !CIPS_TUNE(g.dbg & 2)) issue_tile(t, t * BK);
   for (int kt = 0; kt < nk; ++kt) {
     const int younger = min(DIST - 1, nk - 1 - kt);      // tiles issued after kt that may stay in flight
     if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
@@ -222,8 +222,8 @@ __global__ __launch_bounds__(Cfg<WM>::THREADS, 2) void gemm_bf16x3_kernel(Args g
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // every wave's pieces of tile kt have landed;
                                                           // every wave is done reading stage (kt-1) % NSTAGE
-    if (kt + DIST < nk && !(g.dbg & 2)) issue_tile((kt + DIST) % NSTAGE, (kt + DIST) * BK);
-    if (!(g.dbg & 1)) compute(kt % NSTAGE);
+    if (kt + DIST < nk && !CIPS_TUNE(g.dbg & 2)) issue_tile((kt + DIST) % NSTAGE, (kt + DIST) * BK);
+    if (!CIPS_TUNE(g.dbg & 1)) compute(kt % NSTAGE);
   }
   __builtin_amdgcn_s_barrier();
 
@@ -759,97 +759,78 @@ __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float* __r
 
 }  // namespace
 
-extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream);   // gemm_bf16x3_wide.hip
-extern "C" int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t stream);     // gemm_bf16x3_v3.hip
-extern "C" int cips_gemm_bf16x3_v3_accepts(const cips_gemm_x3_desc* d);
-static int g_wide = -1;   // -1: from env CIPS_X3_WIDE (default 1); 0 never; 1 for large problems; 2 whenever supported;
-                          // 3: like 2 but never the v3 kernel (tests of the wide kernel proper)
-static int g_v3 = -1;     // env CIPS_X3_V3 (default 1): 256x256 tiles of interior shapes on gemm_bf16x3_v3.hip
-extern "C" void cips_gemm_bf16x3_set_wide(int mode) { g_wide = mode; }
+extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream);   // gemm_bf16x3_wide.hip
+extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t stream);     // gemm_bf16x3_v3.hip
+extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_v3_accepts(const cips_gemm_x3_desc* d);
+// Kernel choice (descriptor field `kernel`, cips3d_hip.h): 0 = automatic — 256x256 tiles (v3 schedule for interior shapes,
+// else the wide kernel) for problems that fill the chip with them, the 256x128 kernel below otherwise; 1 = the 256x128 kernel
+// only; 2 = 256x256 tiles whenever a kernel takes the shape; 3 = like 2 but never the v3 schedule.  1-3 exist for the parity
+// tests and microbenchmarks of each kernel; the choice is an argument of the call, the library keeps no mode.
+static inline bool x3_big(const cips_gemm_x3_desc* d) {
+  return d->N >= 256 && d->M >= 256 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 256;
+}
+static inline bool x3_wants_256(const cips_gemm_x3_desc* d) { return d->kernel >= 2 || (d->kernel == 0 && x3_big(d)); }
 
 extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
   if ((d->K & 31) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
     return (int)hipErrorInvalidValue;
+  if (d->kernel < 0 || d->kernel > 3) return (int)hipErrorInvalidValue;
   if (d->gate_bits && ((d->N & 31) || (d->ldp & 31) || (d->strideP & 31))) return (int)hipErrorInvalidValue;
-  // large square-ish problems: 256x256 tiles (less operand traffic per flop, prefetched epilogue inputs);
-  // CIPS_X3_WIDE=0 keeps everything on the 256x128 kernel below
-  if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }
-  const bool big = d->N >= 256 && d->M >= 256 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 256;
-  if (g_v3 < 0) { const char* e = getenv("CIPS_X3_V3"); g_v3 = e ? atoi(e) : 1; }
-  if (g_wide >= 2 || (g_wide == 1 && big)) {
-    if (g_v3 && g_wide != 3) {
-      const int rc3 = cips_gemm_bf16x3_v3(d, stream);
-      if (rc3 != (int)hipErrorNotSupported) return rc3;
-    }
+  // large square-ish problems: 256x256 tiles (less operand traffic per flop, prefetched epilogue inputs)
+  if (x3_wants_256(d) && d->kernel != 3) {
+    const int rc3 = cips_gemm_bf16x3_v3(d, stream);
+    if (rc3 != (int)hipErrorNotSupported) return rc3;
   }
   if (d->torgb_w) return (int)hipErrorNotSupported;       // only the v3 kernel folds ToRGB in: never drop it silently
   if (d->addp_hi) return (int)hipErrorNotSupported;       // ... and only it takes the addend as gated planes
-  if (g_wide >= 2 || (g_wide == 1 && big)) {
+  if (x3_wants_256(d)) {
     const int rc = cips_gemm_bf16x3_wide(d, stream);
     if (rc != (int)hipErrorNotSupported) return rc;
   }
-  // tile choice: 256x128 / 8 waves / 3-stage ring (default, measured fastest); CIPS_X3_TILE=128 selects 128x128 / 4 waves / 4 stages
-  static int tile = 0;
-  CIPS_PER_DEVICE(tile, 0);
-  if (!tile) {
-    const char* e = getenv("CIPS_X3_TILE");
-    tile = (e && atoi(e) == 128) ? 128 : 256;
+  // 256x128 tile / 8 waves / 3-stage ring
+  static bool attr = false;
+  CIPS_PER_DEVICE(attr, false);
+  if (!attr) {
     hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<4>::SMEM_BYTES);
-    hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<2>::SMEM_BYTES);
+    attr = true;
   }
-  const int BMh = tile;
   Args g;
   g.d = *d;
-  g.tiles_m = (d->M + BMh - 1) / BMh;
+  g.tiles_m = (d->M + 255) / 256;
   g.tiles_n = (d->N + BN - 1) / BN;
   long long total = (long long)g.tiles_m * g.tiles_n * d->batch;
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
   static int ncu = 0;
   CIPS_PER_DEVICE(ncu, 0);
-  if (!ncu) {   // persistent grid: one workgroup per CU for the 256-row form, two for the 128-row form
+  if (!ncu) {   // persistent grid: one workgroup per CU
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     if (ncu <= 0) ncu = 256;
     ncu = (ncu / 8) * 8;
-    const char* e = getenv("CIPS_X3_PERSIST");
-    if (e && atoi(e) == 0) ncu = 0x7fffffff;       // one workgroup per tile (non-persistent) for A/B runs
   }
-  const long long want = (long long)ncu * (tile == 256 ? 1 : 2);
-  const int grid = (int)(g.total < want ? g.total : want);
-  // stagger quantum = a quarter of one tile's main-loop time (~3500 cycles per k-tile), only when every
-  // workgroup walks several tiles and the epilogue writes a lot (any plane / fp32 output)
-  static int stagger_on = -1;
-  if (stagger_on < 0) { const char* e = getenv("CIPS_X3_STAGGER"); stagger_on = (e && atoi(e) == 1) ? 1 : 0; }   // measured: no effect (the F/D GEMMs are memory-system bound), off by default
-  g.stagger_cycles = (stagger_on && g.total >= 2 * grid) ? (d->K / BK) * (tile == 256 ? 3500 : 1800) / 4 : 0;
-  g.ncu = ncu;
-  static int gdbg = -1;
-  if (gdbg < 0) { const char* e = getenv("CIPS_X3_GDBG"); gdbg = e ? atoi(e) : 0; }
-  g.dbg = gdbg;
-  if (tile == 256)
-    hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3(grid), dim3(512), Cfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
-  else
-    hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, dim3(grid), dim3(256), Cfg<2>::SMEM_BYTES, (hipStream_t)stream, g);
+  const int grid = g.total < ncu ? g.total : ncu;
+  g.stagger_cycles = 0; g.ncu = ncu; g.dbg = 0;
+#ifdef CIPS_TUNING
+  // stagger quantum = a quarter of one tile's main-loop time (~3500 cycles per k-tile); measured: no effect
+  g.stagger_cycles = (cips_tune_env("CIPS_X3_STAGGER", 0) == 1 && g.total >= 2 * grid) ? (d->K / BK) * 3500 / 4 : 0;
+  g.dbg = cips_tune_env("CIPS_X3_GDBG", 0);
+#endif
+  hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3(grid), dim3(512), Cfg<4>::SMEM_BYTES, (hipStream_t)stream, g);
   return CIPS_CHECK_LAUNCH();
 }
 
 
 extern "C" int cips_gemm_bf16x3_fuses_torgb(const cips_gemm_x3_desc* d) {
   if (!d || !d->torgb_w) return 0;
-  if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }
-  if (g_v3 < 0) { const char* e = getenv("CIPS_X3_V3"); g_v3 = e ? atoi(e) : 1; }
-  const bool big = d->N >= 256 && d->M >= 256 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 256;
-  if (!(g_v3 && g_wide != 3 && (g_wide >= 2 || (g_wide == 1 && big)))) return 0;
+  if (!(x3_wants_256(d) && d->kernel != 3)) return 0;
   return cips_gemm_bf16x3_v3_accepts(d) == 0 ? 1 : 0;
 }
 
 extern "C" int cips_gemm_bf16x3_takes_addp(const cips_gemm_x3_desc* d) {
   if (!d || !d->addp_hi) return 0;
-  if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }
-  if (g_v3 < 0) { const char* e = getenv("CIPS_X3_V3"); g_v3 = e ? atoi(e) : 1; }
-  const bool big = d->N >= 256 && d->M >= 256 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 256;
-  if (!(g_v3 && g_wide != 3 && (g_wide >= 2 || (g_wide == 1 && big)))) return 0;
+  if (!(x3_wants_256(d) && d->kernel != 3)) return 0;
   return cips_gemm_bf16x3_v3_accepts(d) == 0 ? 1 : 0;
 }
 
@@ -859,10 +840,11 @@ extern "C" int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t str
     return (int)hipErrorInvalidValue;
   if (d->P_hi || d->T_hi || d->mask || d->add || d->addp_hi || d->rgb_g || d->C_unmasked || d->mask_out || d->res_hi || d->act)
     return (int)hipErrorNotSupported;            // the K-major form has the plain fp32 epilogue only
-  // square-ish outputs filling the chip with 256x256 tiles: the wide kernel (a single problem is a group of one)
-  if (g_wide < 0) { const char* e = getenv("CIPS_X3_WIDE"); g_wide = e ? atoi(e) : 1; }
-  if (g_wide >= 1 && d->M >= 256 && d->N >= 256 &&
-      ((long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 192 || g_wide >= 2)) {
+  // square-ish outputs filling the chip with 256x256 tiles: the wide kernel (a single problem is a group of one);
+  // descriptor field `kernel`: 1 never, 2 / 3 whenever the shape allows
+  if (d->kernel < 0 || d->kernel > 3) return (int)hipErrorInvalidValue;
+  if (d->kernel != 1 && d->M >= 256 && d->N >= 256 &&
+      ((long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 192 || d->kernel >= 2)) {
     const int rc = cips_gemm_bf16x3_km_grouped(d, 1, stream);
     if (rc != (int)hipErrorNotSupported) return rc;
   }

@@ -470,12 +470,6 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_km_v3_kernel(KArgs g) {
   }
 }
 
-// CIPS_X3_KMV3=0 keeps the round-2 schedule
-bool km_v3_on() {                      // read per call: scripts/bench_km.py and the tests flip it inside one process
-  const char* e = getenv("CIPS_X3_KMV3");
-  return !(e && atoi(e) == 0);
-}
-
 }  // namespace
 
 // Grouped entry: descs[0..ngroups) must agree in M, N, K, batch, leading dimensions and strides; only the operand
@@ -518,7 +512,7 @@ extern "C" int cips_gemm_bf16x3_km_grouped(const cips_gemm_x3_desc* descs, int n
     (void)hipFuncSetAttribute((const void*)gemm_bf16x3_km_v3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
   }
   const int grid = g.total < ncu ? g.total : ncu;
-  if (km_v3_on() && d->K >= 2 * BK)
+  if (d->K >= 2 * BK)                         // else: the one-k-tile form
     hipLaunchKernelGGL(gemm_bf16x3_km_v3_kernel<false>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
   else
     hipLaunchKernelGGL(gemm_bf16x3_km_wide_kernel<false>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
@@ -562,7 +556,7 @@ extern "C" int cips_conv2d_x3_wgrad(const cips_conv_wgrad_desc* c, cips_stream_t
     (void)hipFuncSetAttribute((const void*)gemm_bf16x3_km_v3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
   }
   const int grid = g.total < ncu ? g.total : ncu;
-  if (km_v3_on() && g.cv.ktiles / g.cv.nchunks >= 2)          // every chunk has at least two k-tiles
+  if (g.cv.ktiles / g.cv.nchunks >= 2)          // every chunk has at least two k-tiles (else: the one-k-tile form)
     hipLaunchKernelGGL(gemm_bf16x3_km_v3_kernel<true>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
   else
     hipLaunchKernelGGL(gemm_bf16x3_km_wide_kernel<true>, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);

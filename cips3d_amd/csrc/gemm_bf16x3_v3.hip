@@ -23,7 +23,6 @@
 // K a multiple of 64, no transposed planes, gate planes as bit planes, 16-byte aligned rows of every tensor.
 #include "common.h"
 #include "../../include/cips3d_hip.h"
-#include <stdlib.h>
 #include <utility>
 
 namespace {
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
     else dma(sr.Blo + k0, sr.offB[pp], la + OFF_BLO);
   };
 
-  if (g.skew > 0) {
+  if (CIPS_TUNE(g.skew) > 0) {
     const int ph = (int)(blockIdx.x & 7) % (g.phases > 0 ? g.phases : 1);
     const long long t0 = __builtin_readcyclecounter();
     while (__builtin_readcyclecounter() - t0 < (long long)ph * g.skew) __builtin_amdgcn_s_sleep(32);
@@ -501,8 +500,10 @@ static void launch_v3(const VArgs& g, int grid, hipStream_t stream) {
   if constexpr (A && Mk && !R) {
     if (d.addp_hi) { launch_v3f<A, Mk, R, true, false, false, true>(g, grid, stream); return; }   // likewise
   }
-  if (fast && g.dbg) launch_v3f<A, Mk, R, true, true>(g, grid, stream);
-  else if (fast) launch_v3f<A, Mk, R, true>(g, grid, stream);
+#ifdef CIPS_TUNING
+  if (fast && g.dbg) { launch_v3f<A, Mk, R, true, true>(g, grid, stream); return; }
+#endif
+  if (fast) launch_v3f<A, Mk, R, true>(g, grid, stream);
   else launch_v3f<A, Mk, R, false>(g, grid, stream);
 }
 
@@ -530,11 +531,11 @@ static int v3_accepts(const cips_gemm_x3_desc* d) {
   }
   return 0;
 }
-extern "C" int cips_gemm_bf16x3_v3_accepts(const cips_gemm_x3_desc* d) { return v3_accepts(d); }
+extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_v3_accepts(const cips_gemm_x3_desc* d) { return v3_accepts(d); }
 
 // Internal entry (called by cips_gemm_bf16x3 ahead of the wide kernel): same descriptor.  hipErrorNotSupported for
 // every shape / epilogue it has no code for.
-extern "C" int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t stream) {
+extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t stream) {
   { const int rc = v3_accepts(d); if (rc) return rc; }
   const bool a = d->add != nullptr || d->addp_hi != nullptr, m = d->mask != nullptr, r = d->res_hi != nullptr;
   VArgs g = {};
@@ -553,14 +554,16 @@ extern "C" int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t str
     ncu = (ncu / 8) * 8;
   }
   int grid = g.total < ncu ? g.total : ncu;
+#ifdef CIPS_TUNING
   {
-    // tuning aids, read on every call (cheap): see VArgs
-    const char* e = getenv("CIPS_X3_V3DBG"); g.dbg = e ? atoi(e) : 0;
-    e = getenv("CIPS_X3_V3SKEW"); g.skew = e ? atoi(e) : 0;
-    e = getenv("CIPS_X3_V3PHASES"); g.phases = e ? atoi(e) : 2;
-    e = getenv("CIPS_X3_V3GRID");
-    if (e && atoi(e) > 0 && atoi(e) < grid) grid = (atoi(e) / 8) * 8 > 0 ? (atoi(e) / 8) * 8 : grid;
+    // tuning aids (probe builds only), read on every call: see VArgs
+    g.dbg = cips_tune_env("CIPS_X3_V3DBG", 0);
+    g.skew = cips_tune_env("CIPS_X3_V3SKEW", 0);
+    g.phases = cips_tune_env("CIPS_X3_V3PHASES", 2);
+    const int eg = cips_tune_env("CIPS_X3_V3GRID", 0);
+    if (eg > 0 && eg < grid) grid = (eg / 8) * 8 > 0 ? (eg / 8) * 8 : grid;
   }
+#endif
   hipStream_t st = (hipStream_t)stream;
   if (a) launch_v3<true, true, false>(g, grid, st);
   else if (m) launch_v3<false, true, false>(g, grid, st);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = uw, wm = wave >> 1, wn = wave & 1;       // 4 x 2 waves
   const int M = d.M, N = d.N, K = d.K;
-  const int nk_all = (g.dbg & 4) ? 0 : K / BK;
+  const int nk_all = CIPS_TUNE(g.dbg & 4) ? 0 : K / BK;
   const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
   const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
 #define LDS_B128(a) (*((__attribute__((address_space(3))) const bf16x8*)(uintptr_t)(a)))
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
 
     // ---------------- main loop: two stages, DMA of k-tile kt+1 in flight under the MFMAs of k-tile kt
     Pre pre[2];
-    if (nk > 0 && !first_issued && !(g.dbg & 2)) {
+    if (nk > 0 && !first_issued && !CIPS_TUNE(g.dbg & 2)) {
       const int kb0 = prep_b(src, 0);
 #pragma unroll
       for (int pc = 0; pc < 8; ++pc) dma_piece(src, pc, 0, kb0, smem);
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
       __builtin_amdgcn_s_barrier();              // k-tile kt has landed everywhere; stage (kt+1)&1 is free again
       const bool more = kt + 1 < nk;
       if (!more) prefetch(0, pre[0]);            // last k-tile: the first sub-tile's epilogue inputs ride under its MFMAs
-      if (!(g.dbg & 1)) compute(kt & 1, more && !(g.dbg & 2), (kt + 1) & 1, (kt + 1) * BK);
-      else if (more && !(g.dbg & 2)) {
+      if (!CIPS_TUNE(g.dbg & 1)) compute(kt & 1, more && !CIPS_TUNE(g.dbg & 2), (kt + 1) & 1, (kt + 1) * BK);
+      else if (more && !CIPS_TUNE(g.dbg & 2)) {
         const int kb1 = prep_b(src, (kt + 1) * BK);
 #pragma unroll
         for (int pc = 0; pc < 8; ++pc) dma_piece(src, pc, (kt + 1) * BK, kb1, smem + ((kt + 1) & 1) * STAGE);
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_wide_kernel(WArgs g) {
 
     // ---------------- the next output tile's first k-tile streams into stage 0 while this tile's epilogue runs
     first_issued = false;
-    if (nk > 0 && (nk & 1) == 0 && tseq + (int)gridDim.x < g.total && !(g.dbg & 2)) {
+    if (nk > 0 && (nk & 1) == 0 && tseq + (int)gridDim.x < g.total && !CIPS_TUNE(g.dbg & 2)) {
       int tm2, tn2, bz2, kc2;
       decode(tseq + gridDim.x, tm2, tn2, bz2, kc2);
       Src nsrc;
@@ -752,8 +752,7 @@ extern "C" int cips_conv2d_x3(const cips_conv_x3_desc* c, cips_stream_t stream) 
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
   g.dbg = 0;
-  bool v3 = (K / 32) / ks >= 2;                 // every chunk has at least two k-tiles
-  { const char* e = getenv("CIPS_X3_CONVV3"); if (e && atoi(e) == 0) v3 = false; }      // read per call (A/B inside one process)
+  const bool v3 = (K / 32) / ks >= 2;           // every chunk has at least two k-tiles (else: the one-k-tile form of the wide kernel)
   if (v3) {
     static bool attr = false;
     CIPS_PER_DEVICE(attr, false);
@@ -787,7 +786,7 @@ extern "C" int cips_conv2d_x3_ksplit(int B, int O, int N, int K) {
   return best;
 }
 
-extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream) {
+extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
   if ((d->K & 31) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7)) return (int)hipErrorInvalidValue;
   if (d->T_hi || (d->N & 7) || (d->ldc & 3) || (d->strideC & 3) || (d->ldp & 7) || (d->strideP & 7)) return (int)hipErrorNotSupported;
@@ -802,16 +801,18 @@ extern "C" int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t s
   long long total = (long long)g.tiles_m * g.tiles_n * d->batch;
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   g.total = (int)total;
-  static int ncu = 0, gdbg = 0;
+  static int ncu = 0;
   CIPS_PER_DEVICE(ncu, 0);
   if (!ncu) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     if (ncu <= 0) ncu = 256;
     ncu = (ncu / 8) * 8;
-    const char* e = getenv("CIPS_X3_GDBG"); gdbg = e ? atoi(e) : 0;
   }
-  g.dbg = gdbg;
+  g.dbg = 0;
+#ifdef CIPS_TUNING
+  g.dbg = cips_tune_env("CIPS_X3_GDBG", 0);
+#endif
   const int grid = g.total < ncu ? g.total : ncu;
   hipStream_t st = (hipStream_t)stream;
   if (a) launch_wide<true, true, false>(g, grid, st);

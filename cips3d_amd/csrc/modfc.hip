@@ -1002,16 +1002,13 @@ extern "C" int cips_modfc_prep_x3_batch(const cips_modfc_prep_job* jobs, int njo
     wide = wide && (jobs[i].out_dim % 4 == 0) && (jobs[i].in_dim % 8 == 0);
     vec4 = vec4 && (jobs[i].out_dim % 4 == 0);
   }
-  static int planes64 = -1, fused = -1;
-  if (planes64 < 0) { const char* e = getenv("CIPS_MODFC_PLANES64"); planes64 = (e && atoi(e) == 0) ? 0 : 1; }
-  if (fused < 0) { const char* e = getenv("CIPS_MODFC_VEC4"); fused = (e && atoi(e) == 0) ? 0 : 1; }
-  if (vec4 && fused) {
+  if (vec4) {
     ColJobs Cj = {};
     for (int i = 0; i < njobs; ++i) { Cj.W[i] = J.W[i]; Cj.s[i] = J.s[i]; Cj.out[i] = J.demod[i]; Cj.in_dim[i] = J.in_dim[i]; Cj.out_dim[i] = J.out_dim[i]; }
     hipLaunchKernelGGL(modfc_colsum4_batch_kernel<false>, dim3((max_out + 63) / 64, B, njobs), dim3(256), 0, st, Cj, B, eps);
   } else
     hipLaunchKernelGGL(modfc_demod_batch_kernel, dim3((max_out + 31) / 32, B, njobs), dim3(256), 0, st, J, B, eps);
-  if (wide && planes64)
+  if (wide)
     hipLaunchKernelGGL(modfc_planes_batch64_kernel, dim3((max_out + 63) / 64, (max_in + 63) / 64, B * njobs), dim3(256), 0, st, J, B);
   else
     hipLaunchKernelGGL(modfc_planes_batch_kernel, dim3((max_out + 31) / 32, (max_in + 31) / 32, B * njobs), dim3(256), 0, st, J, B);
@@ -1036,9 +1033,7 @@ extern "C" int cips_modfc_prep_bwd_batch(const cips_modfc_bwd_job* jobs, int njo
   hipStream_t st = (hipStream_t)stream;
   bool vec4 = B <= 64 && max_out <= 1024;        // two reads of G instead of three (see modfc_prep_bwd_ws_batch_kernel)
   for (int i = 0; i < njobs; ++i) vec4 = vec4 && (jobs[i].out_dim % 4 == 0);
-  static int fused = -1;
-  if (fused < 0) { const char* e = getenv("CIPS_MODFC_VEC4"); fused = (e && atoi(e) == 0) ? 0 : 1; }
-  if (vec4 && fused) {
+  if (vec4) {
     ColJobs Cj = {};
     for (int i = 0; i < njobs; ++i) { Cj.W[i] = J.W[i]; Cj.s[i] = J.s[i]; Cj.G[i] = J.G[i]; Cj.out[i] = J.cbuf[i]; Cj.in_dim[i] = J.in_dim[i]; Cj.out_dim[i] = J.out_dim[i]; }
     hipLaunchKernelGGL(modfc_colsum4_batch_kernel<true>, dim3((max_out + 63) / 64, B, njobs), dim3(256), 0, st, Cj, B, 0.f);

@@ -180,7 +180,8 @@ struct CompArgs {
   float *dfeat_c, *dsig_c, *dfeat_f, *dsig_f;
   long long R;
   int S, E, clamp_mode, flags;
-  // debug hook (cips_debug_clamp): the relu clamp's branch per (ray, sorted position), supplied / recorded
+  // optional branch masks of the relu clamp per (ray, sorted position), see cips_composite_fwd in cips3d_hip.h:
+  // clamp_pin supplies the branch (0 = clamped), clamp_rec receives the branch taken; both NULL in production
   const unsigned char* clamp_pin;
   unsigned char* clamp_rec;
 };
@@ -405,19 +406,6 @@ inline int rays_per_block_for(size_t bytes_per_ray) {
 
 }  // namespace
 
-// Debug hook (tests): while set, every composite / fused-march launch takes the relu clamp's branch of sample (ray, sorted
-// position k) from pin[ray*E + k] (0 = clamped) and/or writes the branch it took to rec[ray*E + k].  Process-global and not
-// thread-safe by design: set, launch, reset (cips3d_amd.ops.clamp_debug does exactly that).
-namespace cips_dbg {
-const unsigned char* clamp_pin = nullptr;
-unsigned char* clamp_rec = nullptr;
-}
-extern "C" int cips_debug_clamp(const unsigned char* pin, unsigned char* rec) {
-  cips_dbg::clamp_pin = pin;
-  cips_dbg::clamp_rec = rec;
-  return 0;
-}
-
 extern "C" int cips_rays_fwd(const float* xg, const float* yg, const float* zg, float zc,
                              const float* cam2world, const float* jitter, float* points, float* z,
                              float* dirs, int B, int H, int W, int S, cips_stream_t stream) {
@@ -454,14 +442,15 @@ extern "C" int cips_composite_fwd(const float* feat_c, const float* sig_c, const
                                   const float* feat_f, const float* sig_f, const float* z_f,
                                   const float* noise, float noise_std, float* fea, float* depth,
                                   float* weights, int* order, float* zsorted, int R, int S,
-                                  int clamp_mode, int flags, cips_stream_t stream) {
+                                  int clamp_mode, int flags, const unsigned char* clamp_in, unsigned char* clamp_out,
+                                  cips_stream_t stream) {
   if (R <= 0 || S <= 0) return (int)hipErrorInvalidValue;
   CompArgs a = {};
   a.feat_c = feat_c; a.sig_c = sig_c; a.z_c = z_c; a.feat_f = feat_f; a.sig_f = sig_f; a.z_f = z_f;
   a.noise = noise; a.noise_std = noise_std; a.fea = fea; a.depth = depth; a.weights = weights;
   a.order = order; a.zsorted = zsorted; a.R = R; a.S = S; a.E = feat_f ? 2 * S : S;
   a.clamp_mode = clamp_mode; a.flags = flags;
-  a.clamp_pin = cips_dbg::clamp_pin; a.clamp_rec = cips_dbg::clamp_rec;
+  a.clamp_pin = clamp_in; a.clamp_rec = clamp_out;
   size_t per_ray = (size_t)4 * a.E * sizeof(float);
   int rpb = rays_per_block_for(per_ray);
   int blocks = (R + rpb - 1) / rpb;
@@ -473,14 +462,14 @@ extern "C" int cips_composite_bwd(const float* feat_c, const float* sig_c, const
                                   const float* feat_f, const float* sig_f, const float* z_f,
                                   const float* noise, float noise_std, const int* order, const float* dfea,
                                   float* dfeat_c, float* dsig_c, float* dfeat_f, float* dsig_f, int R, int S,
-                                  int clamp_mode, int flags, cips_stream_t stream) {
+                                  int clamp_mode, int flags, const unsigned char* clamp_in, cips_stream_t stream) {
   if (R <= 0 || S <= 0 || (!order && feat_f)) return (int)hipErrorInvalidValue;
   CompArgs a = {};
   a.feat_c = feat_c; a.sig_c = sig_c; a.z_c = z_c; a.feat_f = feat_f; a.sig_f = sig_f; a.z_f = z_f;
   a.noise = noise; a.noise_std = noise_std; a.order_in = order; a.dfea = dfea;
   a.dfeat_c = dfeat_c; a.dsig_c = dsig_c; a.dfeat_f = dfeat_f; a.dsig_f = dsig_f;
   a.R = R; a.S = S; a.E = feat_f ? 2 * S : S; a.clamp_mode = clamp_mode; a.flags = flags;
-  a.clamp_pin = cips_dbg::clamp_pin; a.clamp_rec = nullptr;
+  a.clamp_pin = clamp_in; a.clamp_rec = nullptr;
   size_t per_ray = (size_t)6 * a.E * sizeof(float);
   int rpb = rays_per_block_for(per_ray);
   int blocks = (R + rpb - 1) / rpb;

@@ -35,13 +35,7 @@
 #include "common.h"
 #include "../../include/cips3d_hip.h"
 #include "raygen.h"
-#include <cstdlib>
 #include <type_traits>
-
-namespace cips_dbg {          // debug hook of the relu clamp (cips_debug_clamp, render.hip)
-extern const unsigned char* clamp_pin;
-extern unsigned char* clamp_rec;
-}
 
 namespace {
 
@@ -91,7 +85,14 @@ __device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned
   f32x2 v = {a, b};
   f16x2 h = __builtin_convertvector(v, f16x2);
   hi = __builtin_bit_cast(unsigned, h);
-  f32x2 r = v - __builtin_convertvector(h, f32x2);
+  // residual x - hi in ONE instruction per element: v_fma_mix_f32 reads the fp16 half in place (op_sel picks the half,
+  // op_sel_hi marks source 0 as fp16) — hipcc's own code is v_cvt_f32_f16 x2 + v_pk_add_f32 (5 instead of 4 per pair, and
+  // a packed-f32 op between MFMAs costs more than its slot, MI355X_MICROARCH.md); it has no builtin and folds
+  // fma(-1, fpext(h), x) back into the subtraction.  Plain VALU -> VALU dependencies: no wait states to pad.
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(a));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(b));
+  f32x2 r = {r0, r1};
   f16x2 l = __builtin_convertvector(r, f16x2);
   lo = __builtin_bit_cast(unsigned, l);
 }
@@ -411,7 +412,7 @@ struct BwdX3Args {
   float* gpart;   // [B*chunks][GPART]
   int B, P, chunk, chunks;
   unsigned long long* prof;
-  int dbg;        // timing attribution only (env CIPS_X3_DBG): bit0/1/2 skip the dWf / dWc / dW1 phases
+  int dbg;        // timing attribution, probe builds only (-DCIPS_TUNING, env CIPS_X3_DBG): bit0/1/2 skip the dWf / dWc / dW1 phases
   RayGen rg;      // points == NULL: the points are generated from the ray parameters (point index = ray * S + s)
 };
 constexpr int GP_G1 = 0, GP_GC = H * H, GP_GF0 = GP_GC + HC * H, GP_GF1 = GP_GF0 + CF * HC, GPART = GP_GF1 + CF * HC;
@@ -528,425 +529,18 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
   if (F16 && tid == 0) *reinterpret_cast<float*>(sm + O_AUX + 128) = isf;
 }
 
-// phase timestamps for tuning (host passes a buffer only when CIPS_X3_PROF is set): workgroup (0,0), lane 0 of
-// each wave, first 8 rounds, s_memtime at each phase boundary
+// phase timestamps for tuning (probe builds, -DCIPS_TUNING, with CIPS_X3_PROF set): workgroup (0,0), lane 0 of each wave,
+// first 8 rounds, s_memtime at each phase boundary.  The production build keeps the sched_barrier: it is part of the
+// hand-pinned instruction order the kernel was tuned with.
+#ifdef CIPS_TUNING
 #define X3_TS(i)                                                                                   \
   __builtin_amdgcn_sched_barrier(0);                                                               \
   if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && lane0 == 0 && rnd < 8)                       \
     a.prof[(rnd * 4 + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime();                            \
   __builtin_amdgcn_sched_barrier(0);
-
-template <bool HW>
-__global__ __launch_bounds__(256, 1) void siren_bwd_x3_kernel(BwdX3Args a) {
-  extern __shared__ __attribute__((aligned(1024))) uchar smem[];
-  const int b = blockIdx.y;
-  stage_weights_x3(smem, a.w, b);
-  __syncthreads();
-
-  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int cstart = blockIdx.x * a.chunk;
-  const int cend = min(cstart + a.chunk, a.P);
-  const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uchar*)smem);
-
-  // weight-gradient accumulators, owned per wave for the whole chunk; aS: column sums (see SRED)
-  f32x16 aG1[4], aGc[2], aGf[1], aS[1];
-  zero_acc(aG1); zero_acc(aGc); zero_acc(aGf); zero_acc(aS);
-  float r_dsg = 0.f;
-
-  // inputs of the first round
-  float px, py, pz, dsg;
-  {
-    const int p = cstart + wave * 32 + (lane0 & 31);
-    const bool valid = p < cend;
-    const long long gp = (long long)b * a.P + (valid ? p : cend - 1);
-    if (a.points) { px = a.points[gp * 3 + 0]; py = a.points[gp * 3 + 1]; pz = a.points[gp * 3 + 2]; }
-    else gen_point(a.rg, b, valid ? p : cend - 1, px, py, pz);
-    dsg = valid ? a.dsigma[gp] : 0.f;
-  }
-
-  int rnd = -1;
-  for (int pbase = cstart; pbase < cend; pbase += 128) {
-    ++rnd;
-    X3_TS(0)
-    // every LDS address below is loop-invariant; laundering the lane id keeps hipcc from hoisting a few hundred
-    // of them out of the loop into live registers
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int l31 = lane & 31, hf = lane >> 5;
-    const LaneAddr LA = lane_addr(lane, sbase);
-    const int prow = wave * 32 + l31;
-    const unsigned c7 = l31 & 7;
-    const unsigned m_d1 = c7 < 4 ? ~0u : 0u, m_d2 = c7 == 4 ? ~0u : 0u, m_h2 = c7 == 5 ? ~0u : 0u;
-    const unsigned m_dc = c7 == 6 ? ~0u : 0u, m_df = c7 == 7 ? ~0u : 0u;
-
-    // ---- upstream gradient of the 32 colour features: requested now, consumed after two layers ----
-    float4 df4[4];
-    {
-      const int p = pbase + prow;
-      const bool valid = p < cend;
-      const float* dp = a.dfeat + ((long long)b * a.P + (valid ? p : cend - 1)) * CF + 4 * hf;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) df4[g] = valid ? ld4(dp + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // ---- aux row of this point: [1, x, y, z, 1, dsigma, 1, 1] ----
-    if (hf == 0) {
-      uint4 ah, al;
-      split2(1.f, px, ah.x, al.x); split2(py, pz, ah.y, al.y); split2(1.f, dsg, ah.z, al.z); split2(1.f, 1.f, ah.w, al.w);
-      const u32x4 vh = {ah.x, ah.y, ah.z, ah.w}, vl = {al.x, al.y, al.z, al.w};
-      *LDS_PTR(u32x4, sbase + O_AUX + prow * 16) = vh;
-      *LDS_PTR(u32x4, sbase + O_AUX + 2048 + prow * 16) = vl;
-      r_dsg += dsg;
-    }
-
-    // ---- layer 0 (VALU); only the packed sines are kept, and only until layer 1 has consumed them ----
-    f32x16 acc[4];
-    zero_acc(acc);
-    {
-      Act<4> h1p;
-      float4 pn[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 16 * e);
-#pragma unroll
-      for (int grp = 0; grp < 16; ++grp) {          // grp = 4q + g: features 32q + 8g + 4hf + {0..3}
-        float4 pk[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = pn[e];
-        if (grp + 1 < 16) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 128 * (grp + 1) + 16 * e);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float sn[4], cs;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          bsincos<HW>(fmaf(pk[e].x, px, fmaf(pk[e].y, py, fmaf(pk[e].z, pz, pk[e].w))), &sn[e], &cs);
-        const int q = grp >> 2, g = grp & 3;
-        split2(sn[0], sn[1], h1p.hi[q][2 * g], h1p.lo[q][2 * g]);
-        split2(sn[2], sn[3], h1p.hi[q][2 * g + 1], h1p.lo[q][2 * g + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---- recompute layer 1 ----
-      layer_fwd<4, 4, H, O_W1H, O_W1L - O_W1H>(LA, h1p, acc);
-    }
-    X3_TS(1)
-    float cs2[4][16];
-    Act<4> h2p;
-    {
-      float4 gn = lds_ld4(LA.v16 + (O_G1 - O_L0)), cn = lds_ld4(LA.v16 + (O_C1 - O_L0));
-#pragma unroll
-      for (int grp = 0; grp < 16; ++grp) {
-        const float4 g4 = gn, c4 = cn;
-        if (grp + 1 < 16) { gn = lds_ld4(LA.v16 + (O_G1 - O_L0) + 32 * (grp + 1)); cn = lds_ld4(LA.v16 + (O_C1 - O_L0) + 32 * (grp + 1)); }
-        __builtin_amdgcn_sched_barrier(0);
-        const int q = grp >> 2, g = grp & 3;
-        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
-        float sn[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bsincos<HW>(fmaf(gg[e], acc[q][4 * g + e], cc[e]), &sn[e], &cs2[q][4 * g + e]);
-        split2(sn[0], sn[1], h2p.hi[q][2 * g], h2p.lo[q][2 * g]);
-        split2(sn[2], sn[3], h2p.hi[q][2 * g + 1], h2p.lo[q][2 * g + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-
-    X3_TS(2)
-    // ---- recompute colour sine layer ----
-    f32x16 accc[2];
-    zero_acc(accc);
-    layer_fwd<2, 4, HC, O_WCH, O_WCL - O_WCH>(LA, h2p, accc);
-    float csc[2][16];
-    Act<2> hcp;
-    {
-      float4 gn = lds_ld4(LA.v16 + (O_GC - O_L0)), cn = lds_ld4(LA.v16 + (O_CC - O_L0));
-#pragma unroll
-      for (int grp = 0; grp < 8; ++grp) {
-        const float4 g4 = gn, c4 = cn;
-        if (grp + 1 < 8) { gn = lds_ld4(LA.v16 + (O_GC - O_L0) + 32 * (grp + 1)); cn = lds_ld4(LA.v16 + (O_CC - O_L0) + 32 * (grp + 1)); }
-        __builtin_amdgcn_sched_barrier(0);
-        const int q = grp >> 2, g = grp & 3;
-        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
-        float sn[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bsincos<HW>(fmaf(gg[e], accc[q][4 * g + e], cc[e]), &sn[e], &csc[q][4 * g + e]);
-        split2(sn[0], sn[1], hcp.hi[q][2 * g], hcp.lo[q][2 * g]);
-        split2(sn[2], sn[3], hcp.hi[q][2 * g + 1], hcp.lo[q][2 * g + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-
-    X3_TS(3)
-    Act<1> dfp;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      split2(df4[g].x, df4[g].y, dfp.hi[0][2 * g], dfp.lo[0][2 * g]);
-      split2(df4[g].z, df4[g].w, dfp.hi[0][2 * g + 1], dfp.lo[0][2 * g + 1]);
-    }
-
-    // ---- dWf += dfeat^T hc over the workgroup's 128 points: wave -> (hc column tile w&1, point half w>>1);
-    //      waves 0 and 2 also take sum_p dfeat (aux column 7) ----
-    if (!(a.dbg & 1)) {
-      constexpr int DFH = 0, DFL = 8192, HCH = 16384, HCL = 32768;
-      stage<1, 128, DFH, DFL>(sbase, prow, hf, dfp);
-      stage<2, 128, HCH, HCL>(sbase, prow, hf, hcp);
-      __syncthreads();
-      const int jt = wave & 1, kh = wave >> 1;
-      const unsigned mdf = jt == 0 ? m_df : 0u;          // waves 1 and 3 add zeros: no wave-dependent branches here
-      Frag fa[2], fb[2], fx[2];
-      // this wave's k-steps (4kh + k) and hc column block are folded into the lane bases
-      const unsigned d0 = opaque(LA.sb[0] + kh * 4096), d1 = opaque(LA.sb[1] + kh * 4096);      // dfeat: k-steps 4kh..
-      const unsigned h0 = opaque(d0 + jt * 8192), h1_ = opaque(d1 + jt * 8192);                  // hc: same k-steps, column block jt
-      const unsigned ax = opaque(LA.ab + kh * 1024);
-      stg_frag<128, DFH, DFL>(d0, d1, 0, 0, fa[0]);
-      stg_frag<128, HCH, HCL>(h0, h1_, 0, 0, fb[0]);
-      aux_frag(ax, 0, mdf, fx[0]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (k + 1 < 4) {
-          stg_frag<128, DFH, DFL>(d0, d1, 0, k + 1, fa[(k + 1) & 1]);
-          stg_frag<128, HCH, HCL>(h0, h1_, 0, k + 1, fb[(k + 1) & 1]);
-          aux_frag(ax, k + 1, mdf, fx[(k + 1) & 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        aGf[0] = x3f(aGf[0], fa[k & 1], fb[k & 1]);
-        aS[0] = x2f(aS[0], fa[k & 1], fx[k & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();
-    }
-
-    X3_TS(4)
-    // ---- d hc = Wf^T dfeat  (K = 32, M = 64);  dac = d hc * cos;  dpc = gc * dac ----
-    zero_acc(accc);
-    layer_tr<2, 2, CF, O_WFH, O_WFL - O_WFH>(LA, dfp, accc);
-    Act<2> dacp, dpcp;
-    {
-      float4 gn = lds_ld4(LA.v16 + (O_GC - O_L0));
-#pragma unroll
-      for (int grp = 0; grp < 8; ++grp) {
-        const float4 g4 = gn;
-        if (grp + 1 < 8) gn = lds_ld4(LA.v16 + (O_GC - O_L0) + 32 * (grp + 1));
-        __builtin_amdgcn_sched_barrier(0);
-        const int q = grp >> 2, g = grp & 3;
-        const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
-        float v[4], w_[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = accc[q][4 * g + e] * csc[q][4 * g + e]; w_[e] = gg[e] * v[e]; }
-        split2(v[0], v[1], dacp.hi[q][2 * g], dacp.lo[q][2 * g]);
-        split2(v[2], v[3], dacp.hi[q][2 * g + 1], dacp.lo[q][2 * g + 1]);
-        split2(w_[0], w_[1], dpcp.hi[q][2 * g], dpcp.lo[q][2 * g]);
-        split2(w_[2], w_[3], dpcp.hi[q][2 * g + 1], dpcp.lo[q][2 * g + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-
-    pin(dacp); pin(h2p);
-    X3_TS(5)
-    // ---- dWc += dac^T h2: two sub-phases of 64 points; wave -> (dac row tile w&1, h2 column tiles 2(w>>1)+{0,1});
-    //      plus sum_p dsigma*h2 (h2 row tile w, aux column 5) and, on waves 0 and 1, sum_p dac (aux column 6).
-    //      Fragment reads run half a k-step ahead of their MFMAs. ----
-    if (!(a.dbg & 2)) {
-      constexpr int DAH = 0, DAL = 8192, H2H = 16384, H2L = 32768;
-      const int it = wave & 1, jt0 = 2 * (wave >> 1);
-      const unsigned mdc = wave < 2 ? m_dc : 0u;         // waves 2 and 3 add zeros: no wave-dependent branches here
-      // wave-dependent column blocks folded into the lane bases (block stride of a 64-row image: 4096 B)
-      const unsigned i0 = opaque(LA.sb[0] + it * 4096), i1 = opaque(LA.sb[1] + it * 4096);
-      const unsigned j0 = opaque(LA.sb[0] + jt0 * 4096), j1 = opaque(LA.sb[1] + jt0 * 4096);
-      const unsigned w0 = opaque(LA.sb[0] + wave * 4096), w1 = opaque(LA.sb[1] + wave * 4096);
-#pragma unroll
-      for (int sp = 0; sp < 2; ++sp) {
-        if ((wave >> 1) == sp) {
-          stage<2, 64, DAH, DAL>(sbase, (wave & 1) * 32 + l31, hf, dacp);
-          stage<4, 64, H2H, H2L>(sbase, (wave & 1) * 32 + l31, hf, h2p);
-        }
-        __syncthreads();
-        Frag fa, fb0, fb1, fh, fx, fy;
-        stg_frag<64, DAH, DAL>(i0, i1, 0, 0, fa);
-        stg_frag<64, H2H, H2L>(j0, j1, 0, 0, fb0);
-        stg_frag<64, H2H, H2L>(j0, j1, 32, 0, fb1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          stg_frag<64, H2H, H2L>(w0, w1, 0, k, fh);
-          aux_frag(LA.ab, 4 * sp + k, m_h2, fx);
-          aux_frag(LA.ab, 4 * sp + k, mdc, fy);
-          __builtin_amdgcn_sched_barrier(0);
-          aGc[0] = x3f(aGc[0], fa, fb0);
-          aGc[1] = x3f(aGc[1], fa, fb1);
-          aS[0] = x2f(aS[0], fa, fy);
-          __builtin_amdgcn_sched_barrier(0);
-          if (k + 1 < 4) {
-            stg_frag<64, DAH, DAL>(i0, i1, 0, k + 1, fa);
-            stg_frag<64, H2H, H2L>(j0, j1, 0, k + 1, fb0);
-            stg_frag<64, H2H, H2L>(j0, j1, 32, k + 1, fb1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          aS[0] = x3f(aS[0], fh, fx);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-      }
-    }
-
-    X3_TS(6)
-    // ---- d h2 = Wc^T dpc + ws * dsigma  (K = 64, M = 128);  da2 = d h2 * cos;  dp2 = g1 * da2 ----
-    zero_acc(acc);
-    layer_tr<4, 4, HC, O_WCH, O_WCL - O_WCH>(LA, dpcp, acc);
-    Act<4> da2p;
-    {
-      Act<4> dp2p;
-      float4 gn = lds_ld4(LA.v16 + (O_G1 - O_L0)), wn = lds_ld4(LA.v16 + (O_WS - O_L0));
-#pragma unroll
-      for (int grp = 0; grp < 16; ++grp) {
-        const float4 g4 = gn, w4 = wn;
-        if (grp + 1 < 16) { gn = lds_ld4(LA.v16 + (O_G1 - O_L0) + 32 * (grp + 1)); wn = lds_ld4(LA.v16 + (O_WS - O_L0) + 32 * (grp + 1)); }
-        __builtin_amdgcn_sched_barrier(0);
-        const int q = grp >> 2, g = grp & 3;
-        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
-        float v[4], w_[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = fmaf(ww[e], dsg, acc[q][4 * g + e]) * cs2[q][4 * g + e];
-          w_[e] = gg[e] * v[e];
-        }
-        split2(v[0], v[1], da2p.hi[q][2 * g], da2p.lo[q][2 * g]);
-        split2(v[2], v[3], da2p.hi[q][2 * g + 1], da2p.lo[q][2 * g + 1]);
-        split2(w_[0], w_[1], dp2p.hi[q][2 * g], dp2p.lo[q][2 * g]);
-        split2(w_[2], w_[3], dp2p.hi[q][2 * g + 1], dp2p.lo[q][2 * g + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---- d h1 = W1^T dp2  (K = 128, M = 128) ----
-      zero_acc(acc);
-      layer_tr<4, 8, H, O_W1H, O_W1L - O_W1H>(LA, dp2p, acc);
-    }
-    X3_TS(7)
-    // ---- da1 = d h1 * cos(layer-0 argument); the layer-0 sines are recomputed alongside for dW1 ----
-    Act<4> h1p, da1p;
-    {
-      float4 pn[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 16 * e);
-#pragma unroll
-      for (int grp = 0; grp < 16; ++grp) {
-        float4 pk[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = pn[e];
-        if (grp + 1 < 16) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pn[e] = lds_ld4(LA.v64 + 128 * (grp + 1) + 16 * e);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const int q = grp >> 2, g = grp & 3;
-        float sn[4], v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float cs;
-          bsincos<HW>(fmaf(pk[e].x, px, fmaf(pk[e].y, py, fmaf(pk[e].z, pz, pk[e].w))), &sn[e], &cs);
-          v[e] = acc[q][4 * g + e] * cs;
-        }
-        split2(sn[0], sn[1], h1p.hi[q][2 * g], h1p.lo[q][2 * g]);
-        split2(sn[2], sn[3], h1p.hi[q][2 * g + 1], h1p.lo[q][2 * g + 1]);
-        split2(v[0], v[1], da1p.hi[q][2 * g], da1p.lo[q][2 * g]);
-        split2(v[2], v[3], da1p.hi[q][2 * g + 1], da1p.lo[q][2 * g + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-
-    pin(da2p); pin(h1p); pin(da1p);
-    X3_TS(8)
-    // ---- inputs of the next round (latency hidden behind the dW1 phase) ----
-    {
-      const int p = pbase + 128 + prow;
-      const bool valid = p < cend;
-      const long long gp = (long long)b * a.P + (valid ? p : cend - 1);
-      if (a.points) { px = a.points[gp * 3 + 0]; py = a.points[gp * 3 + 1]; pz = a.points[gp * 3 + 2]; }
-      else gen_point(a.rg, b, valid ? p : cend - 1, px, py, pz);
-      dsg = valid ? a.dsigma[gp] : 0.f;
-    }
-
-    // ---- dW1 += da2^T h1: four sub-phases of 32 points; wave -> da2 row tile w, all four h1 column tiles;
-    //      plus sum_p da2 (aux column 4) and sum_p da1 * [1, x, y, z] (aux columns 0..3) for row tile w ----
-    if (!(a.dbg & 4)) {
-      constexpr int DAH = 0, DAL = 8192, H1H = 16384, H1L = 24576, D1H = 32768, D1L = 40960;
-      const unsigned w0 = opaque(LA.sb[0] + wave * 2048), w1 = opaque(LA.sb[1] + wave * 2048);   // row tile w
-#pragma unroll 1
-      for (int sp = 0; sp < 4; ++sp) {
-        if (sp == 1) { X3_TS(10) }
-        if (wave == sp) {
-          stage<4, 32, DAH, DAL>(sbase, l31, hf, da2p);
-          stage<4, 32, H1H, H1L>(sbase, l31, hf, h1p);
-          stage<4, 32, D1H, D1L>(sbase, l31, hf, da1p);
-        }
-        if (sp == 1) { X3_TS(11) }
-        __syncthreads();
-        if (sp == 1) { X3_TS(12) }
-        const unsigned ax = opaque(LA.ab + sp * 512);      // aux k-steps 2sp + k
-        Frag fa, fb0, fb1, fb2, fb3, fd, fx, fy;
-        stg_frag<32, DAH, DAL>(w0, w1, 0, 0, fa);
-        stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 0, 0, fb0);
-        stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 32, 0, fb1);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 64, k, fb2);
-          stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 96, k, fb3);
-          aux_frag(ax, k, m_d2, fx);
-          __builtin_amdgcn_sched_barrier(0);
-          aG1[0] = x3f(aG1[0], fa, fb0);
-          aG1[1] = x3f(aG1[1], fa, fb1);
-          __builtin_amdgcn_sched_barrier(0);
-          stg_frag<32, D1H, D1L>(w0, w1, 0, k, fd);
-          aux_frag(ax, k, m_d1, fy);
-          __builtin_amdgcn_sched_barrier(0);
-          aG1[2] = x3f(aG1[2], fa, fb2);
-          aG1[3] = x3f(aG1[3], fa, fb3);
-          aS[0] = x2f(aS[0], fa, fx);
-          __builtin_amdgcn_sched_barrier(0);
-          if (k + 1 < 2) {
-            stg_frag<32, DAH, DAL>(w0, w1, 0, k + 1, fa);
-            stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 0, k + 1, fb0);
-            stg_frag<32, H1H, H1L>(LA.sb[0], LA.sb[1], 32, k + 1, fb1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          aS[0] = x3f(aS[0], fd, fy);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (sp == 1) { X3_TS(13) }
-        __syncthreads();
-        if (sp == 1) { X3_TS(14) }
-      }
-    }
-    X3_TS(9)
-  }
-
-  const int lane = lane0, l31 = lane & 31, hf = lane >> 5;
-  // ---- per-wave column sums and sum of dsigma ----
-  {
-    float* sr = a.sred + (long long)(b * a.chunks + blockIdx.x) * SRED;
-    if (l31 < 8) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sr[wave * 256 + mfma_row(r, hf) * 8 + l31] = aS[0][r];
-    }
-    float t = r_dsg;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
-    if (lane == 0) sr[1024 + wave] = t;
-    if (lane == 1) sr[1028 + wave] = 0.f;
-  }
-  // ---- write the workgroup's partial weight gradients ----
-  {
-    float* gp_ = a.gpart + (long long)(b * a.chunks + blockIdx.x) * GPART;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) gp_[GP_G1 + (32 * wave + mfma_row(r, hf)) * H + 32 * j + l31] = aG1[j][r];
-    const int it = wave & 1, jt0 = 2 * (wave >> 1);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) gp_[GP_GC + (32 * it + mfma_row(r, hf)) * H + 32 * (jt0 + j) + l31] = aGc[j][r];
-    float* gf = gp_ + ((wave >> 1) ? GP_GF1 : GP_GF0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gf[mfma_row(r, hf) * HC + 32 * (wave & 1) + l31] = aGf[0][r];
-  }
-}
+#else
+#define X3_TS(i) __builtin_amdgcn_sched_barrier(0);
+#endif
 
 #include "siren_bwd_x4.inc"
 
@@ -1034,8 +628,8 @@ struct MarchArgs {
   float *weights;            // (B, n, S) or NULL
   float *feat, *sigma, *zout;   // per-sample outputs (B, P, 32), (B, P), (B, P) or NULL
   int B, rays_per_wg;
-  const unsigned char* clamp_pin;   // debug hook (cips_debug_clamp, render.hip): relu branch per (ray, sample) supplied /
-  unsigned char* clamp_rec;         // recorded; both NULL outside tests
+  const unsigned char* clamp_pin;   // optional branch masks of the relu clamp (cips_march_fwd_x3's clamp_in / clamp_out):
+  unsigned char* clamp_rec;         // branch per (ray, sample) supplied / recorded; both NULL in production
 };
 
 
@@ -1277,11 +871,13 @@ extern "C" int cips_siren_bwd_x3_chunks(int B, int P) {
   return (P + chunk - 1) / chunk;
 }
 extern "C" int cips_siren_bwd_x3_gpart(void) { return GPART; }
+#ifdef CIPS_TUNING
 static unsigned long long* g_prof = nullptr;
 extern "C" int cips_siren_bwd_x3_prof(unsigned long long* host_out) {   // tuning aid: copies the 8x4x16 timestamps
   if (!g_prof) return (int)hipErrorNotReady;
   return (int)hipMemcpy(host_out, g_prof, 8 * 4 * 16 * 8, hipMemcpyDeviceToHost);
 }
+#endif
 extern "C" int cips_siren_bwd_x3_sred(void) { return SRED; }
 
 
@@ -1311,48 +907,31 @@ static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points,
   a.B = B; a.P = P;
   a.rg = RayGen{};
   if (!points) { const int rc = fill_raygen(a.rg, rays); if (rc) return rc; }
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("CIPS_X3_DBG"); dbg = e ? atoi(e) : 0; }
-  a.dbg = dbg;
+  a.dbg = 0; a.prof = nullptr;
+#ifdef CIPS_TUNING
+  a.dbg = cips_tune_env("CIPS_X3_DBG", 0);
   static unsigned long long* prof = nullptr;
   static int want_prof = -1;
   if (want_prof < 0) {
-    want_prof = getenv("CIPS_X3_PROF") ? 1 : 0;
+    want_prof = cips_tune_env("CIPS_X3_PROF", 0) ? 1 : 0;
     if (want_prof && hipMalloc(&prof, 8 * 4 * 16 * 8) != hipSuccess) prof = nullptr;
   }
   a.prof = prof; g_prof = prof;
+#endif
   a.chunk = x3_chunk(B, P);
   a.chunks = (P + a.chunk - 1) / a.chunk;
   dim3 grid(a.chunks, B);
-  static bool attr_set = false;
-  CIPS_PER_DEVICE(attr_set, false);
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)siren_bwd_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    hipFuncSetAttribute((const void*)siren_bwd_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    attr_set = true;
+  static bool attr4 = false;
+  CIPS_PER_DEVICE(attr4, false);
+  if (!attr4) {
+    hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr4 = true;
   }
-  // CIPS_SIREN_BWD_V4 (read per call: A/B runs flip it inside one process): the round-4 schedule (m-major layers with the
-  // epilogues woven between the MFMAs, sine arguments in revolutions); 0 = the round-1..3 kernel
-  const char* v4e = getenv("CIPS_SIREN_BWD_V4");
-  const bool v4 = !(v4e && v4e[0] == '0');
-  if (v4) {
-    static bool attr4 = false;
-    CIPS_PER_DEVICE(attr4, false);
-    if (!attr4) {
-      hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-      hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-      attr4 = true;
-    }
-    if ((w->trig_mode & 1))
-      hipLaunchKernelGGL(siren_bwd_x4_kernel<true>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
-    else
-      hipLaunchKernelGGL(siren_bwd_x4_kernel<false>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
-    return CIPS_CHECK_LAUNCH();
-  }
-  if ((w->trig_mode & 1))
-    hipLaunchKernelGGL(siren_bwd_x3_kernel<true>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+  if (w->trig_mode & 1)
+    hipLaunchKernelGGL(siren_bwd_x4_kernel<true>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(siren_bwd_x3_kernel<false>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(siren_bwd_x4_kernel<false>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
   return CIPS_CHECK_LAUNCH();
 }
 
@@ -1402,7 +981,8 @@ static int siren_fwd_x3_launch(const cips_siren_weights* w, const float* points,
 
 extern "C" int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_params* rays, const float* noise,
                                  float noise_std, int clamp_mode, int flags, float* fea, float* depth, float* weights,
-                                 float* feat, float* sigma, float* z, int B, cips_stream_t stream) {
+                                 float* feat, float* sigma, float* z, int B, const unsigned char* clamp_in,
+                                 unsigned char* clamp_out, cips_stream_t stream) {
   if (!w || !fea || B <= 0) return (int)hipErrorInvalidValue;
   MarchArgs a;
   a.w = *w;
@@ -1410,7 +990,7 @@ extern "C" int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_par
   if (rc) return rc;
   a.noise = noise; a.noise_std = noise_std; a.clamp_mode = clamp_mode; a.flags = flags;
   a.fea = fea; a.depth = depth; a.weights = weights; a.feat = feat; a.sigma = sigma; a.zout = z; a.B = B;
-  a.clamp_pin = cips_dbg::clamp_pin; a.clamp_rec = cips_dbg::clamp_rec;
+  a.clamp_pin = clamp_in; a.clamp_rec = clamp_out;
   // a workgroup's 8 waves take 32 rays each: 256-ray chunks keep all of them busy; halve only for small images
   a.rays_per_wg = 256;
   const int n = a.rg.n;

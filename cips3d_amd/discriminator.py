@@ -51,7 +51,6 @@ class gate_debug:
         GATE_PIN, GATE_REC = self.old
 
 
-_ACT_BWD_FUSED = __import__("os").environ.get("CIPS_D_ACT_BWD_FUSED", "1") != "0"
 
 
 class FusedLeakyReLUFunctionBackward(Function):
@@ -59,7 +58,7 @@ class FusedLeakyReLUFunctionBackward(Function):
     def forward(ctx, grad_output, out, negative_slope, scale):
         ctx.save_for_backward(out)
         ctx.negative_slope, ctx.scale = negative_slope, scale
-        if (_ACT_BWD_FUSED and grad_output.dim() == 4 and grad_output.dtype == torch.float32 and out.dtype == torch.float32
+        if (grad_output.dim() == 4 and grad_output.dtype == torch.float32 and out.dtype == torch.float32
                 and grad_output.is_cuda and grad_output.is_contiguous() and out.is_contiguous()):
             return ops.lrelu_bwd_bias(grad_output, out, negative_slope, scale)     # one pass: gated gradient + bias sums
         empty = grad_output.new_empty(0)
@@ -197,19 +196,15 @@ def _x3_ok(K, N, O):
 # Implicit-GEMM form of the x3 convs (CIPS_D_CONV_IMPLICIT=0 keeps the materialised im2col everywhere): the activation is
 # transposed once into NHWC split planes and the NT GEMM's loader gathers the taps; used from 16x16 output planes up
 # (smaller planes leave most of a 256-pixel tile empty).
-IMPLICIT = _os.environ.get("CIPS_D_CONV_IMPLICIT", "1") != "0"
 
 
-_RGB_STREAM = _os.environ.get("CIPS_D_RGB_STREAM", "1") != "0"
-_SKIP_DOWN2 = _os.environ.get("CIPS_D_SKIP_DOWN2", "1") != "0"      # skip branch: blur at down = 2 + stride-1 1x1 conv
 # Small output planes (8x8, 4x4: fewer than 256 pixels per image): the batch is folded into the pixel dimension, one
 # GEMM over B*Ho*Wo columns with the shared weights instead of B GEMMs whose 16- or 64-column tiles are mostly padding
 # (the 4x4 layers spent 14 ms per GAN step in the fp32 GEMM for 5 GFLOP).  CIPS_D_CONV_FOLD=0 restores that.
-_FOLD = _os.environ.get("CIPS_D_CONV_FOLD", "1") != "0"
 
 
 def _fold_ok(K, N, B, O):
-    return _FOLD and CONV_MODE == "bf16x3" and N < 256 and (B * N) % 32 == 0 and K % 32 == 0 and O % 32 == 0
+    return CONV_MODE == "bf16x3" and N < 256 and (B * N) % 32 == 0 and K % 32 == 0 and O % 32 == 0
 
 
 def _split_count(tiles, length):
@@ -237,7 +232,7 @@ def _folded_rows_planes(t):
 
 
 def _implicit_ok(C, N, O):
-    return IMPLICIT and CONV_MODE == "bf16x3" and C % 32 == 0 and O % 32 == 0 and N >= 256 and N % 8 == 0
+    return CONV_MODE == "bf16x3" and C % 32 == 0 and O % 32 == 0 and N >= 256 and N % 8 == 0
 
 
 # NHWC planes of an activation / gradient are shared between the convolution ops that read the same tensor inside ONE
@@ -313,7 +308,6 @@ def _nhwc(t):
 # through .data —, an optimiser step replayed from a hipGraph, a raw-pointer kernel) leaves stale planes in use: such
 # writers call invalidate_weight_cache(module_or_parameters) afterwards.  The cache lives in a weakly keyed table beside
 # the parameters, not in Parameter.__dict__: pickling / deepcopying a module does not carry GPU planes along.
-_WCACHE_ON = _os.environ.get("CIPS_D_WCACHE", "1") != "0"
 import weakref as _weakref
 _WCACHE = {}        # id(Parameter) -> (weakref to it, {(kind, scale): (version, data_ptr, operand)}); the weakref's callback
                     # drops the entry with the Parameter (a WeakKeyDictionary would compare tensor keys with ==)
@@ -332,7 +326,7 @@ def invalidate_weight_cache(what=None):
 
 def _cached(w, scale, kind, build):
     """build(w_eff) -> operand for `kind`, memoised on (parameter, version, scale)"""
-    if not (_WCACHE_ON and isinstance(w, nn.Parameter)):
+    if not isinstance(w, nn.Parameter):
         return build(w if scale == 1.0 else w * scale)
     if w.is_cuda and torch.cuda.is_current_stream_capturing():
         # hipGraph capture (ADVICE r3): a replay runs no Python and never bumps `_version`, so cached planes would go
@@ -390,7 +384,7 @@ def _conv_fwd(x, w, stride, pad, scale=1.0):
     O, _, kh, kw = w.shape
     x = x.contiguous()
     Ho_, Wo_ = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-    if _RGB_STREAM and kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
         return ops.conv1x1_smallk(x, _scaled(w, scale).reshape(O, C).contiguous())      # RGB input convs: streaming, no GEMM
     if _implicit_ok(C, Ho_ * Wo_, O):
         return ops.conv2d_x3(_w_planes(w, scale), _nhwc(x), B, C, H, W, O, kh, kw, stride, pad)
@@ -432,7 +426,7 @@ def _conv_bwd_data(dy, w, in_shape, stride, pad, scale=1.0):
     dy = dy.contiguous()
     Ho, Wo = dy.shape[2], dy.shape[3]
     K, N = C * kh * kw, Ho * Wo
-    if _RGB_STREAM and kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
         return ops.conv1x1_smallk_bwd_data(dy, _scaled(w, scale).reshape(O, C).contiguous(), C)
     if stride == 1 and _implicit_ok(O, H * W, C) and Ho + kh - 1 - 2 * pad == H and kh - 1 - pad >= 0:
         # dx = conv(dy, flipped weights with the channel roles swapped), padding kh-1-pad
@@ -474,7 +468,7 @@ def _conv_bwd_weight_raw(dy, x, w_shape, stride, pad, scale):
     x = x.contiguous()
     dy = dy.contiguous()
     K, N = C * kh * kw, dy.shape[2] * dy.shape[3]
-    if _RGB_STREAM and kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and N % 4 == 0:
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and N % 4 == 0:
         return ops.conv1x1_smallk_bwd_weight(dy, x).view(O, C, 1, 1)       # RGB input convs: streaming reduction
     if _implicit_ok(C, N, O):
         dw = ops.conv2d_x3_wgrad(_nhwc(dy), _nhwc(x), B, C, x.shape[2], x.shape[3], O, kh, kw, stride, pad, scale)
@@ -563,7 +557,7 @@ class ConvBiasActFunction(Function):
         return dx, dw, (dbias if ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
-_CONV_ACT_FUSED = _os.environ.get("CIPS_D_CONV_ACT_FUSED", "1") != "0"
+_CONV_ACT_FUSED = True      # False: bias + LeakyReLU as a separate pass after the convolution (the fusion's parity test flips it)
 
 
 def _conv_act_fusable(x, conv, act):
@@ -710,7 +704,7 @@ class ConvLayer(nn.Sequential):
         # the 1x1 conv at stride 1 on the quarter-size map — implicit GEMM forward and backward, no im2col / col2im.
         blur = getattr(self, "down_blur", None)
         conv = self.equal_conv
-        if (_SKIP_DOWN2 and blur is not None and input.is_cuda and conv.weight.shape[2] == 1 and conv.weight.shape[3] == 1
+        if (blur is not None and input.is_cuda and conv.weight.shape[2] == 1 and conv.weight.shape[3] == 1
                 and conv.stride == 2 and conv.padding == 0):
             x = upfirdn2d(input, blur.kernel, down=2, pad=blur.pad)
             x = conv2d(x, conv.weight, bias=conv.bias, stride=1, padding=0, scale=conv.scale)
@@ -820,7 +814,6 @@ class _EqLinDw(Function):
         return dg, dx, None
 
 
-_LINEAR_HIP = _os.environ.get("CIPS_D_LINEAR_HIP", "1") != "0"
 
 
 class EqualLinear(nn.Module):
@@ -838,7 +831,7 @@ class EqualLinear(nn.Module):
         self.lr_mul = lr_mul
 
     def forward(self, input):
-        if _LINEAR_HIP and input.dim() == 2:
+        if input.dim() == 2:
             if self.activation:
                 out = _EqLinFwd.apply(input, self.weight, None, self.scale, 1.0)
                 return fused_leaky_relu(out, self.bias * self.lr_mul)

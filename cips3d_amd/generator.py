@@ -40,9 +40,6 @@ def kaiming_leaky_init(m):
 # ------------------------------------------------------------------------------------------
 # parameter holders
 # ------------------------------------------------------------------------------------------
-MAPPING_HIP = __import__("os").environ.get("CIPS_MAPPING_HIP", "1") != "0"    # mapping MLPs on the HIP row kernels
-
-
 class PixelNorm(nn.Module):
     """multi_head_mapping.py:13-19"""
 
@@ -132,7 +129,7 @@ class MultiHeadMappingNetwork(nn.Module):
     def _hip_ok(self, z):
         # (large batches — the 10 000 latents of generate_avg_frequencies — stay on hipBLASLt: the row kernels are built for
         # the few rows of a training batch)
-        return (MAPPING_HIP and ops.GROUPED_LINEAR and z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and z.shape[0] <= 256 and z.shape[1] <= 512 and z.shape[1] % 4 == 0
+        return (z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and z.shape[0] <= 256 and z.shape[1] <= 512 and z.shape[1] % 4 == 0
                 and all(not isinstance(m, nn.Linear) or (m.in_features <= 512 and m.in_features % 4 == 0 and m.out_features <= 1024)
                         for m in self.base_net))
 
@@ -372,9 +369,8 @@ class _ToRGBFunction(torch.autograd.Function):
         return dx.view(ctx.shape), dw, db
 
 
-# The INR mapping MLP on a side stream (CIPS_MAPPING_SIDE=0: everything on the caller's stream).  Measured on one box, C2:
-# 17.15 -> 16.79 ms per step (graph replay), 17.22 -> 16.88 eager; the full GPU suite passes either way.
-MAPPING_SIDE_STREAM = os.environ.get("CIPS_MAPPING_SIDE", "1") != "0"
+# The INR mapping MLP runs on a side stream.  Measured on one box, C2: 17.15 -> 16.79 ms per step (graph replay), 17.22 ->
+# 16.88 eager against everything on the caller's stream.
 _SIDE_STREAMS = {}
 
 
@@ -509,7 +505,7 @@ class GeneratorNerfINR(nn.Module):
 
     def mapping_network(self, z_nerf, z_inr, defer_join=False):
         style_dict = {}
-        if MAPPING_SIDE_STREAM and z_inr.is_cuda and z_inr.shape[0] <= 256:
+        if z_inr.is_cuda and z_inr.shape[0] <= 256:
             # the two z -> style MLPs are independent chains of latency-bound launches: the INR one runs on a side stream —
             # its forward next to the NeRF mapping (and, with defer_join, next to the ray march: forward() joins right
             # before the INR head, the first consumer of its styles), its backward (autograd keeps a node on its forward's
@@ -652,7 +648,7 @@ class GeneratorNerfINR(nn.Module):
         # ---------------- camera (O(b) host math) ----------------
         with torch.no_grad():
             pitch_yaw_fused = None
-            if need_cam and simple_cam and ops.CAMERA_HIP and th_raw.is_cuda and not (staged and up_vector is not None):
+            if need_cam and simple_cam and th_raw.is_cuda and not (staged and up_vector is not None):
                 # draws -> pitch, yaw, origin, cam2world in one launch (the ~45 one-wave torch kernels of the op-by-op form
                 # below are 0.2 ms of a captured step)
                 pitch_yaw_fused, origin, cam2world = ops.camera_pose(th_raw, ph_raw, mode == 'uniform', h_stddev, h_mean,
@@ -851,7 +847,7 @@ class GeneratorNerfINR_freeze_NeRF(GeneratorNerfINR):
 
     def mapping_network(self, z_nerf, z_inr, defer_join=False):
         style_dict = {}
-        if MAPPING_SIDE_STREAM and z_inr.is_cuda and z_inr.shape[0] <= 256:       # see GeneratorNerfINR.mapping_network
+        if z_inr.is_cuda and z_inr.shape[0] <= 256:       # see GeneratorNerfINR.mapping_network
             main = torch.cuda.current_stream(z_inr.device)
             side = _side_stream(z_inr.device)
             side.wait_stream(main)

@@ -50,7 +50,6 @@ def _c(t):
 # --------------------------------------------------------------------------------------
 # H1 camera pose + rays
 # --------------------------------------------------------------------------------------
-CAMERA_HIP = _os.environ.get("CIPS_CAMERA_HIP", "1") != "0"     # 0: the camera pose as ~45 torch ops (comm_utils.py order)
 
 
 def camera_pose(theta_raw, phi_raw, uniform, h_stddev, h_mean, v_stddev, v_mean):
@@ -169,9 +168,11 @@ def _split_k(P, target=8):
     return 1
 
 
-SIREN_FWD_MODE = __import__("os").environ.get("CIPS_SIREN_FWD", "x3")   # "x3": split-bf16 chain (default, ~1e-5 rel.); "f32": exact fp32 MFMA
-SIREN_BWD_MODE = __import__("os").environ.get("CIPS_SIREN_BWD", "x3")   # "x3": fused bf16x3 backward; "staged": data pass + GEMMs
-SIREN_BWD_FINALIZE = __import__("os").environ.get("CIPS_SIREN_BWD_FINALIZE", "1") != "0"   # partials -> gradients in one launch
+# The exact-fp32 mode of the path (the only environment variables the package reads besides
+# CIPS_INR_MODE and CIPS_D_CONV_MODE).  Forward "x3": split-operand matrix-core chain (default: fp16 planes, sigma to fp32
+# class); "f32": exact fp32 MFMA.  Backward "x3": fused split-bf16 kernel; "staged": fp32 data pass + GEMMs.
+SIREN_FWD_MODE = __import__("os").environ.get("CIPS_SIREN_FWD", "x3")
+SIREN_BWD_MODE = __import__("os").environ.get("CIPS_SIREN_BWD", "x3")
 
 
 class SirenFunction(torch.autograd.Function):
@@ -232,38 +233,23 @@ def _siren_backward(t, dfeat, dsigma, B, P, points=None, rays=None):
             else:
                 check(lib.cips_siren_bwd_x3_rays(C.byref(sw), C.byref(rays), _p(dfeat), _p(dsigma), _p(sred), _p(gpart), B,
                                                  _stream()), "cips_siren_bwd_x3_rays")
-            if SIREN_BWD_FINALIZE:
-                # the 16 gradient tensors from the partials in one launch (was ~40 tiny torch reductions)
-                from ._lib import SirenGrads
-                shapes = dict(dg0=(B, 128), dp0=(B, 128), dg1=(B, 128), dp1=(B, 128), dgc=(B, 64), dpc=(B, 64), dw0=(128, 3),
-                              db0=(128,), dw1=(128, 128), db1=(128,), dws=(1, 128), dbs=(1,), dwc=(64, 128), dbc=(64,),
-                              dwf=(32, 64), dbf=(32,))
-                outs = {k: torch.empty(*v, device=dev) for k, v in shapes.items()}
-                sg = SirenGrads()
-                for k, v in outs.items():
-                    setattr(sg, k, _p(v))
-                # the chunk partials are summed by two streaming reductions first (88 MB at C2: bandwidth-bound, one
-                # launch each); the finalisation then walks B rows instead of B * chunks
-                SRr = sred.view(B, chunks, sw_).sum(1) if chunks > 1 else sred
-                Gpr = gpart.view(B, chunks, gw).sum(1) if chunks > 1 else gpart
-                check(lib.cips_siren_bwd_x3_finalize(C.byref(sw), _p(SRr), _p(Gpr), B, 1, C.byref(sg), _stream()),
-                      "cips_siren_bwd_x3_finalize")
-                return tuple(outs[k] for k in ("dg0", "dp0", "dg1", "dp1", "dgc", "dpc", "dw0", "db0", "dw1", "db1", "dws",
-                                               "dbs", "dwc", "dbc", "dwf", "dbf"))
-            SR = sred.view(B, chunks, sw_).sum(1)
-            T = SR[:, :1024].view(B, 4, 32, 8)                     # [wave][row][column sums], see cips3d_hip.h
-            R = torch.zeros(B, 868, device=dev)                    # same row format as the staged data pass
-            R[:, 0:128] = T[..., 0].reshape(B, 128)
-            R[:, 128:512] = T[..., 1:4].reshape(B, 128, 3).transpose(1, 2).reshape(B, 384)
-            R[:, 512:640] = T[..., 4].reshape(B, 128)
-            R[:, 640:704] = T[:, 0:2, :, 6].reshape(B, 64)
-            R[:, 704:832] = T[..., 5].reshape(B, 128)
-            R[:, 832:864] = T[:, 0, :, 7] + T[:, 2, :, 7]
-            R[:, 864] = SR[:, 1024:1028].sum(1)
-            Gp = gpart.view(B, chunks, gw).sum(1)
-            G1 = Gp[:, :16384].view(B, 128, 128)                    # da2^T @ h1
-            Gc = Gp[:, 16384:24576].view(B, 64, 128)                # dac^T @ h2
-            dwf = (Gp[:, 24576:26624] + Gp[:, 26624:28672]).sum(0).view(32, 64)   # dfeat^T @ hc
+            # the 16 gradient tensors from the partials in one launch (was ~40 tiny torch reductions)
+            from ._lib import SirenGrads
+            shapes = dict(dg0=(B, 128), dp0=(B, 128), dg1=(B, 128), dp1=(B, 128), dgc=(B, 64), dpc=(B, 64), dw0=(128, 3),
+                          db0=(128,), dw1=(128, 128), db1=(128,), dws=(1, 128), dbs=(1,), dwc=(64, 128), dbc=(64,),
+                          dwf=(32, 64), dbf=(32,))
+            outs = {k: torch.empty(*v, device=dev) for k, v in shapes.items()}
+            sg = SirenGrads()
+            for k, v in outs.items():
+                setattr(sg, k, _p(v))
+            # the chunk partials are summed by two streaming reductions first (88 MB at C2: bandwidth-bound, one
+            # launch each); the finalisation then walks B rows instead of B * chunks
+            SRr = sred.view(B, chunks, sw_).sum(1) if chunks > 1 else sred
+            Gpr = gpart.view(B, chunks, gw).sum(1) if chunks > 1 else gpart
+            check(lib.cips_siren_bwd_x3_finalize(C.byref(sw), _p(SRr), _p(Gpr), B, 1, C.byref(sg), _stream()),
+                  "cips_siren_bwd_x3_finalize")
+            return tuple(outs[k] for k in ("dg0", "dp0", "dg1", "dp1", "dgc", "dpc", "dw0", "db0", "dw1", "db1", "dws",
+                                           "dbs", "dwc", "dbc", "dwf", "dbf"))
         else:
             BP = B * P
             h1, h2, da2 = (Planes.empty(BP, 128, device=dev) for _ in range(3))
@@ -365,13 +351,12 @@ class CompositeFunction(torch.autograd.Function):
         order = torch.empty(R, E, device=dev, dtype=torch.int32)
         zs = torch.empty(R, E, device=dev)
         pin, rec = _clamp_debug_forward(R, E, clamp_mode, dev)
-        with _clamp_hook(pin, rec):
-            check(lib.cips_composite_fwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
-                                         float(noise_std), _p(fea), _p(depth), _p(weights), _p(order), _p(zs),
-                                         R, S, clamp_mode, flags, _stream()), "cips_composite_fwd")
+        check(lib.cips_composite_fwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
+                                     float(noise_std), _p(fea), _p(depth), _p(weights), _p(order), _p(zs),
+                                     R, S, clamp_mode, flags, _p(pin), _p(rec), _stream()), "cips_composite_fwd")
         if rec is not None and CLAMP_REC is not None:
             CLAMP_REC.append(rec.reshape(R, E))
-        ctx.clamp_mask = rec                      # the branches this forward took: the backward takes the same ones
+        ctx.clamp_mask = pin                      # pinned branches: the backward takes the same ones (else: its own sign test)
         ctx.save_for_backward(feat_c, sig_c, z_c, feat_f, sig_f, z_f, noise, order)
         ctx.meta = (float(noise_std), clamp_mode, flags, hier)
         ctx.mark_non_differentiable(depth, weights, order, zs)
@@ -388,17 +373,15 @@ class CompositeFunction(torch.autograd.Function):
         dsig_c = torch.empty_like(sig_c)
         dfeat_f = torch.empty_like(feat_f) if hier else None
         dsig_f = torch.empty_like(sig_f) if hier else None
-        with _clamp_hook(ctx.clamp_mask, None):
-            check(lib.cips_composite_bwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
-                                         noise_std, _p(order), _p(dfea), _p(dfeat_c), _p(dsig_c), _p(dfeat_f),
-                                         _p(dsig_f), R, S, clamp_mode, flags, _stream()), "cips_composite_bwd")
+        check(lib.cips_composite_bwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
+                                     noise_std, _p(order), _p(dfea), _p(dfeat_c), _p(dsig_c), _p(dfeat_f),
+                                     _p(dsig_f), R, S, clamp_mode, flags, _p(ctx.clamp_mask), _stream()), "cips_composite_bwd")
         return dfeat_c, dsig_c, None, dfeat_f, dsig_f, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------
 # Grouped small Linear layers (style -> per-image vectors), one launch for all of them
 # --------------------------------------------------------------------------------------
-GROUPED_LINEAR = __import__("os").environ.get("CIPS_GROUPED_LINEAR", "1") != "0"
 
 
 class GroupedLinearFunction(torch.autograd.Function):
@@ -465,8 +448,6 @@ def grouped_linear(pairs):
     grouped launch (the reference's style dicts alias one tensor per mapping network, multi_head_mapping.py:147-153);
     anything else (truncated / mixed styles) falls back to one launch per distinct input."""
     out = [None] * len(pairs)
-    if not GROUPED_LINEAR:
-        return [lin(x) for x, lin in pairs]
     groups = {}
     for idx, (x, lin) in enumerate(pairs):
         groups.setdefault(id(x), []).append(idx)
@@ -531,8 +512,8 @@ class RowNormFunction(torch.autograd.Function):
 # --------------------------------------------------------------------------------------
 # Fused ray-march (non-hierarchical sampling): rays + SIREN + composite in one kernel
 # --------------------------------------------------------------------------------------
-import os as _os0
-MARCH_FUSED = _os0.environ.get("CIPS_MARCH_FUSED", "1") != "0"
+MARCH_FUSED = True      # False: flat sampling as rays / SIREN / composite launches (what the hierarchical path uses); the
+                        # parity test of the fused kernel against that path flips it
 
 
 def march_available():
@@ -626,12 +607,12 @@ class RayMarchFunction(torch.autograd.Function):
         sw = _siren_struct(t)
         rp = _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S)
         pin, rec = _clamp_debug_forward(B * n, S, clamp_mode, dev)
-        with _clamp_hook(pin, rec):
-            check(lib.cips_march_fwd_x3(C.byref(sw), C.byref(rp), _p(noise), float(noise_std), clamp_mode, flags, _p(fea),
-                                        _p(depth), None, _p(feat), _p(sigma), _p(z), B, _stream()), "cips_march_fwd_x3")
+        check(lib.cips_march_fwd_x3(C.byref(sw), C.byref(rp), _p(noise), float(noise_std), clamp_mode, flags, _p(fea),
+                                    _p(depth), None, _p(feat), _p(sigma), _p(z), B, _p(pin), _p(rec), _stream()),
+              "cips_march_fwd_x3")
         if rec is not None and CLAMP_REC is not None:
             CLAMP_REC.append(rec.reshape(B * n, S))
-        ctx.clamp_mask = rec
+        ctx.clamp_mask = pin
         if train:
             ctx.save_for_backward(xg, yg, zg, cam2world, jitter, noise, feat, sigma, z, *[t[k] for k in _SIREN_NAMES])
         ctx.geom = geom
@@ -649,10 +630,9 @@ class RayMarchFunction(torch.autograd.Function):
         dfea = _c(dfea)
         dfeat = torch.empty_like(feat)
         dsig = torch.empty_like(sigma)
-        with _clamp_hook(ctx.clamp_mask, None):
-            check(lib.cips_composite_bwd(_p(feat), _p(sigma), _p(z), None, None, None, _p(noise), float(noise_std), None,
-                                         _p(dfea), _p(dfeat), _p(dsig), None, None, R, S, clamp_mode, flags, _stream()),
-                  "cips_composite_bwd")
+        check(lib.cips_composite_bwd(_p(feat), _p(sigma), _p(z), None, None, None, _p(noise), float(noise_std), None,
+                                     _p(dfea), _p(dfeat), _p(dsig), None, None, R, S, clamp_mode, flags, _p(ctx.clamp_mask),
+                                     _stream()), "cips_composite_bwd")
         rp = _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S)
         grads = _siren_backward(t, dfeat, dsig, B, n * S, rays=rp)
         return (None,) * 7 + grads
@@ -767,21 +747,6 @@ class clamp_debug:
         CLAMP_PIN, CLAMP_REC = self.old
 
 
-class _clamp_hook:
-    """sets the library's process-global clamp hook around ONE launch (cips_debug_clamp); a no-op unless debugging"""
-
-    def __init__(self, pin, rec):
-        self.pin, self.rec = pin, rec
-
-    def __enter__(self):
-        if self.pin is not None or self.rec is not None:
-            check(_lib.load().cips_debug_clamp(_p(self.pin), _p(self.rec)), "cips_debug_clamp")
-
-    def __exit__(self, *exc):
-        if self.pin is not None or self.rec is not None:
-            _lib.load().cips_debug_clamp(None, None)
-
-
 def _clamp_debug_forward(R, E, clamp_mode, dev):
     """-> (pin, rec) for one composite forward of R rays x E positions: both None outside clamp_debug / for softplus"""
     if (CLAMP_PIN is None and CLAMP_REC is None) or clamp_mode != 0:
@@ -791,7 +756,7 @@ def _clamp_debug_forward(R, E, clamp_mode, dev):
         pin = next(CLAMP_PIN).to(device=dev, dtype=torch.uint8).reshape(-1).contiguous()
         if pin.numel() != R * E:
             raise ValueError(f"clamp_debug: pinned mask of {pin.numel()} entries for {R} rays x {E} positions")
-    return pin, torch.empty(R * E, dtype=torch.uint8, device=dev)
+    return pin, (torch.empty(R * E, dtype=torch.uint8, device=dev) if CLAMP_REC is not None else None)
 
 
 class resample_debug:
@@ -977,7 +942,7 @@ class InrHeadFunction(torch.autograd.Function):
 import os as _os
 INR_MODE = _os.environ.get("CIPS_INR_MODE", "bf16x3")   # "bf16x3" (default, ~1e-5 rel. per layer) or "f32" (exact fp32 MFMA)
 BF = torch.bfloat16
-INR_W_KMAJOR = _os.environ.get("CIPS_INR_W_KMAJOR", "1") == "1"   # dW GEMMs read the row-major planes through LDS
+INR_W_KMAJOR = True   # dW GEMMs read the row-major planes through LDS transpose reads (no transposed copies in HBM)
                                                                  # transpose reads: no transposed planes in HBM
 
 
@@ -994,6 +959,10 @@ class Planes:
 
     def float(self):
         return self.hi.float() + self.lo.float()
+
+
+X3_KERNEL = 0        # descriptor field `kernel` of every split-bf16 GEMM issued from here: 0 = the library's automatic choice
+                     # (production); 1 / 2 / 3 force a kernel (cips3d_hip.h) — set by the kernel parity tests and microbenchmarks
 
 
 def _x3_desc(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, T=None, ldt=0, strideT=0,
@@ -1013,6 +982,7 @@ def _x3_desc(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C=None, P=None, 
     d.act, d.slope = act, LRELU_SLOPE
     d.res_hi, d.res_lo = (_p(res.hi), _p(res.lo)) if res is not None else (None, None)
     d.gate_bits = gate_bits        # bit 0: `mask` is a uint8 bit plane (M, N/8); bit 1: `mask_out` is written as one
+    d.kernel = X3_KERNEL
     if torgb is not None:          # (T (3, N), partials (N/128, batch*M, 4)): ToRGB forward folded into the epilogue
         d.torgb_w, d.torgb_part = _p(torgb[0]), _p(torgb[1])
     if addp is not None:           # (Planes of a gated tensor, bit plane of that gate): the addend, un-gated on the fly
@@ -1024,9 +994,9 @@ _ADDP_OK = {}
 
 
 def _addp_shape_ok(n, cin, cout, nb, dev):
-    """does the library take the planes addend at this shape?  (a property of the shape and of the process-wide kernel
-    switches: asked once per shape with stand-in pointers — the query reads only shapes, flags and pointer alignment)"""
-    key = (n, cin, cout, nb, dev.index)
+    """does the library take the planes addend at this shape?  (a property of the shape and of the kernel selector: asked
+    once per shape with stand-in pointers — the query reads only shapes, flags and pointer alignment)"""
+    key = (n, cin, cout, nb, dev.index, X3_KERNEL)
     ok = _ADDP_OK.get(key)
     if ok is None:
         gq = Planes.empty(1, 8, 8, device=dev)
@@ -1075,6 +1045,7 @@ def gemm_x3_km(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C):
     d.strideA, d.strideB, d.batch = strideA, strideB, batch
     d.C, d.ldc, d.strideC = _p(C), N, M * N
     d.slope = LRELU_SLOPE
+    d.kernel = X3_KERNEL
     check(lib.cips_gemm_bf16x3_km(_ct.byref(d), _stream()), "cips_gemm_bf16x3_km")
 
 
@@ -1089,6 +1060,7 @@ def gemm_x3_km_grouped(problems, M, N, K, lda, ldb, batch, strideA, strideB):
         d.strideA, d.strideB, d.batch = strideA, strideB, batch
         d.C, d.ldc, d.strideC = _p(C), N, M * N
         d.slope = LRELU_SLOPE
+        d.kernel = X3_KERNEL
     rc = lib.cips_gemm_bf16x3_km_grouped(descs, len(problems), _stream())
     if rc == 801:      # hipErrorNotSupported
         for (A, Bm, C) in problems:
@@ -1324,26 +1296,15 @@ def torgb_bwd_w_x3_batch(xps, drgb2d):
 
 
 # LeakyReLU gates of the head kept as bit planes (1 bit per activation, written by the forward GEMMs' epilogues) instead
-# of bf16 planes: 2.5 GB less HBM traffic per C2 step.  CIPS_INR_GATE_BITS=0: bf16 gate planes / sign of the hi plane.
-INR_GATE_BITS = _os.environ.get("CIPS_INR_GATE_BITS", "1") != "0"
+# of bf16 planes: 2.5 GB less HBM traffic per C2 step (layer widths that are not multiples of 32 keep the bf16 form).
+INR_GATE_BITS = True
 
 
-# The head is independent per image (per-image modulated weights): it can run as several CHAINS of launches, one per
-# contiguous range of images, on different streams.  Every launch of a chain is a persistent grid that owns whole CUs
-# (160 KiB of LDS), so the chains do not share CUs — they fill each other's tails: while the last workgroups of a
-# GEMM of chain A are still in their store-bound epilogue, chain B's next GEMM already streams operands on the CUs that
-# are free, and the HBM write bursts of the epilogues (every CU reaches its epilogue at the same moment within ONE
-# launch: 4 TB/s of writes and an idle matrix pipe) are spread over the other chain's main loops.
-# CIPS_INR_CHUNKS=1: one chain (the round-2 behaviour).
-INR_CHUNKS = int(_os.environ.get("CIPS_INR_CHUNKS", "1"))
-# ToRGB forward folded into the epilogue of the block's second GEMM (CIPS_TORGB_FUSED=0: the separate ToRGB kernel)
-TORGB_FUSED = _os.environ.get("CIPS_TORGB_FUSED", "1") != "0"
-# Backward: the skip gradient is re-read from the previous layer's GATED planes (un-gated on the fly with that gate's bit
-# plane) instead of from a separate fp32 copy the previous GEMM would have to write (CIPS_INR_ADDP=0: the fp32 copy)
-INR_ADDP = _os.environ.get("CIPS_INR_ADDP", "1") != "0"
-# the ToRGB tap's gradient into the last block's output as one streaming kernel (0: the K=32 zero-padded GEMM of round 2)
-TORGB_BWDX_STREAM = _os.environ.get("CIPS_TORGB_BWDX_STREAM", "1") != "0"
-_SIDE_STREAMS = {}
+# ToRGB forward folded into the epilogue of the block's second GEMM wherever the 256x256-tile kernel takes the shape
+# (else the separate ToRGB kernel).  Backward: the skip gradient is re-read from the previous layer's GATED planes (un-gated
+# on the fly with that gate's bit plane) instead of from a separate fp32 copy the previous GEMM would have to write, and the
+# ToRGB tap's gradient into the last block's output is one streaming kernel — both where the shapes allow (bit-plane gates,
+# interior tiles); the fp32 copy / the K = 32 zero-padded GEMM remain as the ragged-shape forms.
 
 
 def _bsl(t, b0, b1):
@@ -1356,34 +1317,13 @@ def _bsl(t, b0, b1):
 
 
 def _chunk_ranges(B):
-    nch = INR_CHUNKS if (INR_CHUNKS > 1 and B % INR_CHUNKS == 0 and B // INR_CHUNKS >= 8) else 1
-    step = B // nch
-    return [(i * step, (i + 1) * step) for i in range(nch)]
+    """image ranges the head's launch chain is cut into: one (two chains on two streams measured slower)"""
+    return [(0, B)]
 
 
 def _run_chunks(ranges, fn, dev):
-    """fn(b0, b1) for every range: the first on the current stream, the others on side streams forked from it and
-    joined back (capturable: the side streams enter a hipGraph capture through the event wait)"""
-    if len(ranges) == 1:
-        fn(*ranges[0])
-        return
-    main = torch.cuda.current_stream(dev)
-    fork = torch.cuda.Event()
-    fork.record(main)
-    done = []
-    for i, r in enumerate(ranges[1:]):
-        side = _SIDE_STREAMS.get((dev.index, i))
-        if side is None:
-            side = _SIDE_STREAMS[(dev.index, i)] = torch.cuda.Stream(device=dev)
-        side.wait_event(fork)
-        with torch.cuda.stream(side):
-            fn(*r)
-            e = torch.cuda.Event()
-            e.record(side)
-            done.append(e)
-    fn(*ranges[0])
-    for e in done:
-        main.wait_event(e)
+    for r in ranges:
+        fn(*r)
 
 
 class InrHeadX3Function(torch.autograd.Function):
@@ -1459,7 +1399,7 @@ class InrHeadX3Function(torch.autograd.Function):
                 if e["pin2"] is not None:
                     gemm_x3(a1P, wbt2, n, cout, cout, cout, cout, nb, n * cout, cout * cout, P=oP, T=oT, ldt=n,
                             strideT=cout * n, res=xP if skip else None, mask=m2, gate_bits=1)
-                elif bits and k >= 3 and oT is None and TORGB_FUSED:
+                elif bits and k >= 3 and oT is None:
                     gemm_x3_torgb(a1P, wbt2, n, cout, cout, cout, cout, nb, n * cout, cout * cout, oP, rgbp[2 * (k - 3)],
                                   rgbp[2 * (k - 3) + 1], rgb[b0:b1].view(nb * n, 3), not first_rgb,
                                   act=1, res=xP if skip else None, mask_out=m2, gate_bits=2)
@@ -1530,13 +1470,13 @@ class InrHeadX3Function(torch.autograd.Function):
             # the skip gradient D (un-gated) is either kept as an fp32 copy next to the gated planes every GEMM writes
             # for its successors, or — when every layer has bit-plane gates and the 256x256-tile kernel takes the shapes —
             # recovered from those planes by the consumer (INR_ADDP): no copy written, same bytes read
-            addp = INR_ADDP and km and all(saved[j]["bits"] for j in range(nblocks))
+            addp = km and all(saved[j]["bits"] for j in range(nblocks))
             if addp:
                 for j in range(1, nblocks):
                     if saved[j]["skip"]:
                         cj_in, cj_out = blocks[j][0].shape
                         addp = addp and _addp_shape_ok(n, cj_in, cj_out, nb, dev)
-            if k >= 3 and km and saved[k]["bits"] and width % 8 == 0 and TORGB_BWDX_STREAM:
+            if k >= 3 and km and saved[k]["bits"] and width % 8 == 0:
                 # grad wrt out_k = drgb @ T_k (rank 3), gate of a2_k fused: one streaming kernel writing the planes
                 Dout = torch.empty(nb, n, width, device=dev) if saved[k]["skip"] and not addp else None
                 torgb_bwd_x_x3(drgb2, rgbp[2 * (k - 3)], _bsl(saved[k]["m2"], b0, b1), Dout, gP)

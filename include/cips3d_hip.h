@@ -118,8 +118,6 @@ int cips_siren_fwd_x3(const cips_siren_weights* w, const float* points, float* f
 int cips_siren_bwd_x3_chunks(int B, int P);
 int cips_siren_bwd_x3_gpart(void);
 int cips_siren_bwd_x3_sred(void);
-/* tuning aid: with CIPS_X3_PROF set, phase timestamps (s_memtime) of workgroup (0,0), [round 0..7][wave 0..3][16] */
-int cips_siren_bwd_x3_prof(unsigned long long* host_out);
 int cips_siren_bwd_x3(const cips_siren_weights* w, const float* points, const float* dfeat,
                       const float* dsigma, float* sred, float* gpart, int B, int P, cips_stream_t stream);
 
@@ -163,10 +161,11 @@ int cips_siren_bwd_x3_rays(const cips_siren_weights* w, const cips_ray_params* r
  * noise (B,n,S) standard normals or NULL; clamp_mode 0 relu / 1 softplus; flags bit0 last_back, bit1 white_back.
  * out: fea (B,n,32), depth (B,n) [may be NULL]; optional: weights (B,n,S), and — for a training forward whose backward
  * needs them — the per-sample feat (B,P,32), sigma (B,P), z (B,P).  With those NULL the kernel moves 4*S + 132 B per ray
- * (SURVEY.md §8d-iii). */
+ * (SURVEY.md §8d-iii).  clamp_in / clamp_out: optional (B*n, S) branch masks of the relu clamp, as in cips_composite_fwd
+ * (a separate instantiation of the kernel: the production launch, both NULL, keeps its registers). */
 int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_params* rays, const float* noise, float noise_std,
                       int clamp_mode, int flags, float* fea, float* depth, float* weights, float* feat, float* sigma,
-                      float* z, int B, cips_stream_t stream);
+                      float* z, int B, const unsigned char* clamp_in, unsigned char* clamp_out, cips_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* H3  hierarchical resampling + merge + alpha-composite               */
@@ -201,31 +200,30 @@ int cips_resample_fwd(const float* sigma, const float* z, const float* noise, fl
  * out: fea (R,32), depth (R), weights (R,E) sorted order, order (R,E) int32
  * (index into [fine(0..S-1), coarse(S..2S-1)] like torch.cat([fine, coarse]);
  * for the non-hierarchical case the identity), zsorted (R,E) (may be NULL).
- * flags: bit0 last_back, bit1 white_back. */
+ * flags: bit0 last_back, bit1 white_back.
+ * clamp_in / clamp_out (optional, (R,E) bytes, relu clamp only; no reference counterpart — pigan_utils.py:246-252 is the
+ * clamp they describe): relu(sigma + nerf_noise * eps) is a discontinuity of the gradient — two evaluations whose
+ * pre-activations differ by rounding may take different branches.  With clamp_in the branch of sample (ray, sorted
+ * position k) is clamp_in[ray*E + k] (0 = clamped, else the linear branch) instead of the sign of the value computed here;
+ * clamp_out receives the branch taken.  Both NULL in production; the parity tests pin the CPU oracle's branches through
+ * them.  They are arguments of the call (round 5; rounds 3-4 had a process-global hook): the library keeps no state. */
 int cips_composite_fwd(const float* feat_c, const float* sig_c, const float* z_c,
                        const float* feat_f, const float* sig_f, const float* z_f,
                        const float* noise, float noise_std,
                        float* fea, float* depth, float* weights, int* order, float* zsorted,
-                       int R, int S, int clamp_mode, int flags, cips_stream_t stream);
+                       int R, int S, int clamp_mode, int flags, const unsigned char* clamp_in, unsigned char* clamp_out,
+                       cips_stream_t stream);
 
 /* Backward of the above w.r.t. feat/sigma of both sample sets (z has no grad:
  * fine z is detach()ed, generator_nerf_inr.py:575-579; coarse z is an input).
  * dfea (R,32) upstream.  Re-reads the forward inputs (no saved activations
- * besides `order`; order == NULL with no fine set means the identity). */
+ * besides `order`; order == NULL with no fine set means the identity).  clamp_in as in cips_composite_fwd. */
 int cips_composite_bwd(const float* feat_c, const float* sig_c, const float* z_c,
                        const float* feat_f, const float* sig_f, const float* z_f,
                        const float* noise, float noise_std, const int* order,
                        const float* dfea,
                        float* dfeat_c, float* dsig_c, float* dfeat_f, float* dsig_f,
-                       int R, int S, int clamp_mode, int flags, cips_stream_t stream);
-
-/* Debug hook for parity tests (no reference counterpart; pigan_utils.py:246-252 is the clamp it pins):
- * relu(sigma + nerf_noise * eps) is a discontinuity of the gradient — two evaluations whose pre-activations differ
- * by rounding may take different branches.  While `pin` is set, every cips_composite_fwd / cips_composite_bwd /
- * cips_march_fwd_x3 launch takes the branch of sample (ray, sorted position k) from pin[ray*E + k] (0 = clamped,
- * else the linear branch); while `rec` is set the forward launches write the branch they took to rec[ray*E + k].
- * Process-global, not thread-safe: set, launch, reset with (NULL, NULL). */
-int cips_debug_clamp(const unsigned char* pin, unsigned char* rec);
+                       int R, int S, int clamp_mode, int flags, const unsigned char* clamp_in, cips_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* generic batched fp32 GEMM on v_mfma_f32_32x32x2_f32 with fused epilogues */
@@ -304,6 +302,12 @@ typedef struct cips_gemm_x3_desc {
    * producer need not write, nor this kernel read, a separate fp32 copy (C_unmasked / add: 2 x 4 bytes per element
    * saved).  Exclusive with `add`; needs `mask` as a bit plane; v3 kernel only (hipErrorNotSupported elsewhere). */
   const void* addp_hi; const void* addp_lo; const void* addp_gate; float addp_gain;
+  /* Kernel choice (ABI 5; replaces the process-global cips_gemm_bf16x3_set_wide and the CIPS_X3_* environment variables):
+   * 0 = automatic (production): 256x256 tiles — the v3 schedule for interior shapes, else the ragged-shape wide kernel —
+   * for problems that fill the chip with them, the 256x128 kernel otherwise; 1 = the 256x128 kernel only; 2 = 256x256 tiles
+   * whenever a kernel takes the shape; 3 = like 2 but never the v3 schedule.  1-3 serve the parity tests of each kernel.
+   * The K-major entry points read it the same way (1: never the 256x256-tile kernel, 2 / 3: whenever the shape allows). */
+  int kernel;
 } cips_gemm_x3_desc;
 
 int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream);
@@ -316,9 +320,6 @@ int cips_torgb_finish(const float* part, int nblocks, const float* bias, float* 
                       cips_stream_t stream);
 /* K-major form: C[b][m][n] = sum_k A[b][k][m] * B[b][k][n] (A planes [K][lda], B planes [K][ldb]: the row-major
  * activation / gradient planes themselves; LDS transpose reads build the fragments).  fp32 C output only. */
-/* Tile-form selection of cips_gemm_bf16x3: 0 = 256x128 tiles always, 1 = 256x256 tiles for large problems (default;
- * env CIPS_X3_WIDE), 2 = 256x256 tiles whenever the epilogue is supported (tests). */
-void cips_gemm_bf16x3_set_wide(int mode);
 int cips_gemm_bf16x3_km(const cips_gemm_x3_desc* d, cips_stream_t stream);
 /* Up to four K-major problems of identical shape (M, N, K, batch, leading dimensions, strides) in one launch of
  * 256x256 tiles; only the operand planes and C differ.  hipErrorNotSupported (801) when the shapes do not qualify:

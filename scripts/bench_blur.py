@@ -1,4 +1,4 @@
-"""upfirdn2d microbench on the discriminator's blur shapes (CIPS_BLUR_TILE selects the thread tile of the 4x4 kernel)."""
+"""upfirdn2d microbench on the discriminator's blur shapes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,7 +24,7 @@ def main():
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         gb = (x.numel() + y.numel()) * 4 / 1e9
-        print(f"tile={os.environ.get('CIPS_BLUR_TILE', 'default')}  {name:38s} {us:8.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s")
+        print(f"{name:38s} {us:8.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s")
 
 if __name__ == "__main__":
     main()

@@ -34,7 +34,7 @@ def main():
         for _ in range(reps): ops.SirenFunction.apply(*args)
         e1.record(); torch.cuda.synchronize()
     print(f"  forward only: {e0.elapsed_time(e1) / reps:.3f} ms")
-    if os.environ.get("CIPS_X3_PROF"):
+    if os.environ.get("CIPS_X3_PROF") and hasattr(__import__("cips3d_amd._lib", fromlist=["x"]).load(), "cips_siren_bwd_x3_prof"):      # probe build only
         import ctypes, numpy as np
         from cips3d_amd import _lib
         buf = np.zeros((8, 4, 16), dtype=np.uint64)

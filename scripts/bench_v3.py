@@ -44,8 +44,8 @@ flops = 2.0 * B * n * C * C
 oa, fa = flavours(); ob, fb = flavours()
 ok = True
 for name in fa:
-    lib.cips_gemm_bf16x3_set_wide(3); fa[name]()
-    lib.cips_gemm_bf16x3_set_wide(2); fb[name]()
+    ops.X3_KERNEL = 3; fa[name]()
+    ops.X3_KERNEL = 2; fb[name]()
     torch.cuda.synchronize()
     same = all(torch.equal(a, b) for a, b in ((oa["P"].hi, ob["P"].hi), (oa["P"].lo, ob["P"].lo))) if name != "noout" else True
     if name in ("plain", "res"): same = same and torch.equal(oa["mo"], ob["mo"])
@@ -54,10 +54,10 @@ for name in fa:
     ts = {3: [], 2: []}
     for rnd in range(3):
         for mode, f in ((3, fa), (2, fb)):
-            lib.cips_gemm_bf16x3_set_wide(mode)
+            ops.X3_KERNEL = mode
             ts[mode].append(timeit(f[name]))
     tw, tv = min(ts[3]), min(ts[2])
     print(f"{name:10s} wide {tw:7.1f} us ({flops/tw/1e6:6.1f} TF, frac {flops/tw/1e6/833.3:.3f})   v3 {tv:7.1f} us ({flops/tv/1e6:6.1f} TF, frac {flops/tv/1e6/833.3:.3f})   "
           f"bit-identical {same}   rounds wide {['%.1f' % t for t in ts[3]]} v3 {['%.1f' % t for t in ts[2]]}", flush=True)
-lib.cips_gemm_bf16x3_set_wide(-1)
+ops.X3_KERNEL = 0
 print("ALL BIT-IDENTICAL" if ok else "MISMATCH")

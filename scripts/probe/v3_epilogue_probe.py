@@ -1,5 +1,5 @@
 """Where does the epilogue time of the head NT GEMM go?  v3 kernel, C2 shape, the tuning switches of gemm_bf16x3_v3.hip
-(CIPS_X3_V3DBG / V3SKEW / V3PHASES / V3GRID) set in-process between timings."""
+(needs the probe build, scripts/probe/build_tuning.sh: CIPS_X3_V3DBG / V3SKEW / V3PHASES / V3GRID) set in-process between timings."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -25,8 +25,33 @@ def test_library_builds_and_exports_every_declared_symbol():
     lib = _lib.load()
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.cips_version() == 4
+    assert lib.cips_version() == 5
     assert lib.cips_arch() == b"gfx950"
+
+
+def test_library_is_stateless_reads_no_environment_and_exports_no_hooks():
+    """the C-ABI keeps no mode between calls and no environment variable changes what it computes
+    (round 4 shipped a process-global clamp hook, a process-global kernel selector and ~25 getenv sites, three of which
+    produced wrong results by design).  Checked on the built binary: it does not import getenv, carries no CIPS_* variable
+    name, and exports only what include/cips3d_hip.h declares — no cips_debug_* / cips_*_set_* entry points.  The tuning
+    aids live behind -DCIPS_TUNING (csrc/common.h), which build.py never passes."""
+    import subprocess
+    from cips3d_amd import build, _lib
+    build.build(verbose=False)
+    dyn = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    undefined = {l.split()[-1].split("@")[0] for l in dyn.splitlines() if " U " in l}
+    assert not ({"getenv", "secure_getenv", "setenv", "putenv"} & undefined), undefined
+    exported = sorted(l.split()[-1] for l in dyn.splitlines() if " T cips_" in l)
+    assert exported == header_symbols(), set(exported) ^ set(header_symbols())
+    assert not [e for e in exported if "debug" in e or "_set_" in e or "prof" in e]
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"CIPS_" not in blob, "an environment variable name is compiled into the production library"
+    assert build.HIPCC_EXTRA == [] and "CIPS_TUNING" not in open(build.__file__).read()
+    # the C sources read the environment only through the tuning helper of common.h
+    csrc = os.path.join(ROOT, "cips3d_amd", "csrc")
+    sites = [(f, i + 1) for f in sorted(os.listdir(csrc)) for i, l in enumerate(open(os.path.join(csrc, f)))
+             if "getenv" in l and not l.lstrip().startswith("//")]
+    assert sites == [("common.h", next(i + 1 for i, l in enumerate(open(os.path.join(csrc, "common.h"))) if "getenv(name)" in l))], sites
 
 
 def test_struct_layouts_match_header_field_order():
@@ -49,6 +74,7 @@ def test_struct_layouts_match_header_field_order():
         return out
     assert fields("cips_siren_weights") == [f[0] for f in _lib.SirenWeights._fields_]
     assert fields("cips_gemm_desc") == [f[0] for f in _lib.GemmDesc._fields_]
+    assert fields("cips_gemm_x3_desc") == [f[0] for f in _lib.GemmX3Desc._fields_]
 
 
 def test_product_path_has_no_cpu_fallback():

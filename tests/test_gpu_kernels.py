@@ -294,7 +294,7 @@ def test_fused_march_forward_backward(img, S, b, noise_std, clamp, flags):
     o_feat = torch.empty(b, n * S, 32, device=d); o_sig = torch.empty(b, n * S, device=d); o_z = torch.empty(b, n * S, device=d)
     P = lambda x: C.c_void_p(x.data_ptr())
     check(lib.cips_march_fwd_x3(C.byref(sw), C.byref(rp), P(nd) if noise_std else None, float(noise_std), ops._CLAMP[clamp], flags,
-                                P(o_fea), P(o_depth), P(o_w), P(o_feat), P(o_sig), P(o_z), b, ops._stream()), "march")
+                                P(o_fea), P(o_depth), P(o_w), P(o_feat), P(o_sig), P(o_z), b, None, None, ops._stream()), "march")
     torch.cuda.synchronize()
     assert torch.equal(o_z.cpu().view(b, n, S), r["z"].view(b, n, S)) or max_rel(o_z.view(b, n, S), r["z"].view(b, n, S)) < 1e-6
     e = [max_rel(o_feat.view(b, n, S, 32), out[..., :32]), max_rel(o_sig.view(b, n, S), out[..., 32]),
@@ -532,7 +532,8 @@ def test_gemm_bf16x3_wide(M, N, K, batch, flavour, tile_mode):
     rg = torch.randn(batch * M, 3, generator=g); rw = torch.randn(3, N, generator=g)
     resP = ops.Planes(*[t.to(d) for t in _planes(res)])
     P = ops.Planes.empty(batch, M, N, device=d)
-    lib.cips_gemm_bf16x3_set_wide(tile_mode)
+    monkeypatch_kernel = {2: 2, 3: 3, 0: 1}[tile_mode]
+    old_k, ops.X3_KERNEL = ops.X3_KERNEL, monkeypatch_kernel
     try:
         if flavour == "plain":          # forward FC1: lrelu + planes, and the plain fp32 output
             C = torch.full((batch, M, N), float("nan"), device=d)
@@ -578,7 +579,7 @@ def test_gemm_bf16x3_wide(M, N, K, batch, flavour, tile_mode):
                 assert rel_err(P.float(), s2 * torch.where(mask > 0, 1.0, 0.2).double()) < 3e-5
         torch.cuda.synchronize()
     finally:
-        lib.cips_gemm_bf16x3_set_wide(-1)
+        ops.X3_KERNEL = old_k
 
 
 @pytest.mark.parametrize("M,K,gated,copy", [(4096 * 3, 512, True, False), (1000, 64, True, True), (77, 40, False, True)])
@@ -623,7 +624,7 @@ def test_gemm_bf16x3_planes_addend(M, N, K, batch, rgb):
     gb = _pack_bits(gate).to(d)
     rg = torch.randn(batch * M, 3, generator=g).to(d) if rgb else None
     rw = torch.randn(3, N, generator=g).to(d) if rgb else None
-    lib.cips_gemm_bf16x3_set_wide(2)
+    old_k, ops.X3_KERNEL = ops.X3_KERNEL, 2
     try:
         kw = dict(mask=gb, gate_bits=1, rgb_g=rg, rgb_w=rw)
         assert ops.gemm_x3_takes_addp(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=ops.Planes.empty(batch, M, N, device=d),
@@ -635,7 +636,7 @@ def test_gemm_bf16x3_planes_addend(M, N, K, batch, rgb):
         ops.gemm_x3(Ap, Bp, M, N, K, K, K, batch, M * K, N * K, P=P0, add=D.to(d), C_unmasked=CU, **kw)
         torch.cuda.synchronize()
     finally:
-        lib.cips_gemm_bf16x3_set_wide(-1)
+        ops.X3_KERNEL = old_k
     want = torch.bmm(A.double(), B.double().transpose(1, 2)) + D.double()
     if rgb:
         want = want + (rg.cpu().double() @ rw.cpu().double()).view(batch, M, N)
@@ -688,7 +689,7 @@ def test_gemm_bf16x3_kmajor_wide(M, N, K, batch):
     A = torch.randn(batch, K, M, generator=g); B = torch.randn(batch, K, N, generator=g)
     Ap = ops.Planes(*[t.to(d) for t in _planes(A)]); Bp = ops.Planes(*[t.to(d) for t in _planes(B)])
     ref = torch.bmm(A.to(d).double().transpose(1, 2), B.to(d).double())
-    lib.cips_gemm_bf16x3_set_wide(2)
+    old_k, ops.X3_KERNEL = ops.X3_KERNEL, 2
     try:
         C = torch.full((batch, M, N), float("nan"), device=d)
         ops.gemm_x3_km(Ap, Bp, M, N, K, M, N, batch, K * M, K * N, C)
@@ -696,23 +697,11 @@ def test_gemm_bf16x3_kmajor_wide(M, N, K, batch):
         ops.gemm_x3_km(Ap, Bp, M, N, K, M, N, batch, K * M, K * N, C2)
         torch.cuda.synchronize()
     finally:
-        lib.cips_gemm_bf16x3_set_wide(-1)
+        ops.X3_KERNEL = old_k
     e = rel_err(C, ref)
     print(f"bf16x3 k-major wide {M}x{N}x{K}x{batch}: rel err vs fp64 {e:.3e}")
     assert torch.isfinite(C).all() and e < 3e-5
     assert torch.equal(C, C2)
-    # the round-2 schedule of the same tile (CIPS_X3_KMV3=0): same MFMA order per accumulator, bit-identical output
-    import os
-    os.environ["CIPS_X3_KMV3"] = "0"
-    lib.cips_gemm_bf16x3_set_wide(2)
-    try:
-        C3 = torch.full((batch, M, N), float("nan"), device=d)
-        ops.gemm_x3_km(Ap, Bp, M, N, K, M, N, batch, K * M, K * N, C3)
-        torch.cuda.synchronize()
-    finally:
-        lib.cips_gemm_bf16x3_set_wide(-1)
-        os.environ.pop("CIPS_X3_KMV3", None)
-    assert torch.equal(C, C3)
 
 
 def test_gemm_bf16x3_kmajor_grouped():
