@@ -76,8 +76,14 @@ class Checkpointer:
     def __init__(self, model):
         self.model = _unwrap(model)
 
-    def load_state_dict_from_file(self, path, rank=0, strict=True):
+    def load_state_dict_from_file(self, path, rank=0, strict=True, key=None):
+        """key: which state dict of a combined file ({'generator': ..., 'G_ema': ..., 'state_dict': ...}) to load; without it
+        a file that holds several is ambiguous and raises"""
         sd = torch.load(path, map_location="cpu", weights_only=False)
+        if key is not None:
+            if not (isinstance(sd, dict) and isinstance(sd.get(key), dict)):
+                raise KeyError(f"{path}: no state dict under key '{key}' (keys: {list(sd.keys()) if isinstance(sd, dict) else type(sd)})")
+            sd = sd[key]
         # a file written as {'model': state_dict} / {'state_dict': state_dict} (common wrappers) loads too
         # — but only when exactly ONE candidate key is present: a file holding both 'generator' and 'G_ema' names two
         # networks, and picking one silently (with strict=False nothing would complain) loads the wrong one
@@ -85,7 +91,7 @@ class Checkpointer:
             cands = [k for k in ("model", "state_dict", "G_ema", "generator") if isinstance(sd.get(k), dict)]
             if len(cands) > 1:
                 raise KeyError(f"{path}: several state dicts in one file ({cands}; keys: {list(sd.keys())}) — "
-                               f"pass the one to load, e.g. torch.load(path)['{cands[0]}']")
+                               f"name the one to load: load_state_dict_from_file(path, key='{cands[0]}')")
             if cands:
                 if rank == 0:
                     print(f"Checkpointer: loading the state dict under key '{cands[0]}' of {path}")

@@ -10,10 +10,12 @@ in the CPU tests), restricted to the parameters that actually received a gradien
 on EVERY call by a tiny MAX all-reduce of a presence vector (the exchange DDP's
 find_unused_parameters does per step); the bucket plan is rebuilt — locally, from the agreed
 union, so identically on every rank — only when that union or this rank's own pattern changed.
-On a GPU the presence exchange runs on its own control stream: the host is ahead of the device
-when `__call__` runs (the step's backward, or its hipGraph replay, is still executing), so the
-exchange and the host's read of its result complete under the step's own kernels and the main
-stream is never synchronised.  A training step then issues, per bucket, one concatenation, one
+On a GPU the presence exchange is issued and read back on its own control stream, so the main
+stream is never synchronised; in the classic (non-overlapped) form the host is ahead of the device
+when `__call__` runs and the exchange completes under the step's own kernels.  (Collectives of one
+communicator are serialised by ProcessGroupNCCL: in the overlapped form the exchange is issued
+after the bucket reductions and the host's read therefore waits for them — that form trades host
+run-ahead for the overlap.)  A training step then issues, per bucket, one concatenation, one
 all-reduce and one multi-tensor copy-back — no per-parameter launches (the G step is ~16 ms on an
 MI355X; 170 per-tensor copies would cost > 5 % of it)."""
 import contextlib
@@ -63,6 +65,7 @@ class GradAllReducer:
         self._dirty = False      # a gradient arrived that the plan does not expect: the pattern changed
         self._side = None        # side stream (GPU)
         self._seen = set()       # indices of the parameters whose gradient arrived in the current backward (hooks)
+        self._late = {}          # index -> this rank's gradient of a parameter whose bucket had already been issued
         self._early = 0          # buckets issued from hooks during the current backward
         self.last_launched_early = 0   # ... during the backward that the last __call__ closed (statistics / tests)
         if self.overlap:
@@ -85,23 +88,26 @@ class GradAllReducer:
         self._sig = 0.0
         self._pending = None     # (event, pinned host tensor, expected) of the previous call's plan check
 
-    def _agree(self, local):
-        """the union over ranks of the presence patterns: one MAX all-reduce of len(params) bytes, entered by EVERY rank
-        on EVERY call.  GPU: issued and read back on a control stream that depends on nothing the main stream holds, so
-        the host's wait ends when the tiny collective does, not when the step's kernels do."""
+    def _agree(self, local, late=()):
+        """the union over ranks of the presence patterns: one MAX all-reduce of len(params) ints, entered by EVERY rank on
+        EVERY call -> (union, late union).  A parameter in `late` (overlap mode: its gradient arrived after its bucket had
+        been issued) is sent as 2, so the MAX also agrees on the set of parameters that need the fix-up reduction.  GPU:
+        issued and read back on a control stream; the host's wait ends when the collective does (which, in overlap mode,
+        is behind the bucket reductions of the same communicator)."""
         dev = self.params[0].device
+        vals = [2 if i in late else (1 if f else 0) for i, f in enumerate(local)]
         if dev.type == "cuda":
             if self._ctl is None:
                 self._ctl = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(self._ctl):
-                present = torch.tensor([1 if f else 0 for f in local], dtype=torch.int32, device=dev)
+                present = torch.tensor(vals, dtype=torch.int32, device=dev)
                 dist.all_reduce(present, op=dist.ReduceOp.MAX, group=self.group)
                 flags = present.tolist()                     # synchronises the control stream only
         else:
-            present = torch.tensor([1 if f else 0 for f in local], dtype=torch.int32)
+            present = torch.tensor(vals, dtype=torch.int32)
             dist.all_reduce(present, op=dist.ReduceOp.MAX, group=self.group)
             flags = present.tolist()
-        return tuple(f > 0 for f in flags)
+        return tuple(f > 0 for f in flags), tuple(i for i, f in enumerate(flags) if f > 1)
 
     def _plan(self, local, flags):
         """bucket plan for the agreed union `flags` — a pure function of (flags, this rank's `local`): no collective"""
@@ -142,6 +148,7 @@ class GradAllReducer:
         self._dirty = False
         self._seen = set()
         self._early = 0
+        self._late = {}
 
     def _on_grad(self, p):
         """post-accumulate-grad hook (overlap mode): count the gradient in; issue every bucket that is complete"""
@@ -149,9 +156,20 @@ class GradAllReducer:
         if i in self._seen:                  # a second backward before __call__: not supported in overlap mode
             self._dirty = True
         self._seen.add(i)
-        if self._buckets is None or self._dirty or not dist.is_initialized():
+        if self._buckets is None or not dist.is_initialized():
             return
         b = self._bucket_of.get(id(p))
+        if b is not None and b < self._next and p.grad is not None:
+            # LATE: the bucket of this parameter is already on the wire — the plan did not expect a gradient from this rank
+            # (a peer produced it last step, this rank did not), so the bucket went out with zeros in its place and the
+            # copy-back will overwrite what autograd accumulates now.  Keep this rank's contribution (zero fill + accumulate
+            # = exactly it); __call__ agrees on the late set with the other ranks and adds the missing mean (ADVICE r4:
+            # before, the contribution was silently lost on every rank, and the plan checksum could not see it).
+            self._late[i] = p.grad.detach().clone()
+            self._dirty = True
+            return
+        if self._dirty:
+            return
         if b is None or not self._local[i]:
             self._dirty = True               # a gradient the plan does not expect from this rank: handled in __call__
             return
@@ -249,7 +267,7 @@ class GradAllReducer:
         local = tuple(p.grad is not None for p in self.params)
         # every rank enters the presence exchange, every call; the plan follows from its result alone.  (A caller that
         # leaves gradients in place — zero_grad(set_to_none=False) — shows the previous union on every rank: same plan.)
-        union = self._agree(local)
+        union, _ = self._agree(local)
         if union != self._union or local != self._local:
             self._check_pending(block=True)
             self._plan(local, union)
@@ -302,9 +320,25 @@ class GradAllReducer:
         self._issue_ready(force=True)             # same bucket order on every rank, whatever arrived
         # the presence exchange comes AFTER the forced pass: the number of buckets the hooks issued early differs from
         # rank to rank, the sequence "all buckets of the old plan, then the exchange" does not
-        union = self._agree(local)
+        late_mine = dict(self._late)
+        union, late = self._agree(local, late=late_mine)
         nbytes, sigs, wants = self._drain(world)
         self._record_sigs(sigs, wants)
+        if late:
+            # the same index set on every rank (an agreed value): the contributions that missed their buckets, zeros from
+            # the ranks that were not late, summed and added to the means the buckets delivered
+            ps = [self.params[i] for i in late]
+            parts = [late_mine[i].reshape(-1) if i in late_mine else torch.zeros(p.numel(), dtype=p.grad.dtype, device=p.grad.device)
+                     for i, p in zip(late, ps)]
+            flat = torch.cat(parts)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(world)
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.grad.add_(flat[off:off + n].view_as(p.grad))
+                off += n
+            nbytes += flat.numel() * flat.element_size()
         if union != old_union or local != self._local:
             # the parameters of the old plan are reduced; the ones new to the union (the same set on every rank: both
             # unions are agreed values) are reduced now, and the next backward runs under the new plan

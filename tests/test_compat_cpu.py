@@ -179,3 +179,14 @@ def test_checkpoint_nested_optimizer_state_and_wrapped_payload(tmp_path):
     net3 = torch.nn.Linear(5, 3)
     Checkpointer(net3).load_state_dict_from_file(p)
     assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net3.state_dict().values()))
+    # a combined file names several networks: ambiguous without `key`, selectable with it
+    other = torch.nn.Linear(5, 3)
+    p2 = str(tmp_path / "combined.pth")
+    torch.save({"generator": other.state_dict(), "G_ema": net.state_dict(), "state_dict": {"step": 7}}, p2)
+    net4 = torch.nn.Linear(5, 3)
+    with pytest.raises(KeyError, match="key="):
+        Checkpointer(net4).load_state_dict_from_file(p2)
+    Checkpointer(net4).load_state_dict_from_file(p2, key="G_ema")
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net4.state_dict().values()))
+    with pytest.raises(KeyError):
+        Checkpointer(net4).load_state_dict_from_file(p2, key="discriminator")
