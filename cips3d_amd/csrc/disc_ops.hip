@@ -2,7 +2,6 @@
 // ships as CUDA extensions, with identical contracts, plus the im2col / col2im pair that
 // feeds EqualConv2d to the fp32 MFMA GEMM.  All HBM-bandwidth bound streaming kernels.
 #include "common.h"
-#include <cstdlib>
 #include "../../include/cips3d_hip.h"
 
 // A readable zero outside any tensor: out-of-range taps of the register-tiled upfirdn2d kernels are redirected here by
@@ -32,6 +31,42 @@ __global__ __launch_bounds__(256) void fused_bias_act_kernel(const float* __rest
       case 32: o = 0.f; break;
     }
     y[i] = o * scale;
+  }
+}
+
+// The same op on whole planes: blockIdx.y walks the planes (a plane = step_b contiguous elements that share one bias
+// value, i.e. one (image, channel) map), threads take float4s of the plane — no per-element 64-bit division / modulo, 16-byte
+// accesses.  Bit-identical results (the arithmetic per element is unchanged).  Needs step_b % 4 == 0 and 16-byte aligned
+// tensors; every feature map of the discriminator qualifies, the (rows, C) outputs of the linear layers (step_b = 1) and odd
+// planes take the scalar kernel above.
+__device__ __forceinline__ float fba_one(float v, float r, int mode, float alpha) {
+  switch (mode) {
+    default:
+    case 10: return v;
+    case 11: return v;
+    case 12: return 0.f;
+    case 30: return (v > 0.f) ? v : v * alpha;
+    case 31: return (r > 0.f) ? v : v * alpha;
+    case 32: return 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void fused_bias_act_planes_kernel(const float4* __restrict__ x, const float* __restrict__ b,
+                                                                    const float4* __restrict__ ref, float4* __restrict__ y,
+                                                                    long long planes, int size_b, int step4, int mode,
+                                                                    float alpha, float scale) {
+  for (long long pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+    const float bias = b ? b[pl % size_b] : 0.f;
+    const long long base = pl * step4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < step4; i += gridDim.x * 256) {
+      float4 v = x[base + i];
+      v.x += bias; v.y += bias; v.z += bias; v.w += bias;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ref) r = ref[base + i];
+      float4 o;
+      o.x = fba_one(v.x, r.x, mode, alpha) * scale; o.y = fba_one(v.y, r.y, mode, alpha) * scale;
+      o.z = fba_one(v.z, r.z, mode, alpha) * scale; o.w = fba_one(v.w, r.w, mode, alpha) * scale;
+      y[base + i] = o;
+    }
   }
 }
 
@@ -665,6 +700,21 @@ extern "C" int cips_fused_bias_act(const float* x, const float* bias, const floa
                                    float scale, cips_stream_t stream) {
   if (numel <= 0) return 0;
   if (bias && (size_b <= 0 || step_b <= 0)) return (int)hipErrorInvalidValue;
+  const bool aligned = !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)refer) & 15);
+  // planes form: with a bias, planes of step_b elements; without one (the activation's backward: grad_output, refer = out)
+  // the whole tensor is one plane
+  const long long plane = bias ? step_b : numel;
+  if (plane >= 64 && (plane & 3) == 0 && plane / 4 < 0x7fffffffLL && numel % plane == 0 && aligned) {
+    const long long planes = numel / plane;
+    const int step4 = (int)(plane / 4);
+    const int by = (int)(planes < 65535 ? planes : 65535);
+    const long long want = (step4 + 255) / 256, cap = 16384 / by > 1 ? 16384 / by : 1;
+    const int bx = (int)(want < cap ? want : cap);
+    hipLaunchKernelGGL(fused_bias_act_planes_kernel, dim3(bx, by), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(x), bias, reinterpret_cast<const float4*>(refer),
+                       reinterpret_cast<float4*>(y), planes, bias ? size_b : 1, step4, act * 10 + grad, alpha, scale);
+    return CIPS_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(fused_bias_act_kernel, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, x, bias,
                      refer, y, numel, size_b, step_b, act * 10 + grad, alpha, scale);
   return CIPS_CHECK_LAUNCH();

@@ -889,12 +889,16 @@ def test_upfirdn2d_golden_and_fused_bias_act():
                              c["pad"][0], c["pad"][1], c["pad"][0], c["pad"][1])
         assert y.shape == c["y"].shape and max_rel(y, c["y"]) < 1e-6
     g = torch.Generator().manual_seed(8)
-    x = torch.randn(3, 5, 7, 6, generator=g); bias = torch.randn(5, generator=g); ref = torch.randn(3, 5, 7, 6, generator=g)
     empty = torch.empty(0)
-    for (act, grad, bb, rr) in [(3, 0, bias, empty), (3, 1, empty, ref), (1, 0, bias, empty), (3, 2, empty, ref), (3, 1, bias, ref)]:
-        y = ops.fused_bias_act(x.to(d), bb.to(d), rr.to(d), act, grad, 0.2, 2 ** 0.5)
-        yr = orc.fused_bias_act(x, bb, rr, act, grad, 0.2, 2 ** 0.5)
-        assert torch.equal(y.cpu(), yr) or max_rel(y, yr) < 1e-7
+    # (3, 5, 7, 6): odd planes -> the scalar kernel; the others -> the plane-wise float4 kernel (bias: one plane per (image,
+    # channel) map; no bias: the whole tensor as one plane), incl. more planes than the grid's y extent
+    for shape in [(3, 5, 7, 6), (3, 5, 16, 16), (2, 64, 64, 64), (70000, 1, 8, 8), (2, 3, 4, 34)]:
+        C = shape[1]
+        x = torch.randn(*shape, generator=g); bias = torch.randn(C, generator=g); ref = torch.randn(*shape, generator=g)
+        for (act, grad, bb, rr) in [(3, 0, bias, empty), (3, 1, empty, ref), (1, 0, bias, empty), (3, 2, empty, ref), (3, 1, bias, ref)]:
+            y = ops.fused_bias_act(x.to(d), bb.to(d), rr.to(d), act, grad, 0.2, 2 ** 0.5)
+            yr = orc.fused_bias_act(x, bb, rr, act, grad, 0.2, 2 ** 0.5)
+            assert torch.equal(y.cpu(), yr) or max_rel(y, yr) < 1e-7, (shape, act, grad)
 
 
 @pytest.mark.parametrize("shape,down,pad", [((5, 64, 64), 1, (2, 2)), ((3, 63, 65), 1, (1, 1)), ((2, 200, 260), 1, (2, 2)),
