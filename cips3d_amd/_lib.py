@@ -119,8 +119,6 @@ SIGNATURES = {
     "cips_torgb_finish": (i32, [vp, i32, vp, vp, i64, i32, vp]),
     "cips_equal_linear_scratch": (i64, [i32, i32, i32, i32]),
     "cips_equal_linear": (i32, [i32, vp, vp, vp, f32, f32, vp, vp, i32, i32, i32, vp]),
-    "cips_gemm_bf16x3_chain": (i32, [C.POINTER(GemmX3Desc), i32, i32, i32, vp]),
-    "cips_gemm_bf16x3_chain_accepts": (i32, [C.POINTER(GemmX3Desc), i32]),
     "cips_gemm_bf16x3_km": (i32, [C.POINTER(GemmX3Desc), vp]),
     "cips_gemm_bf16x3_km_grouped": (i32, [C.POINTER(GemmX3Desc), i32, vp]),
     "cips_lrelu_bwd_bias_slices": (i32, [i32]),

@@ -51,43 +51,6 @@ struct VArgs {
   int skew, phases;     // workgroups of XCD x start (x % phases) * skew shader cycles late
 };
 
-// Chain form (round 5): ONE launch runs a sequence of layers of the head — every 512 x 512 modulated-FC GEMM of the forward
-// from the second layer on.  A workgroup owns ROW BLOCKS (256 pixels of one image) and walks row block -> layer -> column
-// tile: layer l's rows depend only on the same rows of earlier layers (A operand = the previous layer's planes, residual =
-// the block input two layers back), all written by this very workgroup, so the only synchronisation is the workgroup's own
-// `s_waitcnt vmcnt(0); s_barrier` at a layer boundary — no kernel boundary per layer, no grid-wide barrier.  What it buys:
-// the workgroups of a per-layer launch reach their store-bound epilogues together (268 MB in one burst at 4.2 TB/s with
-// the matrix pipe idle, four times per launch: DESIGN.md section 3); here they are started a quarter of a tile period apart
-// (`skew`), paid once per ~36-72 tiles instead of once per 4, so one CU's epilogue runs beside its neighbours' main loops.
-// Per-layer operands come from `L[layer]`; shapes, strides and the slope are common (`v.d`).  Same per-tile arithmetic as
-// the per-layer launches: bit-identical planes, gate planes and ToRGB partials.
-constexpr int MAXL = 20;
-struct ChainLayer {
-  const void *A_hi, *A_lo, *B_hi, *B_lo;
-  void *P_hi, *P_lo, *mask_out;
-  const void *res_hi, *res_lo;      // NULL: no residual
-  const float* torgb_w;             // NULL: no ToRGB partials
-  float* torgb_part;
-};
-struct CArgs {
-  VArgs v;
-  ChainLayer L[MAXL];
-  int nlayers, nrb;                 // nrb = row blocks = tiles_m * batch
-  int skew_cycles, phases;
-};
-__device__ __forceinline__ const VArgs& base_args(const VArgs& g) { return g; }
-__device__ __forceinline__ const VArgs& base_args(const CArgs& g) { return g.v; }
-__device__ __forceinline__ int ga_nrb(const VArgs&) { return 0; }
-__device__ __forceinline__ int ga_nrb(const CArgs& c) { return c.nrb; }
-__device__ __forceinline__ int ga_nlayers(const VArgs&) { return 1; }
-__device__ __forceinline__ int ga_nlayers(const CArgs& c) { return c.nlayers; }
-__device__ __forceinline__ int ga_skew(const VArgs&) { return 0; }
-__device__ __forceinline__ int ga_skew(const CArgs& c) { return c.skew_cycles; }
-__device__ __forceinline__ int ga_phases(const VArgs&) { return 1; }
-__device__ __forceinline__ int ga_phases(const CArgs& c) { return c.phases; }
-template <bool CHAIN> struct ArgsOf { using type = VArgs; };
-template <> struct ArgsOf<true> { using type = CArgs; };
-
 template <typename F, int... I>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
@@ -115,10 +78,9 @@ __device__ __forceinline__ constexpr int mfma_b(int m) { return (m >> 3) == 1 ? 
 // ADDP: the addend (HAS_ADD) arrives as the split planes of a gated tensor plus the bit plane of that gate (descriptor fields
 // addp_*): value = (hi + lo) * (bit ? 1 : addp_gain), same bytes in as the fp32 addend, and no C_unmasked copy is needed by
 // the next layer.
-template <bool HAS_ADD, bool HAS_MASK, bool HAS_RES, bool FAST, bool DBG = false, bool RGBF = false, bool ADDP = false, bool CHAIN = false>
-__global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(typename ArgsOf<CHAIN>::type ga) {
+template <bool HAS_ADD, bool HAS_MASK, bool HAS_RES, bool FAST, bool DBG = false, bool RGBF = false, bool ADDP = false>
+__global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(VArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const VArgs& g = base_args(ga);
   const cips_gemm_x3_desc& d = g.d;
   const int tid = threadIdx.x;
   const int lane0 = tid & 63;
@@ -140,24 +102,12 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(typename ArgsOf<CHA
   // LDS-DMA source of one output tile: four uniform plane pointers + one 32-bit byte offset per lane, operand and
   // row-group half (lane L = row L>>2 of the wave's 16-row group, 16-byte slot (L&3) ^ ((row>>2)&3): the swizzle
   // lives in the source address, the LDS image is lane-linear)
-  // operand / output pointers of a layer: the descriptor's (one layer per launch) or L[layer]'s (chain)
-  struct LPtr { const void *A_hi, *A_lo, *B_hi, *B_lo; void *P_hi, *P_lo, *mask_out; const void *res_hi, *res_lo; const float* torgb_w; float* torgb_part; };
-  auto layer_ptrs = [&](int layer) -> LPtr {
-    if constexpr (CHAIN) {
-      const ChainLayer& L = ga.L[layer];
-      return LPtr{L.A_hi, L.A_lo, L.B_hi, L.B_lo, L.P_hi, L.P_lo, L.mask_out, L.res_hi, L.res_lo, L.torgb_w, L.torgb_part};
-    } else {
-      (void)layer;
-      return LPtr{d.A_hi, d.A_lo, d.B_hi, d.B_lo, d.P_hi, d.P_lo, d.mask_out, d.res_hi, d.res_lo, d.torgb_w, d.torgb_part};
-    }
-  };
   struct Src { const u16 *Ahi, *Alo, *Bhi, *Blo; unsigned offA[2], offB[2]; };
-  auto make_src = [&](int tm, int tn, int bz, int layer, int lane, Src& sr) {
-    const LPtr lp = layer_ptrs(layer);
-    sr.Ahi = (const u16*)lp.A_hi + (long long)bz * d.strideA + (long long)tm * BM * d.lda;
-    sr.Alo = (const u16*)lp.A_lo + (long long)bz * d.strideA + (long long)tm * BM * d.lda;
-    sr.Bhi = (const u16*)lp.B_hi + (long long)bz * d.strideB + (long long)tn * BN * d.ldb;
-    sr.Blo = (const u16*)lp.B_lo + (long long)bz * d.strideB + (long long)tn * BN * d.ldb;
+  auto make_src = [&](int tm, int tn, int bz, int lane, Src& sr) {
+    sr.Ahi = (const u16*)d.A_hi + (long long)bz * d.strideA + (long long)tm * BM * d.lda;
+    sr.Alo = (const u16*)d.A_lo + (long long)bz * d.strideA + (long long)tm * BM * d.lda;
+    sr.Bhi = (const u16*)d.B_hi + (long long)bz * d.strideB + (long long)tn * BN * d.ldb;
+    sr.Blo = (const u16*)d.B_lo + (long long)bz * d.strideB + (long long)tn * BN * d.ldb;
     const int drow = lane >> 2, dslot = lane & 3;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -180,41 +130,18 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(typename ArgsOf<CHA
     else dma(sr.Blo + k0, sr.offB[pp], la + OFF_BLO);
   };
 
-  // ---- the workgroup's tile sequence.  Per-layer launch: tiles blockIdx.x, + gridDim.x, ... of the XCD-contiguous order.
-  // Chain: the workgroup's row blocks (XCD-contiguous: the row blocks of one image share their per-image weights in one
-  // XCD's L2), each through every layer, each layer through its column tiles.
-  const int nunits = CHAIN ? ga_nrb(ga) : g.total;            // row blocks / tiles dealt out over the grid
-  const int nmine = nunits > (int)blockIdx.x ? (nunits - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int nseq = CHAIN ? nmine * ga_nlayers(ga) * g.tiles_n : nmine;
-  auto seq = [&](int q, int& tm, int& tn, int& bz, int& layer) {
-    if constexpr (CHAIN) {
-      const int per_rb = ga_nlayers(ga) * g.tiles_n;
-      const int rbi = q / per_rb, rem = q - rbi * per_rb;
-      layer = rem / g.tiles_n; tn = rem - layer * g.tiles_n;
-      const int nx = 8, nrb = ga_nrb(ga);
-      const int t = (int)blockIdx.x + rbi * (int)gridDim.x;
-      const int qq = nrb / nx, r = nrb % nx, xcd = t % nx, idx = t / nx;
-      const int rb = ((xcd < r) ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
-      tm = rb % g.tiles_m; bz = rb / g.tiles_m;
-    } else {
-      layer = 0;
-      decode((int)blockIdx.x + q * (int)gridDim.x, tm, tn, bz);
-    }
-  };
-  {
-    const int skew = CHAIN ? ga_skew(ga) : CIPS_TUNE(g.skew), phases = CHAIN ? ga_phases(ga) : g.phases;
-    if (skew > 0) {
-      const int ph = (int)(CHAIN ? (blockIdx.x >> 3) : (blockIdx.x & 7)) % (phases > 0 ? phases : 1);
-      const long long t0 = __builtin_readcyclecounter();
-      while (__builtin_readcyclecounter() - t0 < (long long)ph * skew) __builtin_amdgcn_s_sleep(32);
-    }
+  if (CIPS_TUNE(g.skew) > 0) {
+    const int ph = (int)(blockIdx.x & 7) % (g.phases > 0 ? g.phases : 1);
+    const long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (long long)ph * g.skew) __builtin_amdgcn_s_sleep(32);
   }
   // ---- kernel prologue: the first tile's k-tiles 0 and 1
-  if (nseq > 0) {
-    int tm, tn, bz, layer;
-    seq(0, tm, tn, bz, layer);
+  bool have = (int)blockIdx.x < g.total;
+  if (have) {
+    int tm, tn, bz;
+    decode(blockIdx.x, tm, tn, bz);
     Src s0;
-    make_src(tm, tn, bz, layer, lane0, s0);
+    make_src(tm, tn, bz, lane0, s0);
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) dma_piece(s0, pc, 0, 0);
 #pragma unroll
@@ -222,23 +149,17 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(typename ArgsOf<CHA
   }
   int younger = 0;        // lower bound of the VMEM operations issued after the 16 DMA pieces of the coming tile
 
-  for (int q = 0; q < nseq; ++q) {
+  for (int tseq = blockIdx.x; tseq < g.total; tseq += gridDim.x) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));        // keeps the per-lane epilogue addresses out of the persistent loop's preheader
     const int l31 = lane & 31, hf = lane >> 5;
-    int tm, tn, bz, layer;
-    seq(q, tm, tn, bz, layer);
-    const LPtr lp = layer_ptrs(layer);
+    int tm, tn, bz;
+    decode(tseq, tm, tn, bz);
     const int m0 = tm * BM, n0 = tn * BN;
     Src src;
-    make_src(tm, tn, bz, layer, lane, src);
-    const bool have_next_any = q + 1 < nseq;
-    int tm2 = 0, tn2 = 0, bz2 = 0, layer2 = 0;
-    if (have_next_any) seq(q + 1, tm2, tn2, bz2, layer2);
-    // chain: the next tile opens a new layer of this row block -> its A operand is what this workgroup is about to store;
-    // it is fetched after the epilogue, behind the workgroup's own vmcnt(0) + barrier, not under it
-    const bool next_dep = CHAIN && have_next_any && layer2 != layer && layer2 != 0;
-    const bool have_next = have_next_any && !next_dep;
+    make_src(tm, tn, bz, lane, src);
+    const int tnext = tseq + (int)gridDim.x;
+    const bool have_next = tnext < g.total;
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -312,12 +233,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(typename ArgsOf<CHA
         p.mask = q[eP >> 3];
       }
       if constexpr (HAS_RES) {
-        if (!CHAIN || lp.res_hi) {
-          const char* qh = (const char*)((const u16*)lp.res_hi + pbase + uoffP(hs));
-          const char* ql = (const char*)((const u16*)lp.res_lo + pbase + uoffP(hs));
-          p.rh = *reinterpret_cast<const uint4*>(qh + eP * 2u);
-          p.rl = *reinterpret_cast<const uint4*>(ql + eP * 2u);
-        }
+        const char* qh = (const char*)((const u16*)d.res_hi + pbase + uoffP(hs));
+        const char* ql = (const char*)((const u16*)d.res_lo + pbase + uoffP(hs));
+        p.rh = *reinterpret_cast<const uint4*>(qh + eP * 2u);
+        p.rl = *reinterpret_cast<const uint4*>(ql + eP * 2u);
       }
     };
     constexpr bool HAS_IN = HAS_ADD || HAS_MASK || HAS_RES;
@@ -344,7 +263,11 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(typename ArgsOf<CHA
       // k-step b
       Src nsrc;
       if constexpr (MODE == 2) {
-        if (have_next) make_src(tm2, tn2, bz2, layer2, lane, nsrc);
+        if (have_next) {
+          int tm2, tn2, bz2;
+          decode(tnext, tm2, tn2, bz2);
+          make_src(tm2, tn2, bz2, lane, nsrc);
+        }
       }
       static_for(std::make_integer_sequence<int, 24>{}, [&](auto M_) {
         constexpr int m = decltype(M_)::value;
@@ -386,9 +309,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(typename ArgsOf<CHA
     ktile(std::integral_constant<int, 2>{}, nk - 1);
 
     // ---- epilogue (order of operations: +add, +rgb term, C_unmasked, gate, act, mask_out, +res, outputs)
-    u16* Phi = (u16*)lp.P_hi; u16* Plo = (u16*)lp.P_lo;
+    u16* Phi = (u16*)d.P_hi; u16* Plo = (u16*)d.P_lo;
     const bool do_act = FAST ? !HAS_MASK : (d.act != 0);
-    const bool do_bits = FAST ? !HAS_MASK : (lp.mask_out != nullptr);
+    const bool do_bits = FAST ? !HAS_MASK : (d.mask_out != nullptr);
     const bool do_c = FAST ? false : (d.C != nullptr);
     const bool do_p = FAST ? true : (Phi != nullptr);
     const bool do_cu = (FAST && !HAS_ADD) ? false : (d.C_unmasked != nullptr);
@@ -490,28 +413,25 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(typename ArgsOf<CHA
         v |= (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
         v |= (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
         if (q2 == 0 && !(DBG && (g.dbg & 1))) {
-          unsigned char* q = (unsigned char*)lp.mask_out + ((pbase + up) >> 3);
+          unsigned char* q = (unsigned char*)d.mask_out + ((pbase + up) >> 3);
           *reinterpret_cast<unsigned*>(q + (eP >> 3)) = v;
         }
       }
       if constexpr (HAS_RES) {
-        if (!CHAIN || lp.res_hi) {
-          const unsigned wh[4] = {cur.rh.x, cur.rh.y, cur.rh.z, cur.rh.w}, wl[4] = {cur.rl.x, cur.rl.y, cur.rl.z, cur.rl.w};
+        const unsigned wh[4] = {cur.rh.x, cur.rh.y, cur.rh.z, cur.rh.w}, wl[4] = {cur.rl.x, cur.rl.y, cur.rl.z, cur.rl.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            y[2 * e] += __uint_as_float(wh[e] << 16) + __uint_as_float(wl[e] << 16);
-            y[2 * e + 1] += __uint_as_float(wh[e] & 0xffff0000u) + __uint_as_float(wl[e] & 0xffff0000u);
-          }
+        for (int e = 0; e < 4; ++e) {
+          y[2 * e] += __uint_as_float(wh[e] << 16) + __uint_as_float(wl[e] << 16);
+          y[2 * e + 1] += __uint_as_float(wh[e] & 0xffff0000u) + __uint_as_float(wl[e] & 0xffff0000u);
         }
       }
       if constexpr (RGBF) {
-       if (!CHAIN || lp.torgb_w) {
         constexpr int jj = hs & 3, rs = hs >> 2;             // column sub-block (innermost), row set (si, h)
         const int col = n0 + wn * 128 + jj * 32 + q2 * 8;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float4 w0 = *reinterpret_cast<const float4*>(lp.torgb_w + (long long)c * d.N + col);
-          const float4 w1 = *reinterpret_cast<const float4*>(lp.torgb_w + (long long)c * d.N + col + 4);
+          const float4 w0 = *reinterpret_cast<const float4*>(d.torgb_w + (long long)c * d.N + col);
+          const float4 w1 = *reinterpret_cast<const float4*>(d.torgb_w + (long long)c * d.N + col + 4);
           float t = (jj == 0) ? 0.f : tacc[c];
           t = fmaf(y[0], w0.x, t); t = fmaf(y[1], w0.y, t); t = fmaf(y[2], w0.z, t); t = fmaf(y[3], w0.w, t);
           t = fmaf(y[4], w1.x, t); t = fmaf(y[5], w1.y, t); t = fmaf(y[6], w1.z, t); t = fmaf(y[7], w1.w, t);
@@ -528,11 +448,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(typename ArgsOf<CHA
           }
           if (q2 == 0 && !(DBG && (g.dbg & 1))) {
             const long long row = (long long)bz * d.M + m0 + wm * 64 + (rs >> 1) * 32 + (rs & 1) * 16 + h_rr;
-            float* q = lp.torgb_part + ((long long)(tn * 2 + wn) * d.batch * d.M + row) * 4;
+            float* q = d.torgb_part + ((long long)(tn * 2 + wn) * d.batch * d.M + row) * 4;
             *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], 0.f);
           }
         }
-       }
       }
       if (do_c) {
         float* q = d.C + cbase + uc;
@@ -554,22 +473,6 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(typename ArgsOf<CHA
       }
       if constexpr (HAS_IN && hs + NPF - 1 < 16) prefetch(hs + NPF - 1, pre[(hs + NPF - 1) % NPF]);
     });
-    if constexpr (CHAIN) {
-      if (next_dep) {
-        // layer boundary of a row block: every wave's stores of this layer must have reached L2 before any wave's LDS-DMA
-        // reads them back as the next layer's A operand (same CU: a workgroup-scope hand-off — waitcnt + barrier; the lines
-        // were never read before in this launch, so no stale L1 copy can exist).  Then the two first k-tiles, as in the
-        // kernel prologue.
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        Src s2;
-        make_src(tm2, tn2, bz2, layer2, lane0, s2);
-#pragma unroll
-        for (int pc = 0; pc < 8; ++pc) dma_piece(s2, pc, 0, 0);
-#pragma unroll
-        for (int pc = 0; pc < 8; ++pc) dma_piece(s2, pc, BK, STAGE);
-        younger = 0;
-      }
-    }
   }  // persistent tile loop
 }
 
@@ -629,79 +532,6 @@ static int v3_accepts(const cips_gemm_x3_desc* d) {
   return 0;
 }
 extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_v3_accepts(const cips_gemm_x3_desc* d) { return v3_accepts(d); }
-
-// 0: the descriptors form a chain this file runs in one launch (see ChainLayer); else the error code
-static int chain_accepts(const cips_gemm_x3_desc* ds, int n) {
-  if (!ds || n < 1) return (int)hipErrorInvalidValue;
-  if (n > MAXL) return (int)hipErrorNotSupported;
-  const cips_gemm_x3_desc& a = ds[0];
-  for (int l = 0; l < n; ++l) {
-    const cips_gemm_x3_desc& e = ds[l];
-    const int rc = v3_accepts(&e);
-    if (rc) return rc;
-    // forward flavours with the compile-time epilogue only: lrelu + gate bit plane + planes out (+ residual, + ToRGB partials)
-    if (e.add || e.addp_hi || e.mask || e.rgb_g || e.C || e.C_unmasked || e.T_hi || !e.P_hi || !e.P_lo || !e.mask_out || e.act != 1 ||
-        !(e.gate_bits & 2))
-      return (int)hipErrorNotSupported;
-    if (e.M != a.M || e.N != a.N || e.K != a.K || e.batch != a.batch || e.lda != a.lda || e.ldb != a.ldb || e.strideA != a.strideA ||
-        e.strideB != a.strideB || e.ldp != a.ldp || e.strideP != a.strideP || e.slope != a.slope)
-      return (int)hipErrorNotSupported;
-    if ((e.res_hi == nullptr) != (e.res_lo == nullptr) || (e.torgb_w == nullptr) != (e.torgb_part == nullptr)) return (int)hipErrorInvalidValue;
-    if (l > 0) {
-      // the row-local dependency the kernel's hand-off covers: layer l reads the planes layer l-1 wrote, same geometry
-      if (e.A_hi != ds[l - 1].P_hi || e.A_lo != ds[l - 1].P_lo || e.lda != e.ldp || e.strideA != e.strideP || e.K != e.N)
-        return (int)hipErrorNotSupported;
-    }
-    for (int j = l; j < n; ++j) {          // no layer may read rows another workgroup writes: inputs written in this launch
-      const cips_gemm_x3_desc& w = ds[j];  // must be an earlier layer's planes (checked above for A; here: residual)
-      if (e.res_hi && (e.res_hi == w.P_hi || e.res_lo == w.P_lo)) return (int)hipErrorInvalidValue;
-      if (j > l && (e.P_hi == w.P_hi || e.P_lo == w.P_lo || e.mask_out == w.mask_out)) return (int)hipErrorInvalidValue;
-      if (j >= l && (e.A_hi == w.P_hi || e.B_hi == w.P_hi || e.B_lo == w.P_lo)) return (int)hipErrorInvalidValue;
-    }
-  }
-  if (a.ldp != a.N || a.strideP != (long long)a.M * a.N) return (int)hipErrorNotSupported;      // residual / planes share `pbase`
-  return 0;
-}
-extern "C" int cips_gemm_bf16x3_chain_accepts(const cips_gemm_x3_desc* descs, int nlayers) { return chain_accepts(descs, nlayers); }
-
-extern "C" int cips_gemm_bf16x3_chain(const cips_gemm_x3_desc* descs, int nlayers, int skew_cycles, int phases, cips_stream_t stream) {
-  { const int rc = chain_accepts(descs, nlayers); if (rc) return rc; }
-  if (skew_cycles < 0 || phases < 0) return (int)hipErrorInvalidValue;
-  CArgs c = {};
-  c.v.d = descs[0];
-  c.v.tiles_m = descs[0].M / BM;
-  c.v.tiles_n = descs[0].N / BN;
-  const long long nrb = (long long)c.v.tiles_m * descs[0].batch;
-  if (nrb * c.v.tiles_n > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-  c.v.total = (int)(nrb * c.v.tiles_n);
-  c.v.phases = 1;
-  c.nrb = (int)nrb;
-  c.nlayers = nlayers;
-  c.skew_cycles = skew_cycles;
-  c.phases = phases > 0 ? phases : 1;
-  for (int l = 0; l < nlayers; ++l) {
-    const cips_gemm_x3_desc& e = descs[l];
-    c.L[l] = ChainLayer{e.A_hi, e.A_lo, e.B_hi, e.B_lo, e.P_hi, e.P_lo, e.mask_out, e.res_hi, e.res_lo, e.torgb_w, e.torgb_part};
-  }
-  static int ncu = 0;
-  CIPS_PER_DEVICE(ncu, 0);
-  if (!ncu) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
-    ncu = (ncu / 8) * 8;
-  }
-  const int grid = c.nrb < ncu ? c.nrb : ncu;
-  auto kern = gemm_bf16x3_v3_kernel<false, false, true, true, false, true, false, true>;
-  static bool attr = false;
-  CIPS_PER_DEVICE(attr, false);
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    attr = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM_BYTES, (hipStream_t)stream, c);
-  return CIPS_CHECK_LAUNCH();
-}
 
 // Internal entry (called by cips_gemm_bf16x3 ahead of the wide kernel): same descriptor.  hipErrorNotSupported for
 // every shape / epilogue it has no code for.

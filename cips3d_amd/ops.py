@@ -1036,29 +1036,6 @@ def gemm_x3_torgb(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, P, rgb_w, r
     torgb_fwd_x3(P, rgb_w, rgb_b, rgb2d, accumulate)
 
 
-CHAIN_SKEW_CYCLES = 16000    # start-phase stagger of the chain launch: workgroup w starts ((w >> 3) % CHAIN_PHASES) * this many shader
-CHAIN_PHASES = 4             # cycles late (a quarter of a 256 x 256 x 512 tile period each), paid once per launch
-CHAIN_MIN_ROW_BLOCKS = 256   # below this the per-layer launches (column tiles spread over the CUs) fill the chip better
-
-
-def gemm_x3_chain(layers, before=None):
-    """layers: list of (args, kwargs) of consecutive gemm_x3 calls — every layer reads the planes the previous one wrote — as ONE
-    launch (cips_gemm_bf16x3_chain: a workgroup owns row blocks and walks them through all layers).  -> True when the library
-    took it, False when the shapes / epilogues do not qualify (nothing was launched; issue the layers one by one).  `before()`
-    runs between the acceptance check and the launch (the producer of the first layer's input)."""
-    lib = _lib.load()
-    descs = (GemmX3Desc * len(layers))()
-    for i, (a, kw) in enumerate(layers):
-        d = _x3_desc(*a, **kw)
-        _ct.memmove(_ct.byref(descs[i]), _ct.byref(d), _ct.sizeof(GemmX3Desc))
-    if lib.cips_gemm_bf16x3_chain_accepts(descs, len(layers)) != 0:
-        return False
-    if before is not None:
-        before()
-    check(lib.cips_gemm_bf16x3_chain(descs, len(layers), CHAIN_SKEW_CYCLES, CHAIN_PHASES, _stream()), "cips_gemm_bf16x3_chain")
-    return True
-
-
 def gemm_x3_km(A, Bm, M, N, K, lda, ldb, batch, strideA, strideB, C):
     """C[b][m][n] = sum_k A[b][k][m] * B[b][k][n]; A, B: Planes stored [K][ld] (k-major), C fp32 (M,N)."""
     lib = _lib.load()
@@ -1321,9 +1298,6 @@ def torgb_bwd_w_x3_batch(xps, drgb2d):
 # LeakyReLU gates of the head kept as bit planes (1 bit per activation, written by the forward GEMMs' epilogues) instead
 # of bf16 planes: 2.5 GB less HBM traffic per C2 step (layer widths that are not multiples of 32 keep the bf16 form).
 INR_GATE_BITS = True
-# The forward's 512 x 512 layers (all but the first) as one chain launch where the shapes allow (interior tiles, bit-plane gates,
-# at least CHAIN_MIN_ROW_BLOCKS row blocks); False: one launch per layer (the kernel parity test of the chain flips it)
-INR_CHAIN = True
 
 
 # ToRGB forward folded into the epilogue of the block's second GEMM wherever the 256x256-tile kernel takes the shape
@@ -1404,48 +1378,8 @@ class InrHeadX3Function(torch.autograd.Function):
             plan.append(e)
         any_rgb = nblocks > 3
 
-        def run_chain():
-            """every 512-wide layer of the head from block 0's second layer on in ONE launch (gemm_bf16x3_v3.hip, chain form):
-            same per-tile arithmetic as the launches below — bit-identical planes, gate planes and rgb"""
-            if (not INR_CHAIN or X3_KERNEL != 0 or not train or nblocks < 2 or n % 256 or B * (n // 256) < CHAIN_MIN_ROW_BLOCKS
-                    or want_t or any(not e["bits"] or e["pin1"] is not None or e["pin2"] is not None for e in plan)):
-                return False
-            width = plan[0]["cout"]
-            if any(e["cout"] != width for e in plan) or any(e["cin"] != width for e in plan[1:]) or width % 256:
-                return False
-            e0 = plan[0]
-
-            def first_layer():       # block 0's first layer (32 -> 512: K = 32 is not a chain shape) on its usual kernel
-                gemm_x3(x0P, prepped[0][1], n, width, e0["cin"], e0["cin"], e0["cin"], B, n * e0["cin"], width * e0["cin"], P=e0["a1P"],
-                        act=1, mask_out=e0["a1g"], gate_bits=2)
-            layers, finish = [], []
-            xP = x0P
-            for k, e in enumerate(plan):
-                _, wbt1, _ = prepped[2 * k]
-                _, wbt2, _ = prepped[2 * k + 1]
-                dims = (n, width, width, width, width, B, n * width, width * width)
-                if k > 0:
-                    layers.append(((xP, wbt1) + dims, dict(P=e["a1P"], act=1, mask_out=e["a1g"], gate_bits=2)))
-                kw = dict(P=e["oP"], act=1, res=xP if e["skip"] else None, mask_out=e["m2"], gate_bits=2)
-                if k >= 3:
-                    part = torch.empty(width // 128, B * n, 4, device=dev)
-                    kw["torgb"] = (rgbp[2 * (k - 3)], part)
-                    finish.append((part, rgbp[2 * (k - 3) + 1]))
-                layers.append(((e["a1P"], wbt2) + dims, kw))
-                xP = e["oP"]
-            if not all(w.is_contiguous() for w in rgbp[0::2]) or not gemm_x3_chain(layers, before=first_layer):
-                return False
-            lib = _lib.load()
-            rgb2d = rgb.view(B * n, 3)
-            for i, (part, bias) in enumerate(finish):
-                check(lib.cips_torgb_finish(_p(part), width // 128, _p(bias), _p(rgb2d), B * n, 1 if i else 0, _stream()),
-                      "cips_torgb_finish")
-            return True
-
         def run(b0, b1):
             nb = b1 - b0
-            if b0 == 0 and b1 == B and run_chain():
-                return
             xP = _bsl(x0P, b0, b1)
             first_rgb = True
             for k, e in enumerate(plan):

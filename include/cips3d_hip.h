@@ -315,19 +315,6 @@ int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream);
 int cips_gemm_bf16x3_fuses_torgb(const cips_gemm_x3_desc* d);
 /* 1 when cips_gemm_bf16x3 would take this descriptor's planes addend (addp_*; v3 kernel only) */
 int cips_gemm_bf16x3_takes_addp(const cips_gemm_x3_desc* d);
-/* Chain form (ABI 5): `nlayers` (<= 20) consecutive forward layers of the CIPS head in ONE launch
- * (generator.py:949-974, 1107-1154: mod1 -> lrelu -> mod2 -> lrelu (+ skip) (+ ToRGB) per block).  A workgroup owns 256-row
- * blocks of one image and walks each through every layer; layer l's rows depend only on the same rows of earlier layers, so
- * the hand-off is the workgroup's own store-drain + barrier — no launch boundary, no grid barrier — and the workgroups are
- * started `skew_cycles` shader cycles apart in `phases` groups so that their store-bound epilogues do not coincide (0 / 1: no
- * stagger).  Requirements (else hipErrorNotSupported and nothing is launched; cips_gemm_bf16x3_chain_accepts answers the
- * same question without launching): every descriptor a shape of the 256x256-tile kernel (M, N % 256, K % 64) with the
- * forward epilogue (act 1, mask_out as a bit plane, planes out, optionally res_* and torgb_*; no add / mask / C / T), all of
- * one shape (M, N, K = N, batch, leading dimensions, strides), descs[l].A == descs[l-1].P, residuals only from earlier
- * layers' planes or from tensors the chain does not write, ldp == N.  Outputs are bit-identical to issuing the descriptors
- * one by one through cips_gemm_bf16x3. */
-int cips_gemm_bf16x3_chain(const cips_gemm_x3_desc* descs, int nlayers, int skew_cycles, int phases, cips_stream_t stream);
-int cips_gemm_bf16x3_chain_accepts(const cips_gemm_x3_desc* descs, int nlayers);
 /* rgb[m][c] = (accumulate ? rgb[m][c] : 0) + bias[c] + sum_j part[j][m][c];  part (nblocks, M, 4), rgb (M, 3) */
 int cips_torgb_finish(const float* part, int nblocks, const float* bias, float* rgb, long long M, int accumulate,
                       cips_stream_t stream);

@@ -829,74 +829,6 @@ def test_inr_head_forward_backward(mode, n):
             assert p.grad is None or float(p.grad.abs().max()) == 0, k
 
 
-@pytest.mark.parametrize("b,n,skew", [(2, 4096, 16000), (3, 1024, 0), (5, 256, 4000), (2, 2048, 16000)])
-def test_inr_head_chain_launch_is_bit_identical_to_per_layer_launches(b, n, skew, monkeypatch):
-    """Round 5: the forward's seventeen 512 x 512 layers as ONE launch (cips_gemm_bf16x3_chain: a workgroup walks its 256-row
-    blocks through every layer; gemm_bf16x3_v3.hip) against one launch per layer — the same per-tile arithmetic, so the image,
-    every LeakyReLU gate plane, and (through the saved planes) every gradient must be IDENTICAL bit for bit.  Grids smaller and
-    larger than the number of row blocks, with and without the start-phase stagger."""
-    from cips3d_amd import ops
-    monkeypatch.setattr(ops, "CHAIN_MIN_ROW_BLOCKS", 1)
-    monkeypatch.setattr(ops, "CHAIN_SKEW_CYCLES", skew)
-    G = seeded_generator(9).to(dev())
-    g = torch.Generator().manual_seed(b + n)
-    fea = torch.randn(b, n, 32, generator=g).to(dev()); w_inr = torch.randn(b, 512, generator=g).to(dev())
-    up = torch.randn(b, n, 3, generator=g).to(dev())
-    launches = []
-    real_chain = ops.gemm_x3_chain
-
-    def counting_chain(layers, before=None):
-        ok = real_chain(layers, before=before)
-        launches.append((len(layers), ok))
-        return ok
-    monkeypatch.setattr(ops, "gemm_x3_chain", counting_chain)
-
-    def run(chain):
-        monkeypatch.setattr(ops, "INR_CHAIN", chain)
-        G.zero_grad()
-        fd = fea.clone().requires_grad_(True); wd = w_inr.clone().requires_grad_(True)
-        rec = []
-        with ops.gate_debug(rec=rec):
-            out = G.inr_net(fd, {k: wd for k in G.inr_net.style_dim_dict})
-        (out * up).sum().backward()
-        torch.cuda.synchronize()
-        return out.detach().clone(), [r.clone() for r in rec], fd.grad.clone(), wd.grad.clone(), {k: p.grad.clone() for k, p in G.inr_net.named_parameters() if p.grad is not None}
-
-    a = run(False)
-    assert launches == []
-    c = run(True)
-    assert launches == [(17, True)], launches
-    assert torch.isfinite(c[0]).all() and torch.equal(a[0], c[0])
-    assert len(a[1]) == len(c[1]) == 18 and all(torch.equal(x, y) for x, y in zip(a[1], c[1]))
-    assert torch.equal(a[2], c[2]) and torch.equal(a[3], c[3])
-    assert set(a[4]) == set(c[4]) and all(torch.equal(a[4][k], c[4][k]) for k in a[4])
-
-
-def test_gemm_chain_refuses_what_it_cannot_run():
-    """cips_gemm_bf16x3_chain_accepts: pinned gates (mask input), ragged shapes and a layer that does not read its predecessor's
-    planes are not chains — the caller then issues the layers one by one (nothing was launched)"""
-    from cips3d_amd import ops
-    d = dev()
-    M, N, b = 512, 512, 2
-    P = [ops.Planes.empty(b, M, N, device=d) for _ in range(3)]
-    W = ops.Planes.empty(b, N, N, device=d)
-    bits = [torch.empty(b, M, N // 8, device=d, dtype=torch.uint8) for _ in range(2)]
-    dims = (M, N, N, N, N, b, M * N, N * N)
-    good = [((P[0], W) + dims, dict(P=P[1], act=1, mask_out=bits[0], gate_bits=2)),
-            ((P[1], W) + dims, dict(P=P[2], act=1, mask_out=bits[1], gate_bits=2, res=P[0]))]
-    for x in P + [W]:
-        x.hi.zero_(); x.lo.zero_()
-    assert ops.gemm_x3_chain(good)
-    pinned = [good[0], ((P[1], W) + dims, dict(P=P[2], mask=bits[1], gate_bits=1))]
-    assert not ops.gemm_x3_chain(pinned)
-    broken = [good[0], ((P[0], W) + dims, dict(P=P[2], act=1, mask_out=bits[1], gate_bits=2))]      # layer 1 does not read layer 0's output
-    assert not ops.gemm_x3_chain(broken)
-    Ps = [ops.Planes.empty(b, 300, N, device=d) for _ in range(2)]
-    ragged = [((Ps[0], W) + (300, N, N, N, N, b, 300 * N, N * N), dict(P=Ps[1], act=1, mask_out=torch.empty(b, 300, N // 8, device=d, dtype=torch.uint8), gate_bits=2))]
-    assert not ops.gemm_x3_chain(ragged)
-    torch.cuda.synchronize()
-
-
 def test_inr_head_bf16x3_vs_f32_at_scale():
     """bf16x3 against the exact-fp32 HIP path at 2 x 4096 rows.  Forward agreement is ~3e-6.  Free-running, their
     gradients differ by ~1 %: the WHOLE difference is LeakyReLU gates — with the f32 path's gates pinned into the
