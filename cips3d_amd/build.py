@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libcips3d_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "gemm_bf16x3_wide.hip", "gemm_bf16x3_v3.hip", "gemm_bf16x3_v5.hip", "gemm_bf16x3_km_wide.hip", "siren.hip", "siren_bwd_x3.hip", "render.hip", "modfc.hip", "disc_ops.hip", "optim.hip", "small_ops.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "gemm_bf16x3_wide.hip", "gemm_bf16x3_v3.hip", "gemm_bf16x3_km_wide.hip", "siren.hip", "siren_bwd_x3.hip", "render.hip", "modfc.hip", "disc_ops.hip", "optim.hip", "small_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 # per-source extras.  siren_bwd_x3.hip: the m-major layers of siren_bwd_x4.inc unroll 32 items x (3 MFMAs + 3 epilogue slots);

@@ -762,7 +762,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float* __r
 extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_wide(const cips_gemm_x3_desc* d, cips_stream_t stream);   // gemm_bf16x3_wide.hip
 extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_v3(const cips_gemm_x3_desc* d, cips_stream_t stream);     // gemm_bf16x3_v3.hip
 extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_v3_accepts(const cips_gemm_x3_desc* d);
-extern "C" CIPS_INTERNAL int cips_gemm_bf16x3_v5(const cips_gemm_x3_desc* d, cips_stream_t stream);     // gemm_bf16x3_v5.hip (experiment)
 // Kernel choice (descriptor field `kernel`, cips3d_hip.h): 0 = automatic — 256x256 tiles (v3 schedule for interior shapes,
 // else the wide kernel) for problems that fill the chip with them, the 256x128 kernel below otherwise; 1 = the 256x128 kernel
 // only; 2 = 256x256 tiles whenever a kernel takes the shape; 3 = like 2 but never the v3 schedule.  1-3 exist for the parity
@@ -776,14 +775,8 @@ extern "C" int cips_gemm_bf16x3(const cips_gemm_x3_desc* d, cips_stream_t stream
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return (int)hipErrorInvalidValue;
   if ((d->K & 31) || (d->lda & 7) || (d->ldb & 7) || (d->strideA & 7) || (d->strideB & 7))
     return (int)hipErrorInvalidValue;
-  if (d->kernel < 0 || d->kernel > 4) return (int)hipErrorInvalidValue;
+  if (d->kernel < 0 || d->kernel > 3) return (int)hipErrorInvalidValue;
   if (d->gate_bits && ((d->N & 31) || (d->ldp & 31) || (d->strideP & 31))) return (int)hipErrorInvalidValue;
-  if (d->kernel == 4) {                      // EXPERIMENT (round 5): role-split main loop
-    const int rc5 = cips_gemm_bf16x3_v5(d, stream);
-    if (rc5 != (int)hipErrorNotSupported) return rc5;
-    cips_gemm_x3_desc e = *d; e.kernel = 0;
-    return cips_gemm_bf16x3(&e, stream);
-  }
   // large square-ish problems: 256x256 tiles (less operand traffic per flop, prefetched epilogue inputs)
   if (x3_wants_256(d) && d->kernel != 3) {
     const int rc3 = cips_gemm_bf16x3_v3(d, stream);
