@@ -583,6 +583,9 @@ class GeneratorNerfINR(nn.Module):
         clamp = ops._CLAMP[clamp_mode]
         flags = (1 if last_back else 0) | (2 if white_back else 0)
         staged = forward_points is not None
+        part = grad_points is not None and grad_points < n
+        if part:
+            staged = False          # generator.py:1325-1347: part_grad_forward is not handed forward_points
 
         # ---------------- random draws in reference order ----------------
         def draw(kind, fn, shape, override=True):
@@ -610,9 +613,6 @@ class GeneratorNerfINR(nn.Module):
             fn = torch.rand if mode == 'uniform' else torch.randn
             return draw('theta', fn, (bs, 1), override), draw('phi', fn, (bs, 1), override)
 
-        part = grad_points is not None and grad_points < n
-        if part and staged:
-            raise NotImplementedError("grad_points together with forward_points")
         if part:
             jitter = draw('jitter', torch.rand, (b, n, S, 1))
             th_raw, ph_raw = draw_cam(b) if need_cam else (None, None)

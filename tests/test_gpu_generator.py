@@ -90,6 +90,27 @@ def _grad_errors(fix, grads, g64):
     return rows
 
 
+def test_grad_points_ignores_forward_points_like_the_reference():
+    """generator.py:1325-1347: with grad_points < img_size**2 the reference takes part_grad_forward and never looks at
+    forward_points.  Same call with and without it -> the same images and gradients, bit for bit."""
+    fix = load_golden("g_r16_part")
+    d = torch.device("cuda:0")
+    G = seeded_generator(fix["seed"], freeze=fix["freeze"], device=d)
+    zs = {k: v.to(d) for k, v in fix["zs"].items()}
+    rand = {k: v.to(d) for k, v in fix["rand"].items()}
+    out = []
+    for fp in (None, 50):
+        for p in G.parameters():
+            p.grad = None
+        imgs, _ = G(zs, img_size=fix["img_size"], nerf_noise=fix["nerf_noise"], return_aux_img=fix["aux"],
+                    grad_points=fix["grad_points"], forward_points=fp, rand_override=rand, **fix["G_kwargs"])
+        (imgs * fix["G0"].to(d)).sum().backward()
+        out.append((imgs.detach().clone(), {n: p.grad.clone() for n, p in G.named_parameters() if p.grad is not None}))
+    assert torch.equal(out[0][0], out[1][0])
+    assert out[0][1].keys() == out[1][1].keys() and all(torch.equal(out[0][1][k], out[1][1][k]) for k in out[0][1])
+    assert max_rel(out[0][0].cpu(), fix["imgs"]) < TOL
+
+
 @pytest.mark.parametrize("tag", CASES)
 def test_generator_matches_reference_golden(tag, inr_mode):
     """Images within 1e-3 of the reference; parameter gradients within 1e-3 of the reference for the SAME LeakyReLU
