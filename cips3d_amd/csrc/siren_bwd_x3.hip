@@ -416,6 +416,7 @@ struct BwdX3Args {
   RayGen rg;      // points == NULL: the points are generated from the ray parameters (point index = ray * S + s)
   unsigned short* da2_hi;   // SPLIT form: da2 planes, da2_rows rows of 256 B per image (siren_bwd_tail.inc)
   unsigned short* da2_lo;
+  float* da2_pts;           // float4 per (padded) point: x, y, z, 0
   long long da2_rows;
 };
 constexpr int GP_G1 = 0, GP_GC = H * H, GP_GF0 = GP_GC + HC * H, GP_GF1 = GP_GF0 + CF * HC, GPART = GP_GF1 + CF * HC;
@@ -892,7 +893,7 @@ static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points,
 extern "C" long long cips_siren_bwd_x3_workspace(int B, int P) {
   if (B <= 0 || P <= 0) return 0;
   const int chunk = x3_chunk(B, P);
-  return 2ll * B * ((P + chunk - 1) / chunk) * chunk * 256;       // da2 hi + lo planes, 256 B per (padded) point
+  return (long long)B * ((P + chunk - 1) / chunk) * chunk * (2 * 256 + 16);       // da2 hi + lo planes + the points, per (padded) point
 }
 
 extern "C" int cips_siren_bwd_x3(const cips_siren_weights* w, const float* points, const float* dfeat,
@@ -945,7 +946,7 @@ static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points,
   }
   const bool hw = (w->trig_mode & 1) != 0;
   if (!workspace) {
-    a.da2_hi = a.da2_lo = nullptr; a.da2_rows = 0;
+    a.da2_hi = a.da2_lo = nullptr; a.da2_pts = nullptr; a.da2_rows = 0;
     if (hw) hipLaunchKernelGGL((siren_bwd_x4_kernel<true, false>), grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((siren_bwd_x4_kernel<false, false>), grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
     return CIPS_CHECK_LAUNCH();
@@ -954,13 +955,14 @@ static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points,
   a.da2_rows = (long long)a.chunks * a.chunk;
   a.da2_hi = reinterpret_cast<unsigned short*>(workspace);
   a.da2_lo = a.da2_hi + (long long)B * a.da2_rows * 128;
+  a.da2_pts = reinterpret_cast<float*>(a.da2_lo + (long long)B * a.da2_rows * 128);
   if (hw) hipLaunchKernelGGL((siren_bwd_x4_kernel<true, true>), grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((siren_bwd_x4_kernel<false, true>), grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
   int rc = CIPS_CHECK_LAUNCH();
   if (rc) return rc;
   TailArgs ta;
-  ta.w = *w; ta.points = points; ta.da2_hi = a.da2_hi; ta.da2_lo = a.da2_lo; ta.da2_rows = a.da2_rows;
-  ta.sred = sred; ta.gpart = gpart; ta.B = B; ta.P = P; ta.chunk = a.chunk; ta.chunks = a.chunks; ta.rg = a.rg;
+  ta.w = *w; ta.da2_hi = a.da2_hi; ta.da2_lo = a.da2_lo; ta.da2_pts = a.da2_pts; ta.da2_rows = a.da2_rows;
+  ta.sred = sred; ta.gpart = gpart; ta.B = B; ta.P = P; ta.chunk = a.chunk; ta.chunks = a.chunks;
   if (hw) hipLaunchKernelGGL(siren_bwd_tail_kernel<true>, grid, dim3(512), T_SMEM, (hipStream_t)stream, ta);
   else hipLaunchKernelGGL(siren_bwd_tail_kernel<false>, grid, dim3(512), T_SMEM, (hipStream_t)stream, ta);
   return CIPS_CHECK_LAUNCH();
