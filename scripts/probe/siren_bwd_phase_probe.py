@@ -23,7 +23,7 @@ def inputs(b, seed=0):
 
 names = ["L0+L1", "film2", "Lc+filmc", "dWf", "dhc+dac", "dWc", "dh2(+dh1)", "da1 tail", "dW1"]
 ops.TRIG_MODE = 1
-for b in (4, 32):
+for b in (32,):
     pts, t, df, ds = inputs(b)
     for split in (False, True):
         ops.SIREN_BWD_SPLIT = split
