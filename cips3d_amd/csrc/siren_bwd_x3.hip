@@ -963,8 +963,12 @@ static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points,
   TailArgs ta;
   ta.w = *w; ta.da2_hi = a.da2_hi; ta.da2_lo = a.da2_lo; ta.da2_pts = a.da2_pts; ta.da2_rows = a.da2_rows;
   ta.sred = sred; ta.gpart = gpart; ta.B = B; ta.P = P; ta.chunk = a.chunk; ta.chunks = a.chunks;
-  if (hw) hipLaunchKernelGGL(siren_bwd_tail_kernel<true>, grid, dim3(512), T_SMEM, (hipStream_t)stream, ta);
-  else hipLaunchKernelGGL(siren_bwd_tail_kernel<false>, grid, dim3(512), T_SMEM, (hipStream_t)stream, ta);
+  ta.prof = nullptr;
+#ifdef CIPS_TUNING
+  if (cips_tune_env("CIPS_X3_PROF", 0) == 2) { ta.prof = a.prof; a.prof = nullptr; }      // 2: stamp the tail kernel instead of the chain
+#endif
+  if (hw) hipLaunchKernelGGL(siren_bwd_tail_kernel<true>, grid, dim3(256), T_SMEM, (hipStream_t)stream, ta);
+  else hipLaunchKernelGGL(siren_bwd_tail_kernel<false>, grid, dim3(256), T_SMEM, (hipStream_t)stream, ta);
   return CIPS_CHECK_LAUNCH();
 }
 
