@@ -103,10 +103,9 @@ SIGNATURES = {
     "cips_siren_bwd_x3_chunks": (i32, [i32, i32]),
     "cips_siren_bwd_x3_gpart": (i32, []),
     "cips_siren_bwd_x3_sred": (i32, []),
-    "cips_siren_bwd_x3_workspace": (C.c_longlong, [i32, i32]),
-    "cips_siren_bwd_x3": (i32, [C.POINTER(SirenWeights), vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "cips_siren_bwd_x3": (i32, [C.POINTER(SirenWeights), vp, vp, vp, vp, vp, i32, i32, vp]),
     "cips_siren_fwd_x3_rays": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, vp, vp, i32, vp]),
-    "cips_siren_bwd_x3_rays": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, vp, vp, vp, i32, vp, vp]),
+    "cips_siren_bwd_x3_rays": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, vp, vp, vp, i32, vp]),
     "cips_siren_bwd_x3_finalize": (i32, [C.POINTER(SirenWeights), vp, vp, i32, i32, C.POINTER(SirenGrads), vp]),
     "cips_march_fwd_x3": (i32, [C.POINTER(SirenWeights), C.POINTER(RayParams), vp, f32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "cips_siren_bwd_data": (i32, [C.POINTER(SirenWeights)] + [vp] * 14 + [i32, i32, vp]),

@@ -414,10 +414,6 @@ struct BwdX3Args {
   unsigned long long* prof;
   int dbg;        // timing attribution, probe builds only (-DCIPS_TUNING, env CIPS_X3_DBG): bit0/1/2 skip the dWf / dWc / dW1 phases
   RayGen rg;      // points == NULL: the points are generated from the ray parameters (point index = ray * S + s)
-  unsigned short* da2_hi;   // SPLIT form: da2 planes, da2_rows rows of 256 B per image (siren_bwd_tail.inc)
-  unsigned short* da2_lo;
-  float* da2_pts;           // float4 per (padded) point: x, y, z, 0
-  long long da2_rows;
 };
 constexpr int GP_G1 = 0, GP_GC = H * H, GP_GF0 = GP_GC + HC * H, GP_GF1 = GP_GF0 + CF * HC, GPART = GP_GF1 + CF * HC;
 constexpr int SRED = 4 * 32 * 8 + 8;   // per wave a 32x8 tile of column sums, then 4 per-wave sums of dsigma (+ pad)
@@ -547,7 +543,6 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
 #endif
 
 #include "siren_bwd_x4.inc"
-#include "siren_bwd_tail.inc"
 
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -888,31 +883,24 @@ extern "C" int cips_siren_bwd_x3_sred(void) { return SRED; }
 
 static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points, const cips_ray_params* rays,
                                const float* dfeat, const float* dsigma, float* sred, float* gpart, int B, int P,
-                               void* workspace, cips_stream_t stream);
-
-extern "C" long long cips_siren_bwd_x3_workspace(int B, int P) {
-  if (B <= 0 || P <= 0) return 0;
-  const int chunk = x3_chunk(B, P);
-  return (long long)B * ((P + chunk - 1) / chunk) * chunk * (2 * 256 + 16);       // da2 hi + lo planes + the points, per (padded) point
-}
+                               cips_stream_t stream);
 
 extern "C" int cips_siren_bwd_x3(const cips_siren_weights* w, const float* points, const float* dfeat,
-                                 const float* dsigma, float* sred, float* gpart, int B, int P, void* workspace,
+                                 const float* dsigma, float* sred, float* gpart, int B, int P,
                                  cips_stream_t stream) {
   if (!points) return (int)hipErrorInvalidValue;
-  return siren_bwd_x3_launch(w, points, nullptr, dfeat, dsigma, sred, gpart, B, P, workspace, stream);
+  return siren_bwd_x3_launch(w, points, nullptr, dfeat, dsigma, sred, gpart, B, P, stream);
 }
 
 extern "C" int cips_siren_bwd_x3_rays(const cips_siren_weights* w, const cips_ray_params* rays, const float* dfeat,
-                                      const float* dsigma, float* sred, float* gpart, int B, void* workspace,
-                                      cips_stream_t stream) {
+                                      const float* dsigma, float* sred, float* gpart, int B, cips_stream_t stream) {
   if (!rays) return (int)hipErrorInvalidValue;
-  return siren_bwd_x3_launch(w, nullptr, rays, dfeat, dsigma, sred, gpart, B, rays->W * rays->H * rays->S, workspace, stream);
+  return siren_bwd_x3_launch(w, nullptr, rays, dfeat, dsigma, sred, gpart, B, rays->W * rays->H * rays->S, stream);
 }
 
 static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points, const cips_ray_params* rays,
                                const float* dfeat, const float* dsigma, float* sred, float* gpart, int B, int P,
-                               void* workspace, cips_stream_t stream) {
+                               cips_stream_t stream) {
   if (!w || !dfeat || !dsigma || !sred || !gpart || B <= 0 || P <= 0) return (int)hipErrorInvalidValue;
   BwdX3Args a;
   a.w = *w; a.points = points; a.dfeat = dfeat; a.dsigma = dsigma; a.sred = sred; a.gpart = gpart;
@@ -936,39 +924,14 @@ static int siren_bwd_x3_launch(const cips_siren_weights* w, const float* points,
   static bool attr4 = false;
   CIPS_PER_DEVICE(attr4, false);
   if (!attr4) {
-    (void)hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void*)siren_bwd_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_SMEM);
-    (void)hipFuncSetAttribute((const void*)siren_bwd_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_SMEM);
+    hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipFuncSetAttribute((const void*)siren_bwd_x4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     attr4 = true;
   }
-  const bool hw = (w->trig_mode & 1) != 0;
-  if (!workspace) {
-    a.da2_hi = a.da2_lo = nullptr; a.da2_pts = nullptr; a.da2_rows = 0;
-    if (hw) hipLaunchKernelGGL((siren_bwd_x4_kernel<true, false>), grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((siren_bwd_x4_kernel<false, false>), grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
-    return CIPS_CHECK_LAUNCH();
-  }
-  // split form: the chain up to da2 (planes into the workspace), then the contraction over points
-  a.da2_rows = (long long)a.chunks * a.chunk;
-  a.da2_hi = reinterpret_cast<unsigned short*>(workspace);
-  a.da2_lo = a.da2_hi + (long long)B * a.da2_rows * 128;
-  a.da2_pts = reinterpret_cast<float*>(a.da2_lo + (long long)B * a.da2_rows * 128);
-  if (hw) hipLaunchKernelGGL((siren_bwd_x4_kernel<true, true>), grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((siren_bwd_x4_kernel<false, true>), grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
-  int rc = CIPS_CHECK_LAUNCH();
-  if (rc) return rc;
-  TailArgs ta;
-  ta.w = *w; ta.da2_hi = a.da2_hi; ta.da2_lo = a.da2_lo; ta.da2_pts = a.da2_pts; ta.da2_rows = a.da2_rows;
-  ta.sred = sred; ta.gpart = gpart; ta.B = B; ta.P = P; ta.chunk = a.chunk; ta.chunks = a.chunks;
-  ta.prof = nullptr;
-#ifdef CIPS_TUNING
-  if (cips_tune_env("CIPS_X3_PROF", 0) == 2) { ta.prof = a.prof; a.prof = nullptr; }      // 2: stamp the tail kernel instead of the chain
-#endif
-  if (hw) hipLaunchKernelGGL(siren_bwd_tail_kernel<true>, grid, dim3(256), T_SMEM, (hipStream_t)stream, ta);
-  else hipLaunchKernelGGL(siren_bwd_tail_kernel<false>, grid, dim3(256), T_SMEM, (hipStream_t)stream, ta);
+  if (w->trig_mode & 1)
+    hipLaunchKernelGGL(siren_bwd_x4_kernel<true>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(siren_bwd_x4_kernel<false>, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
   return CIPS_CHECK_LAUNCH();
 }
 

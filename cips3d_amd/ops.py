@@ -173,7 +173,6 @@ def _split_k(P, target=8):
 # class); "f32": exact fp32 MFMA.  Backward "x3": fused split-bf16 kernel; "staged": fp32 data pass + GEMMs.
 SIREN_FWD_MODE = __import__("os").environ.get("CIPS_SIREN_FWD", "x3")
 SIREN_BWD_MODE = __import__("os").environ.get("CIPS_SIREN_BWD", "x3")
-SIREN_BWD_SPLIT = True    # EXPERIMENT (round 5): chain kernel up to da2 + contraction-over-points tail kernel; False: one kernel
 
 
 class SirenFunction(torch.autograd.Function):
@@ -228,14 +227,12 @@ def _siren_backward(t, dfeat, dsigma, B, P, points=None, rays=None):
             sw_ = lib.cips_siren_bwd_x3_sred()
             sred = torch.empty(B * chunks, sw_, device=dev)
             gpart = torch.empty(B * chunks, gw, device=dev)
-            # da2 planes between the two launches (512 B per point; freed when this function returns)
-            ws = torch.empty(lib.cips_siren_bwd_x3_workspace(B, P), dtype=torch.uint8, device=dev) if SIREN_BWD_SPLIT else None
             if points is not None:
                 check(lib.cips_siren_bwd_x3(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(sred), _p(gpart), B, P,
-                                            _p(ws), _stream()), "cips_siren_bwd_x3")
+                                            _stream()), "cips_siren_bwd_x3")
             else:
                 check(lib.cips_siren_bwd_x3_rays(C.byref(sw), C.byref(rays), _p(dfeat), _p(dsigma), _p(sred), _p(gpart), B,
-                                                 _p(ws), _stream()), "cips_siren_bwd_x3_rays")
+                                                 _stream()), "cips_siren_bwd_x3_rays")
             # the 16 gradient tensors from the partials in one launch (was ~40 tiny torch reductions)
             from ._lib import SirenGrads
             shapes = dict(dg0=(B, 128), dp0=(B, 128), dg1=(B, 128), dp1=(B, 128), dgc=(B, 64), dpc=(B, 64), dw0=(128, 3),

@@ -102,11 +102,8 @@ int cips_siren_fwd_x3(const cips_siren_weights* w, const float* points, float* f
                       int B, int P, cips_stream_t stream);
 
 /* Backward, fused bf16x3 form (default): forward recompute, data gradients, all three weight-gradient
- * contractions and every per-feature sum over points on v_mfma_f32_32x32x16_bf16 with 3-pass split operands (fp32
- * accumulate).  Two launches (ABI 6): the register chain up to da2 = d loss / d (sine argument of layer 1), which it
- * writes as split-bf16 planes into `workspace` (cips_siren_bwd_x3_workspace(B,P) bytes of device memory, 512 B per
- * point; contents undefined on return), then a contraction over points for dW1, d h1, the layer-0 sums and sum_p da2.
- * No other activation is staged in HBM.
+ * contractions and every per-feature sum over points in one kernel on v_mfma_f32_32x32x16_bf16 with 3-pass
+ * split operands (fp32 accumulate); no activation staging in HBM.
  * chunks = cips_siren_bwd_x3_chunks(B,P) workgroups per image; partials of image b are rows
  * [b*chunks, (b+1)*chunks) of both outputs:
  *   sred  (B*chunks, cips_siren_bwd_x3_sred())  floats [wave w=0..3][row 0..31][col 0..7], then 4 per-wave
@@ -121,10 +118,8 @@ int cips_siren_fwd_x3(const cips_siren_weights* w, const float* points, float* f
 int cips_siren_bwd_x3_chunks(int B, int P);
 int cips_siren_bwd_x3_gpart(void);
 int cips_siren_bwd_x3_sred(void);
-long long cips_siren_bwd_x3_workspace(int B, int P);
 int cips_siren_bwd_x3(const cips_siren_weights* w, const float* points, const float* dfeat,
-                      const float* dsigma, float* sred, float* gpart, int B, int P, void* workspace,
-                      cips_stream_t stream);
+                      const float* dsigma, float* sred, float* gpart, int B, int P, cips_stream_t stream);
 
 /* The 16 gradient tensors of the SIREN from the fused backward's per-workgroup partials, in one launch (chain rule of
  * exp/comm/models/film_layer.py:88-107): per-image FiLM gradients dg* / dp* (B,128 | B,64) and the batch-summed weight /
@@ -156,7 +151,7 @@ int cips_siren_fwd_x3_rays(const cips_siren_weights* w, const cips_ray_params* r
 
 /* cips_siren_bwd_x3 with the points generated in-kernel from `rays` (P = H*W*S points per image). */
 int cips_siren_bwd_x3_rays(const cips_siren_weights* w, const cips_ray_params* rays, const float* dfeat,
-                           const float* dsigma, float* sred, float* gpart, int B, void* workspace, cips_stream_t stream);
+                           const float* dsigma, float* sred, float* gpart, int B, cips_stream_t stream);
 
 /* Fused ray-march for NON-hierarchical sampling: ray set-up + FiLM-SIREN + alpha-composite in one kernel that walks
  * the samples along the ray (a wave owns 32 rays, one lane pair per ray; the running transmittance / feature / depth
