@@ -70,7 +70,9 @@ typedef struct cips_siren_weights {
   const float* gc;  /* (B,64)  */
   const float* pc;  /* (B,64)  */
   float box_scale;  /* 2/0.24 (UniformBoxWarp) */
-  int trig_mode;    /* 0: Cody-Waite + minimax polynomial sin/cos (default); 1: v_sin_f32/v_cos_f32 */
+  int trig_mode;    /* bit 0: 0 = Cody-Waite + minimax polynomial sin/cos, 1 = v_sin_f32 / v_cos_f32 (what the Python layer passes);
+                       bit 1 (x3 forward kernels only): bf16 operand planes (2^-17) instead of the default fp16 planes (2^-22) —
+                       kept for the A/B of tests/test_gpu_kernels.py::test_siren_forward_x3_sigma_is_fp32_class */
 } cips_siren_weights;
 
 /* points (B,P,3) -> feat (B,P,32), sigma (B,P). */
