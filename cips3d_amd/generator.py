@@ -802,7 +802,8 @@ class GeneratorNerfINR(nn.Module):
                         h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise, white_back,
                         last_back, return_aux_img, forward_points, rand_override=None, grad_points=None, **cam):
         try:
-            if forward_points is not None:
+            part = grad_points is not None and grad_points < img_size ** 2       # generator.py:1325: part_grad_forward, forward_points unused
+            if forward_points is not None and not part:
                 with torch.no_grad():
                     return self._render(style_dict, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                                         h_mean, v_mean, hierarchical_sample, sample_dist, clamp_mode, nerf_noise,
