@@ -505,18 +505,11 @@ def main():
         # ~570 kernel launches per step: capture latents (graph-safe Philox RNG: fresh draws per replay) + forward +
         # backward once, replay per step; the gradient all-reduce stays outside the graph.  Eager on any capture error.
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    fwd_bwd()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            # with a process group up, RCCL's watchdog thread may touch the HIP runtime while this thread captures:
-            # only this thread's calls belong to the capture
-            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
-                fwd_bwd()
+            # the product's capture helper (cips3d_amd/graph.py): two eager warm-up calls on a side stream, then the capture;
+            # with a process group up, RCCL's watchdog thread may touch the HIP runtime while this thread captures, so only
+            # this thread's calls belong to the capture (thread_local)
+            from cips3d_amd.graph import capture
+            graph = capture(fwd_bwd, warmup=2, thread_local=world > 1)
         except Exception as e:                      # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
