@@ -1056,6 +1056,18 @@ class Discriminator_MultiScale(nn.Module):
         return out, None, None
 
 
+AUX_SIDE_STREAM = True
+_AUX_STREAMS = {}
+
+
+def _aux_stream(device):
+    key = torch.device(device).index
+    st = _AUX_STREAMS.get(key)
+    if st is None:
+        st = _AUX_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class Discriminator_MultiScale_Aux(nn.Module):
     """discriminator.py:589-664"""
 
@@ -1077,8 +1089,24 @@ class Discriminator_MultiScale_Aux(nn.Module):
     def forward(self, input, use_aux_disc=False, summary_ddict=None, alpha=1., **kwargs):
         if use_aux_disc:
             b = input.shape[0] // 2
-            main_out, latent, position = self.main_disc(input[:b], alpha, summary_ddict=summary_ddict)
-            aux_out, _, _ = self.aux_disc(input[b:], alpha)
+            if AUX_SIDE_STREAM and input.is_cuda:
+                # EXPERIMENT (round 5): the two discriminators are independent networks on different halves of the batch; the
+                # auxiliary one (256 channels at half resolution: grids that do not fill 256 CUs) runs on a side stream next to
+                # the main one.  autograd keeps every node on its forward's stream, so both backward passes overlap as well.
+                cur = torch.cuda.current_stream(input.device)
+                side = _aux_stream(input.device)
+                side.wait_stream(cur)
+                input.record_stream(side)
+                # main first in program order (the gate tapes of the parity tests record in call order; the host runs ahead of
+                # the GPU either way, so the auxiliary launches are queued long before the main network's kernels have run)
+                main_out, latent, position = self.main_disc(input[:b], alpha, summary_ddict=summary_ddict)
+                with torch.cuda.stream(side):
+                    aux_out, _, _ = self.aux_disc(input[b:], alpha)
+                cur.wait_stream(side)
+                aux_out.record_stream(cur)
+            else:
+                main_out, latent, position = self.main_disc(input[:b], alpha, summary_ddict=summary_ddict)
+                aux_out, _, _ = self.aux_disc(input[b:], alpha)
             out = torch.cat([main_out, aux_out], dim=0)
         else:
             out, latent, position = self.main_disc(input, alpha, summary_ddict=summary_ddict)
