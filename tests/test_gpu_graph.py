@@ -40,3 +40,41 @@ def test_captured_generator_step_replays_the_eager_gradients():
         assert (p.grad is None) == (g is None)
         if g is not None:
             assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-9), float((p.grad - g).abs().max())
+
+
+def test_captured_discriminator_step_with_the_auxiliary_stream_replays_the_eager_gradients():
+    """Discriminator_MultiScale_Aux forks its auxiliary network onto a side stream inside forward(): under capture the fork and the
+    join (and autograd's per-stream backward, R1 double backward included) must all land in the one graph."""
+    import torch.nn.functional as F
+    from cips3d_amd.graph import capture
+    from cips3d_amd import discriminator as dmod
+    from conftest import D_CFG
+    d = torch.device("cuda:0")
+    assert dmod.AUX_SIDE_STREAM
+    torch.manual_seed(3)
+    D = dmod.Discriminator_MultiScale_Aux(**D_CFG).to(d)
+    g = torch.Generator().manual_seed(1)
+    x_static = torch.randn(4, 3, 16, 16, generator=g).to(d)
+    params = list(D.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        x = x_static.detach().requires_grad_(True)
+        out, _, _ = D(x, alpha=1.0, use_aux_disc=True)
+        gr, = torch.autograd.grad(outputs=out.sum(), inputs=x, create_graph=True)
+        (F.softplus(-out).mean() + 5.0 * gr.flatten(1).pow(2).sum(1).mean()).backward()
+
+    step()
+    torch.cuda.synchronize()
+    eager = [None if p.grad is None else p.grad.detach().clone() for p in params]
+    cs = capture(step, warmup=1, params=params)
+    cs(); cs()
+    torch.cuda.synchronize()
+    n = 0
+    for p, e in zip(params, eager):
+        assert (p.grad is None) == (e is None)
+        if e is not None:
+            n += 1
+            assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-8), float((p.grad - e).abs().max())
+    assert n > 20
