@@ -190,3 +190,19 @@ def test_checkpoint_nested_optimizer_state_and_wrapped_payload(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net4.state_dict().values()))
     with pytest.raises(KeyError):
         Checkpointer(net4).load_state_dict_from_file(p2, key="discriminator")
+
+
+def test_graph_capture_and_side_streams_fail_loudly_or_stay_inline_without_a_gpu():
+    """No CPU path: the capture helper refuses; the discriminator's side stream is only taken for GPU tensors (module construction
+    and the switch itself need no GPU)."""
+    import pytest
+    import torch
+    from cips3d_amd import graph, discriminator
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side behaviour")
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        graph.capture(lambda: None)
+    assert discriminator.AUX_SIDE_STREAM is True
+    D = discriminator.Discriminator_MultiScale_Aux(diffaug=False, max_size=64, channel_multiplier=2, first_downsample=False, stddev_group=0)
+    with pytest.raises(RuntimeError):                       # CPU tensors reach the HIP-only operators in line, and those refuse
+        D(torch.zeros(2, 3, 16, 16), alpha=1.0, use_aux_disc=True)
