@@ -217,6 +217,51 @@ def head_gemm_in_situ(fwd_bwd, b, n, reps=3):
                    "launch of the fused flavours included in its pair)"}
 
 
+def power_sample(run_step, seconds=1.5):
+    """Socket power and shader clock while the benchmarked step replays (AFTER the timed region: a separate loop of `seconds`,
+    sampled by a thread through rocm-smi).  -> dict or None when rocm-smi is not there.  Evidence, in the run's own line, for what
+    profiles/r5_power_envelope.txt measured with a dedicated probe: the step runs against the board's power limit."""
+    import re, shutil, subprocess, threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+
+    def one():
+        try:
+            out = subprocess.run([smi, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+            c = next(iter(json.loads(out[out.index("{"):]).values()))
+            pw = [float(v) for k, v in c.items() if "ower" in k and "(W)" in k]
+            sc = [int(re.sub(r"[^0-9]", "", v)) for k, v in c.items() if k.lower().startswith("sclk clock speed")]
+            return (pw[0] if pw else None), (sc[0] if sc else None)
+        except Exception:                           # noqa: BLE001
+            return None, None
+
+    try:
+        cap = subprocess.run([smi, "--showmaxpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+        capw = [float(v) for v in next(iter(json.loads(cap[cap.index("{"):]).values())).values()]
+    except Exception:                               # noqa: BLE001
+        capw = []
+    samples, stop = [], threading.Event()
+    th = threading.Thread(target=lambda: [samples.append(one()) for _ in iter(stop.is_set, True)])
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            run_step()
+        torch.cuda.synchronize()
+        n += 10
+    dt = time.perf_counter() - t0
+    stop.set(); th.join()
+    pw = [p for p, _ in samples if p is not None]
+    sc = [c for _, c in samples if c is not None]
+    if not pw and not sc:
+        return None
+    return {"board_power_limit_w": capw[0] if capw else None, "socket_power_w": [min(pw), max(pw)] if pw else None,
+            "sclk_mhz": [min(sc), max(sc)] if sc else None, "samples": len(samples), "steps": n,
+            "ms_per_step_while_sampling": round(dt / n * 1e3, 3),
+            "how": "rocm-smi --showpower --showclocks sampled by a thread during a separate replay loop after the timed region"}
+
+
 def cpu_baseline(img_size, S, hier):
     """Oracle (CPU restatement of the reference path, kind 'port': /root/reference does not exist on the GPU box) on
     this host's cores, bounded sample per SURVEY.md §8d: b=4 images at the bench geometry (b=32 needs ~20 GB of
@@ -678,6 +723,11 @@ def main():
             except Exception:                       # noqa: BLE001
                 pass
             line["roofline"] = r
+        if world == 1 and not a.no_roofline:
+            try:
+                line["power"] = power_sample(step)
+            except Exception as e:                      # noqa: BLE001
+                line["power"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(img, S, a.hier)
             try:
