@@ -179,10 +179,14 @@ class NeRFNetwork(nn.Module):
     def __init__(self, in_dim=3, hidden_dim=256, hidden_layers=2, style_dim=512, rgb_dim=3, device=None,
                  name_prefix='nerf', **kwargs):
         super().__init__()
-        if not (in_dim == 3 and hidden_dim == 128 and hidden_layers == 2 and rgb_dim == 32):
+        if not (in_dim == 3 and rgb_dim == 32 and hidden_layers >= 1):
             raise NotImplementedError(
-                "the fused SIREN kernel is specialised for the shipped configs "
-                "(in 3, hidden 128, 2 layers, rgb_dim 32; ffhq_exp.yaml:51-58)")
+                "the ray set-up produces 3-vectors and the composite / CIPS head take 32 colour features "
+                "(in_dim 3, rgb_dim 32: every shipped config, ffhq_exp.yaml:51-58)")
+        # the fused SIREN kernels hold exactly the shipped matrices in LDS (hidden 128, two FiLM layers); any other width or depth
+        # runs the same arithmetic as plain GPU tensor operations (hipBLASLt linears + elementwise sine, torch autograd) through
+        # the unfused rays -> SIREN -> composite path: functional parity with the reference module, not its speed
+        self.fused = hidden_dim == 128 and hidden_layers == 2
         self.device = device
         self.in_dim, self.hidden_dim, self.rgb_dim = in_dim, hidden_dim, rgb_dim
         self.style_dim, self.hidden_layers, self.name_prefix = style_dim, hidden_layers, name_prefix
@@ -207,8 +211,25 @@ class NeRFNetwork(nn.Module):
         self.module_name_list.append('color_layer_linear')
         self.dim_styles = sum(self.style_dim_dict.values())
 
+    def _evaluate_unfused(self, points, style_dict):
+        """generator.py:260-317 for any hidden width / depth: UniformBoxWarp (x 2 / 0.24), FiLM sine layers
+        (film_layer.py:78-107: sin(gain * linear(x) + bias)), sigma head, colour sine layer, colour linear."""
+        if not points.is_cuda:
+            raise RuntimeError("NeRFNetwork runs on the GPU only (there is no CPU path)")
+        p = self.name_prefix
+        x = points * (2.0 / 0.24)
+        for idx, layer in enumerate(self.network):
+            gain, bias = layer.film(style_dict[f'{p}_w{idx}'])
+            x = torch.sin(gain.unsqueeze(1) * layer.linear(x) + bias.unsqueeze(1))
+        sigma = self.final_layer(x).squeeze(-1)
+        gain, bias = self.color_layer_sine.film(style_dict[f'{p}_rgb'])
+        c = torch.sin(gain.unsqueeze(1) * self.color_layer_sine.linear(x) + bias.unsqueeze(1))
+        return self.color_layer_linear(c), sigma
+
     def evaluate(self, points, style_dict):
-        """points (b,P,3) -> feat (b,P,32), sigma (b,P) via the fused HIP kernel."""
+        """points (b,P,3) -> feat (b,P,32), sigma (b,P) via the fused HIP kernel (shipped shape) or tensor operations."""
+        if not self.fused:
+            return self._evaluate_unfused(points, style_dict)
         p = self.name_prefix
         (g0, p0), (g1, p1), (gc, pc) = _film_all([self.network[0], self.network[1], self.color_layer_sine],
                                                  [style_dict[f'{p}_w0'], style_dict[f'{p}_w1'], style_dict[f'{p}_rgb']])
@@ -671,10 +692,10 @@ class GeneratorNerfINR(nn.Module):
             zc = float((-torch.ones(1) / np.tan((2 * math.pi * fov / 360) / 2)).item())
             # non-hierarchical sampling of whole images: rays + SIREN + composite fused in one kernel that walks the
             # samples along each ray (ops.RayMarchFunction); no (b,n,S,3) points, no per-sample features in HBM
-            fused = (not hierarchical_sample) and (not part) and ops.march_available()
+            fused = (not hierarchical_sample) and (not part) and ops.march_available() and self.siren.fused
             # hierarchical sampling of whole images: both SIREN passes and the resampler regenerate rays / points
             # in-kernel (no rays kernel, no (b,n,S,3) point tensors for either pass)
-            gen_rays = hierarchical_sample and (not part) and ops.march_available()
+            gen_rays = hierarchical_sample and (not part) and ops.march_available() and self.siren.fused
             if not fused and not gen_rays:
                 points, z_vals, dirs = ops.rays_fwd(xg, yg, zg, zc, cam2world, jitter.reshape(b, n, S), b, H, W, S)
             ray_origins = origin if pitch_yaw_fused is not None else cam2world[:, :3, 3].contiguous()       # every ray starts at the camera

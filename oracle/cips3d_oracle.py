@@ -183,8 +183,10 @@ def film(sd, prefix, x, style):
 def siren(sd, points, w_nerf, prefix="siren."):
     """points (b,P,3), w_nerf (b,128) -> (b,P,33) = [feat(32), sigma(1)]."""
     x = points * (2 / 0.24)
-    x = film(sd, prefix + "network.0.", x, w_nerf)
-    x = film(sd, prefix + "network.1.", x, w_nerf)
+    idx = 0
+    while prefix + f"network.{idx}.linear.weight" in sd:          # generator.py:287: `for index, layer in enumerate(self.network)`
+        x = film(sd, prefix + f"network.{idx}.", x, w_nerf)
+        idx += 1
     sigma = F.linear(x, sd[prefix + "final_layer.weight"], sd[prefix + "final_layer.bias"])
     c = film(sd, prefix + "color_layer_sine.", x, w_nerf)
     feat = F.linear(c, sd[prefix + "color_layer_linear.0.weight"], sd[prefix + "color_layer_linear.0.bias"])
