@@ -153,10 +153,15 @@ class GradAllReducer:
     def _on_grad(self, p):
         """post-accumulate-grad hook (overlap mode): count the gradient in; issue every bucket that is complete"""
         i = self._index[id(p)]
-        if i in self._seen:                  # a second backward before __call__: not supported in overlap mode
-            self._dirty = True
+        planned = self._buckets is not None and dist.is_initialized()
+        if i in self._seen and planned:
+            # a second backward before __call__ (gradient accumulation, train.py:466's batch_split loop): the buckets of this
+            # step went out with the first backward's gradients, so what arrives now cannot be told from a LATE gradient and
+            # the result would be mean(g1) + mean(g1 + g2) (ADVICE r5: measured 40 % off).  Refuse instead of mis-reducing.
+            raise RuntimeError("GradAllReducer(overlap=True): a parameter's gradient arrived twice before the reduction — "
+                               "gradient accumulation over several backward passes needs overlap=False")
         self._seen.add(i)
-        if self._buckets is None or not dist.is_initialized():
+        if not planned:
             return
         b = self._bucket_of.get(id(p))
         if b is not None and b < self._next and p.grad is not None:
@@ -190,11 +195,13 @@ class GradAllReducer:
 
     def _issue(self, b):
         bucket = self._buckets[b]
-        for p in bucket:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        grads = [p.grad for p in bucket]
-        dev = grads[0].device
+        # what goes on the wire: this rank's gradient, or a PRIVATE zero vector for a parameter it has none for.  (Round 5
+        # bound zeros to p.grad here: autograd then accumulated a late gradient into the very tensor the side stream's
+        # concatenation was still reading — ADVICE r5, write-after-read across streams — and under create_graph=True
+        # AccumulateGrad rebinds p.grad, which left the copy-back writing an orphan.)  The copy-back looks p.grad up again.
+        dev = bucket[0].device
+        dtype = next((p.grad.dtype for p in bucket if p.grad is not None), bucket[0].dtype)
+        grads = [p.grad if p.grad is not None else None for p in bucket]
         if dev.type == "cuda":
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
@@ -210,14 +217,17 @@ class GradAllReducer:
             with torch.cuda.stream(self._side):
                 for ev in evs:
                     self._side.wait_event(ev)    # the gradients of this bucket are complete on their producing streams
-                sig = torch.full((1,), self._sig_for(grads[0].dtype), device=dev, dtype=grads[0].dtype)
-                flat = torch.cat([g.reshape(-1) for g in grads] + [sig])
+                flat = self._pack(bucket, grads, dtype, dev)
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            sig = torch.full((1,), self._sig_for(grads[0].dtype), device=dev, dtype=grads[0].dtype)
-            flat = torch.cat([g.reshape(-1) for g in grads] + [sig])
+            flat = self._pack(bucket, grads, dtype, dev)
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._inflight.append((flat, work, grads))
+        self._inflight.append((flat, work, bucket))
+
+    def _pack(self, bucket, grads, dtype, dev):
+        sig = torch.full((1,), self._sig_for(dtype), device=dev, dtype=dtype)
+        parts = [g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=dtype, device=dev) for p, g in zip(bucket, grads)]
+        return torch.cat(parts + [sig])
 
     def _drain(self, world):
         """wait for the issued buckets, divide, copy back; returns (bytes, checksum views, expected checksums)"""
@@ -225,15 +235,21 @@ class GradAllReducer:
         dev = self.params[0].device
         ctx = torch.cuda.stream(self._side) if (dev.type == "cuda" and self._side is not None) else _null()
         with ctx:
-            for flat, work, grads in self._inflight:
+            for flat, work, bucket in self._inflight:
                 work.wait()
                 flat.div_(world)
-                views, off = [], 0
-                for g in grads:
-                    n = g.numel()
-                    views.append(flat[off:off + n].view_as(g))
+                dst, views, off = [], [], 0
+                for p in bucket:
+                    n = p.numel()
+                    v = flat[off:off + n].view_as(p)
                     off += n
-                torch._foreach_copy_(grads, views)
+                    if p.grad is None:               # no gradient on this rank: it receives the others' mean
+                        p.grad = v.clone()
+                    else:                            # the tensor p.grad is bound to NOW (autograd may have rebound it)
+                        dst.append(p.grad)
+                        views.append(v)
+                if dst:
+                    torch._foreach_copy_(dst, views)
                 sigs.append(flat[off:off + 1])
                 wants.append(self._sig_for(flat.dtype))
                 nbytes += (flat.numel() - 1) * flat.element_size()
@@ -322,6 +338,11 @@ class GradAllReducer:
         # rank to rank, the sequence "all buckets of the old plan, then the exchange" does not
         late_mine = dict(self._late)
         union, late = self._agree(local, late=late_mine)
+        dev = self.params[0].device
+        if dev.type == "cuda" and self._side is not None:
+            # backward() has returned, so the caller's stream has joined every stream a gradient was produced on — including
+            # the accumulation of a LATE gradient, which no bucket event covers.  The copy-back below must come after it.
+            self._side.wait_stream(torch.cuda.current_stream(dev))
         nbytes, sigs, wants = self._drain(world)
         self._record_sigs(sigs, wants)
         if late:
