@@ -50,6 +50,11 @@ def parse():
                     help="skip the short extra timings of BASELINE's other geometries (C4 at 256x256, C3's per-GPU share, C2 eager)")
     ap.add_argument("--inr-mode", default=None, choices=["bf16x3", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph of the step")
+    ap.add_argument("--rccl", action="store_true",
+                    help="N = 1: bring up a one-rank RCCL process group anyway and run the gradient exchange through it every step "
+                         "(communicator init with device_id, thread-local graph capture beside the watchdog, presence exchange and "
+                         "bucket all-reduce on RCCL's streams) — what a one-GPU box can execute of the N > 1 path; implied when "
+                         "torchrun launched a single rank")
     ap.add_argument("--overlap-reduce", action="store_true",
                     help="N > 1: issue each gradient bucket's all-reduce from autograd hooks while backward is still running "
                          "(implies --no-graph; validated over gloo only: not the default)")
@@ -333,11 +338,14 @@ def full_gan_step(dev, b, img, S, steps=4, warmup=2, freeze=False, diffaug=False
     real = torch.rand(b, 3, img, img, device=dev) * 2 - 1
     # N > 1 (scripts/bench_full_step.py --gpus N): the step exchanges BOTH gradient sets, like the reference's two DDP
     # wrappers (train.py:235-236) — D's after the D backward (~150 MB, three buckets), G's after the G backward (45 MB)
-    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    # (a one-rank group — bench.py --rccl — runs the same exchanges: what a one-GPU box can execute of this path)
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     red_bytes = {"D": 0, "G": 0}
     if dist_on:
         from cips3d_amd.distributed import GradAllReducer
-        red_D, red_G = GradAllReducer(list(D.parameters())), GradAllReducer(list(G.parameters()))
+        one = torch.distributed.get_world_size() == 1
+        red_D = GradAllReducer(list(D.parameters()), single_rank_exchange=one)
+        red_G = GradAllReducer(list(G.parameters()), single_rank_exchange=one)
 
     def d_step():
         for p in G.parameters(): p.requires_grad_(False)
@@ -511,8 +519,14 @@ def main():
                          "(CIPS_BENCH_BACKEND=gloo runs a functional check with ranks sharing devices)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # a process group exists for N > 1, and for N = 1 when asked for (--rccl, or torchrun started the single rank)
+    pg = world > 1 or a.rccl or ("WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ)
+    if pg:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")     # --rccl without a launcher
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -532,10 +546,10 @@ def main():
     b, img = a.batch, a.img_size
     G0 = torch.randn(b, 3, img, img, device=dev) / (b * 3 * img * img)
     params = list(G.parameters())
-    overlap = bool(a.overlap_reduce and world > 1)
+    overlap = bool(a.overlap_reduce and pg)
     if overlap:
         a.no_graph = True                      # hooks run in eager autograd only
-    reduce_grads = GradAllReducer(params, bucket_mb=8.0 if overlap else 64.0, overlap=overlap)
+    reduce_grads = GradAllReducer(params, bucket_mb=8.0 if overlap else 64.0, overlap=overlap, single_rank_exchange=pg and world == 1)
 
     def fwd_bwd():
         zs = G.get_zs(b)
@@ -554,7 +568,7 @@ def main():
             # with a process group up, RCCL's watchdog thread may touch the HIP runtime while this thread captures, so only
             # this thread's calls belong to the capture (thread_local)
             from cips3d_amd.graph import capture
-            graph = capture(fwd_bwd, warmup=2, thread_local=world > 1)
+            graph = capture(fwd_bwd, warmup=2, thread_local=pg)
         except Exception as e:                      # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
@@ -568,7 +582,7 @@ def main():
             graph.replay()
         else:
             fwd_bwd()
-        if world > 1:
+        if pg:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             ar_bytes[0] = reduce_grads() or ar_bytes[0]
@@ -577,7 +591,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if pg:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -602,7 +616,7 @@ def main():
         if record and len(evs) > 1:
             ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1))
             per_step.update(median=ts[len(ts) // 2], min=ts[0], max=ts[-1])
-        if world > 1:
+        if pg:
             t = torch.tensor([dt], device=dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
@@ -630,7 +644,7 @@ def main():
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 g32 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g32, capture_error_mode="thread_local" if world > 1 else "global"):
+                with torch.cuda.graph(g32, capture_error_mode="thread_local" if pg else "global"):
                     fwd_bwd()
             except Exception as e:                  # noqa: BLE001
                 print(f"[bench] hipGraph capture of the fp32-MFMA leg failed ({type(e).__name__}: {e}); eager", file=sys.stderr)
@@ -663,16 +677,16 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"FFHQ r{img}, {E} SIREN evals/ray (num_steps {S}, hierarchical {a.hier}), "
                                f"batch {b}/GPU, G fwd+bwd, all 9 CIPS blocks" + (", NeRF frozen" if a.freeze else ""),
-                   "global_batch": world * b, "parallelism": f"dp{world}", "rccl_ranks": world if backend == "nccl" else 0,
+                   "global_batch": world * b, "parallelism": f"dp{world}", "rccl_ranks": (world if backend == "nccl" else 0) if pg else 0,
                    "inr_gemm_mode": mode,
                    "launch": "hipGraph replay" if use_graph[0] else "eager",
                    "grad_reduce": ("bucketed all-reduce issued from autograd hooks during backward" if overlap else
-                                   "flat-bucket all-reduce after backward") if world > 1 else "none"},
+                                   "flat-bucket all-reduce after backward") if pg else "none"},
         **({"backend_note": f"{backend} functional check, not a measurement"} if backend != "nccl" and world > 1 else {}),
     }
     if exact:
         line["f32_mfma_head_and_siren_forward"] = exact
-    if world > 1 and ar_events:
+    if pg and ar_events:
         # gradient exchange as the stream sees it (events around the all-reduce of every timed step; with the overlapped
         # form this is what is left exposed after the backward): median ms, bytes per rank, ring bus bandwidth
         tail = ar_events[-a.steps:]
@@ -680,7 +694,7 @@ def main():
         med = ts[len(ts) // 2]
         line["allreduce"] = {"ms_median": round(med, 4), "ms_min": round(ts[0], 4), "ms_max": round(ts[-1], 4),
                              "bytes_per_rank": int(ar_bytes[0]),
-                             "bus_GBps": round(ar_bytes[0] * 2 * (world - 1) / world / (med * 1e-3) / 1e9, 2) if med > 0 else None,
+                             "bus_GBps": round(ar_bytes[0] * 2 * (world - 1) / world / (med * 1e-3) / 1e9, 2) if (med > 0 and world > 1) else None,
                              # both terms from this rank's own stream events (median all-reduce / median step)
                              "step_ms_median_events": round(per_step.get("median", ms), 4),
                              "frac_of_step": round(med / max(per_step.get("median", ms), 1e-9), 4)}
@@ -737,7 +751,7 @@ def main():
             except Exception:                       # noqa: BLE001
                 pass
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if pg:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -42,8 +42,12 @@ class GradAllReducer:
     Parameters are NOT filtered by `requires_grad` (train.py:335-336, 441-442 toggle it on G and D
     every step): what takes part is decided per call by which gradients exist."""
 
-    def __init__(self, params, bucket_mb=64.0, group=None, overlap=False):
-        """overlap=True: once a plan exists, a bucket's all-reduce is issued from a post-accumulate-grad hook as soon as
+    def __init__(self, params, bucket_mb=64.0, group=None, overlap=False, single_rank_exchange=False):
+        """single_rank_exchange=True: a group of ONE rank still runs the whole exchange (presence MAX on the control stream,
+        bucket concatenation, all-reduce, copy-back, plan checksum) instead of returning early — the way to execute this
+        code over real RCCL streams on a one-GPU box (bench.py --rccl; the result is the identity).
+
+        overlap=True: once a plan exists, a bucket's all-reduce is issued from a post-accumulate-grad hook as soon as
         the last of its locally expected gradients has arrived (buckets are formed in REVERSE parameter order — roughly
         the order in which backward produces gradients — and issued strictly in bucket order, like DDP's reducer, so
         every rank issues the same sequence of collectives); on a GPU the concatenation, the collective and the copy-back
@@ -56,6 +60,7 @@ class GradAllReducer:
         self.group = group
         self.limit = int(bucket_mb * 1024 * 1024)
         self.overlap = bool(overlap)
+        self.single_rank_exchange = bool(single_rank_exchange)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._bucket_of = {}     # id(param) -> bucket index of the cached plan
         self._expected = []      # per bucket: how many of its parameters THIS rank produces a gradient for
@@ -275,7 +280,7 @@ class GradAllReducer:
         if not dist.is_available() or not dist.is_initialized():
             return 0
         world = dist.get_world_size(self.group)
-        if world == 1:
+        if world == 1 and not self.single_rank_exchange:
             return 0
         self._check_pending()
         if self.overlap and self._buckets is not None:

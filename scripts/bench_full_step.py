@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--torch-optim", action="store_true", help="torch clip_grad_norm_ + Adam + python EMA instead of the fused tail")
     ap.add_argument("--gpus", type=int, default=1, help="N > 1: one rank per GPU over RCCL (CIPS_BENCH_BACKEND=gloo: functional "
                     "check with the ranks sharing the visible devices), both gradient sets all-reduced every step")
+    ap.add_argument("--rccl", action="store_true", help="N = 1: run both gradient exchanges through a one-rank RCCL process group")
     a = ap.parse_args()
     import bench
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -31,7 +32,12 @@ def main():
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     backend = os.environ.get("CIPS_BENCH_BACKEND", "nccl")
-    if world > 1:
+    pg = world > 1 or a.rccl
+    if pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(bench._free_port())
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl" and torch.cuda.device_count() < world:
             raise SystemExit(f"--gpus {world} needs {world} GPUs (CIPS_BENCH_BACKEND=gloo: functional check on fewer)")
         local = local % torch.cuda.device_count()
@@ -42,11 +48,11 @@ def main():
     torch.cuda.set_device(dev)
     res = bench.full_gan_step(dev, a.batch, a.img_size, a.num_steps, steps=a.steps, warmup=a.warmup,
                               freeze=a.freeze, diffaug=a.diffaug, aux=not a.no_aux, torch_optim=a.torch_optim)
-    if world > 1:
+    if pg:
         res["backend"] = backend if backend == "nccl" else f"{backend} (functional check, not a measurement)"
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if pg:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -129,5 +129,7 @@ _ORDER = ["test_gpu_kernels", "test_gpu_generator", "test_gpu_discriminator", "t
 def pytest_collection_modifyitems(session, config, items):
     def key(it):
         mod = os.path.splitext(os.path.basename(str(it.fspath)))[0]
+        if mod == "test_gpu_rccl":               # brings up RCCL communicators in child processes: the very last
+            return len(_ORDER) + 1
         return _ORDER.index(mod) if mod in _ORDER else (len(_ORDER) if mod.startswith("test_gpu") else -1)
     items.sort(key=key)          # stable: order inside a file is kept
