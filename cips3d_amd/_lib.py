@@ -86,6 +86,12 @@ class ConvX3Desc(C.Structure):
                 ("act_scale", f32)]
 
 
+class ConvDgradS2Desc(C.Structure):
+    _fields_ = [("w_hi", vp), ("w_lo", vp), ("dy_hi", vp), ("dy_lo", vp), ("dxp", vp),
+                ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("O", i32), ("kh", i32), ("kw", i32),
+                ("w_off", i64 * 4), ("out_off", i64 * 4)]
+
+
 class ConvWgradDesc(C.Structure):
     _fields_ = [("dy_hi", vp), ("dy_lo", vp), ("x_hi", vp), ("x_lo", vp), ("part", vp),
                 ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("O", i32), ("kh", i32), ("kw", i32),
@@ -132,6 +138,7 @@ SIGNATURES = {
     "cips_split_planes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
     "cips_split_planes_nhwc": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "cips_conv2d_x3_ksplit": (i32, [i32, i32, i32, i32]),
+    "cips_conv2d_x3_dgrad_s2": (i32, [C.POINTER(ConvDgradS2Desc), vp]),
     "cips_conv_wgrad_finish": (i32, [vp, vp, i32, i32, i32, i32, f32, vp]),
     "cips_modfc_prep_x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cips_torgb_fwd_x3": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
@@ -162,6 +169,7 @@ SIGNATURES = {
     "cips_axpby": (i32, [vp, vp, vp, f32, f32, i64, vp]),
     "cips_image_to_u8": (i32, [vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "cips_upfirdn2d": (i32, [vp, vp, vp] + [i32] * 14 + [vp]),
+    "cips_upfirdn2d_parity": (i32, [vp, C.POINTER(i64 * 4), vp, vp] + [i32] * 7 + [vp]),
     "cips_im2col": (i32, [vp, vp] + [i32] * 8 + [vp]),
     "cips_im2col_x3": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cips_col2im": (i32, [vp, vp] + [i32] * 8 + [vp]),

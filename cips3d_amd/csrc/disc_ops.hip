@@ -134,8 +134,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirArgs a) {
 // Thread tile TW x TH outputs.  4 x 4 minimises loads per output (3.1) but neighbouring lanes then read addresses 16 B apart:
 // every wave load touches 1 KiB for 256 useful bytes and the texture path moves 12.5 x the output bytes.  1 x 16 (lanes
 // along x) needs 4.75 loads per output, each fully coalesced: 4.75 x.
-template <int DOWN, int TW, int TH>
-__global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(UpfirArgs a, int bw, int bh) {
+// PAR: the input plane is not stored row-major but as the four parity blocks cips_conv2d_x3_dgrad_s2 writes — pixel (iy, ix) of
+// plane mj lives at blk[iy&1][ix&1] + mj * np[..] + (iy>>1) * ws[ix&1] + (ix>>1).  Only the load address changes: same taps, same order.
+struct ParityIn { const float* blk[4]; int np[4]; int ws[2]; };
+template <int DOWN, int TW, int TH, bool PAR = false>
+__global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(UpfirArgs a, int bw, int bh, ParityIn pin = ParityIn()) {
   constexpr int NX = (TW - 1) * DOWN + 4, NR = (TH - 1) * DOWN + 4;
   float ck[16];
 #pragma unroll
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(UpfirArgs a, int 
     const int rem = (int)(t - mj * per_plane), by = rem / bw, bx = rem - by * bw;
     const int oy0 = by * TH, ox0 = bx * TW;
     const int iyb = oy0 * DOWN - a.pad_y0, ixb = ox0 * DOWN - a.pad_x0;
-    const float* src = a.in + mj * (long long)a.in_h * a.in_w;
+    const float* src = PAR ? nullptr : a.in + mj * (long long)a.in_h * a.in_w;
     int colx[NX];
     bool cok[NX];
 #pragma unroll
@@ -166,10 +169,18 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(UpfirArgs a, int 
     for (int r = 0; r < NR; ++r) {
       const int iy = iyb + r;
       const bool rok = (unsigned)iy < (unsigned)a.in_h;
-      const float* rowp = src + (long long)min(max(iy, 0), a.in_h - 1) * a.in_w;
       float x[NX];
+      if constexpr (PAR) {
+        const int iyc = min(max(iy, 0), a.in_h - 1), pa = iyc & 1, U = iyc >> 1;
+        const float* p0 = pin.blk[2 * pa] + mj * (long long)pin.np[2 * pa] + (long long)U * pin.ws[0];
+        const float* p1 = pin.blk[2 * pa + 1] + mj * (long long)pin.np[2 * pa + 1] + (long long)U * pin.ws[1];
 #pragma unroll
-      for (int i = 0; i < NX; ++i) x[i] = *((rok && cok[i]) ? rowp + colx[i] : zp);
+        for (int i = 0; i < NX; ++i) x[i] = *((rok && cok[i]) ? ((colx[i] & 1) ? p1 : p0) + (colx[i] >> 1) : zp);
+      } else {
+        const float* rowp = src + (long long)min(max(iy, 0), a.in_h - 1) * a.in_w;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = *((rok && cok[i]) ? rowp + colx[i] : zp);
+      }
 #pragma unroll
       for (int ry = 0; ry < TH; ++ry) {
         const int ky = r - ry * DOWN;
@@ -741,7 +752,7 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
       const int bw = a.out_w, bh = (a.out_h + th - 1) / th;
       const long long nthreads = (long long)major * bw * bh;
       const unsigned grid = (unsigned)((nthreads + 255) / 256 < 131072 ? (nthreads + 255) / 256 : 131072);
-#define CIPS_UF(D, TW_, TH_) hipLaunchKernelGGL((upfirdn2d_direct_kernel<D, TW_, TH_>), dim3(grid), dim3(256), 0, st, a, bw, bh)
+#define CIPS_UF(D, TW_, TH_) hipLaunchKernelGGL((upfirdn2d_direct_kernel<D, TW_, TH_, false>), dim3(grid), dim3(256), 0, st, a, bw, bh, ParityIn())
       if (down_x == 1) { if (th == 8) CIPS_UF(1, 1, 8); else CIPS_UF(1, 1, 16); }
       else { if (th == 8) CIPS_UF(2, 1, 8); else CIPS_UF(2, 1, 16); }
 #undef CIPS_UF
@@ -778,6 +789,34 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
     }
   }
   hipLaunchKernelGGL(upfirdn2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return CIPS_CHECK_LAUNCH();
+}
+
+// The 4 x 4 FIR (up 1, down 1) over a plane stored as the four parity blocks of cips_conv2d_x3_dgrad_s2: the transpose of
+// the Blur in front of a stride-2 convolution, applied straight to that convolution's data gradient (include/cips3d_hip.h).
+extern "C" int cips_upfirdn2d_parity(const float* dxp, const long long* blk_off, const float* kernel, float* out, int major,
+                                     int in_h, int in_w, int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream) {
+  if (!dxp || !blk_off || !kernel || !out || major <= 0 || in_h <= 0 || in_w <= 0 || pad_x0 < 0 || pad_y0 < 0) return (int)hipErrorInvalidValue;
+  UpfirArgs a;
+  a.in = dxp; a.k = kernel; a.out = out; a.major = major; a.in_h = in_h; a.in_w = in_w; a.minor = 1;
+  a.kh = 4; a.kw = 4; a.up_x = a.up_y = 1; a.down_x = a.down_y = 1; a.pad_x0 = pad_x0; a.pad_y0 = pad_y0;
+  a.out_h = in_h + pad_y0 + pad_y1 - 4 + 1;
+  a.out_w = in_w + pad_x0 + pad_x1 - 4 + 1;
+  if (a.out_h <= 0 || a.out_w <= 0) return (int)hipErrorInvalidValue;
+  ParityIn pin;
+  for (int pa = 0; pa < 2; ++pa)
+    for (int pb = 0; pb < 2; ++pb) {
+      const int hs = (in_h - pa + 1) / 2, ws = (in_w - pb + 1) / 2;
+      pin.blk[2 * pa + pb] = dxp + blk_off[2 * pa + pb];
+      pin.np[2 * pa + pb] = (hs * ws + 7) & ~7;
+      pin.ws[pb] = ws;
+    }
+  const int th = a.out_h < 48 ? 8 : 16;
+  const int bw = a.out_w, bh = (a.out_h + th - 1) / th;
+  const long long nthreads = (long long)major * bw * bh;
+  const unsigned grid = (unsigned)((nthreads + 255) / 256 < 131072 ? (nthreads + 255) / 256 : 131072);
+  if (th == 8) hipLaunchKernelGGL((upfirdn2d_direct_kernel<1, 1, 8, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, bw, bh, pin);
+  else hipLaunchKernelGGL((upfirdn2d_direct_kernel<1, 1, 16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, bw, bh, pin);
   return CIPS_CHECK_LAUNCH();
 }
 

@@ -61,12 +61,25 @@ struct ConvGeom {
   int act;                     // 1: y = leaky_relu(y + bias, slope) * act_scale   (FusedLeakyReLU, fused_act.py:47-86)
   float slope, act_scale;
 };
+// One homogeneous range of output tiles of conv2d_x3_v3_kernel.  A plain convolution is one range; the data gradient of a
+// stride-2 convolution is four (one per parity class of the input pixel: every class is a small stride-1 convolution over
+// dy with its own tap window, output plane and filter bank), run by ONE persistent launch.
+struct ConvPart {
+  int tile0, tiles_n;          // first tile of the range; tiles per output plane along the pixel dimension
+  int kw, pad_y, pad_x, Wo;    // tap window width, top / left padding, output plane width
+  int N, K, lda;               // output pixels per image (rows of B; a multiple of 8), contraction length, A row pitch
+  int ldc;                     // output row pitch
+  long long a_off, c_off;      // element offsets of this range's filter bank (A planes) and output block (C)
+  long long strideC;           // output elements per image
+};
 struct WArgs {
   cips_gemm_x3_desc d;
   int tiles_m, tiles_n, total, dbg;
   int ksplit;                  // > 1: the contraction is cut into ksplit ranges of k-tiles (chunk c takes k-tiles
                                // [c*T/ksplit, (c+1)*T/ksplit)); chunk c of batch entry b writes C + (c*batch + b)*strideC
   ConvGeom cv;
+  int nparts;                  // conv2d_x3_v3_kernel only: 0 = one range described by d / cv / tiles_n (plain convolution)
+  ConvPart part[4];
 };
 
 __device__ __forceinline__ u16 f2bf(float v) {
@@ -490,35 +503,47 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
   const int lane0 = tid & 63;
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = uw, wm = wave >> 1, wn = wave & 1;
-  const int M = d.M, N = d.N;
-  const int nk_all = d.K / BK;
+  const int M = d.M;
   const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
   const unsigned sbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
-  auto chunk_kt0 = [&](int kc) -> int { return (int)((long long)kc * nk_all / ksplit); };
 
   for (int tseq = blockIdx.x; tseq < g.total; tseq += gridDim.x) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int l31 = lane & 31, hf = lane >> 5;
     int tm, tn, bz, kc;
+    // geometry of this tile's range (uniform values: scalar registers)
+    int N = d.N, K = d.K, lda = d.lda, ldc = d.ldc, p_kw = g.cv.kw, pad_y = g.cv.pad, pad_x = g.cv.pad, p_Wo = g.cv.Wo;
+    long long a_off = 0, c_off = 0, strideC = d.strideC;
     {
       const int nx = 8;
       int q = g.total / nx, r = g.total % nx;
       int xcd = tseq % nx, idx = tseq / nx;
       int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-      const int bid = base + idx;
-      tn = bid % g.tiles_n;
-      tm = (bid / g.tiles_n) % g.tiles_m;
-      const int bk = bid / (g.tiles_n * g.tiles_m);
+      int bid = base + idx;
+      int tiles_n = g.tiles_n;
+      if (g.nparts > 0) {
+        int pi = 0;
+        while (pi + 1 < g.nparts && bid >= g.part[pi + 1].tile0) ++pi;
+        const ConvPart& cp = g.part[pi];
+        bid -= cp.tile0; tiles_n = cp.tiles_n;
+        N = cp.N; K = cp.K; lda = cp.lda; ldc = cp.ldc; p_kw = cp.kw; pad_y = cp.pad_y; pad_x = cp.pad_x; p_Wo = cp.Wo;
+        a_off = cp.a_off; c_off = cp.c_off; strideC = cp.strideC;
+      }
+      tn = bid % tiles_n;
+      tm = (bid / tiles_n) % g.tiles_m;
+      const int bk = bid / (tiles_n * g.tiles_m);
       kc = bk % ksplit;
       bz = bk / ksplit;
     }
+    const int nk_all = K / BK;
+    auto chunk_kt0 = [&](int kc_) -> int { return (int)((long long)kc_ * nk_all / ksplit); };
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbase = chunk_kt0(kc) * BK;
     const int nk = chunk_kt0(kc + 1) - chunk_kt0(kc);          // >= 2 (host)
     // ---- sources: weights (A) row-major [O][kh*kw*C]; pixels (B) gathered per tap from the NHWC planes of image bz
-    const u16* Ahi = (const u16*)d.A_hi + (long long)m0 * d.lda + kbase;
-    const u16* Alo = (const u16*)d.A_lo + (long long)m0 * d.lda + kbase;
+    const u16* Ahi = (const u16*)d.A_hi + a_off + (long long)m0 * lda + kbase;
+    const u16* Alo = (const u16*)d.A_lo + a_off + (long long)m0 * lda + kbase;
     const u16* Bhi = (const u16*)d.B_hi + (long long)bz * g.cv.img_stride;
     const u16* Blo = (const u16*)d.B_lo + (long long)bz * g.cv.img_stride;
     const unsigned zero_rel = (unsigned)((g.cv.zero_elem - (long long)bz * g.cv.img_stride) * 2);
@@ -531,17 +556,17 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
         const int row = (uw + 8 * p) * 16 + drow;
         const int kcsw = dslot ^ ((row >> 2) & 3);
         const int ra = (row < M - m0) ? row : (M - m0 - 1), rb = (row < N - n0) ? row : (N - n0 - 1);
-        offA[p] = (unsigned)(ra * d.lda + kcsw * 8) * 2u;
-        const int pix = n0 + rb, oy = pix / g.cv.Wo, ox = pix - oy * g.cv.Wo;
-        iy0[p] = oy * g.cv.stride - g.cv.pad;
-        ix0[p] = ox * g.cv.stride - g.cv.pad;
+        offA[p] = (unsigned)(ra * lda + kcsw * 8) * 2u;
+        const int pix = n0 + rb, oy = pix / p_Wo, ox = pix - oy * p_Wo;
+        iy0[p] = oy * g.cv.stride - pad_y;
+        ix0[p] = ox * g.cv.stride - pad_x;
         chunk[p] = (unsigned)kcsw * 16u;
       }
     }
     auto prep_b = [&](int k0) {                                // refresh the two per-lane B offsets for k-tile k0
       const int kk = k0 + kbase;
       const int tap = kk / g.cv.C, c0 = kk - tap * g.cv.C;
-      const int ky = tap / g.cv.kw, kx = tap - ky * g.cv.kw;
+      const int ky = tap / p_kw, kx = tap - ky * p_kw;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int iy = iy0[p] + ky, ix = ix0[p] + kx;
@@ -623,7 +648,7 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
     __syncthreads();
 
     // ---- epilogue: bias + FusedLeakyReLU (unsplit launches), fp32 rows of 8 through the per-wave scratch (stage 1)
-    const long long cb = ((long long)kc * d.batch + bz) * d.strideC;
+    const long long cb = c_off + ((long long)kc * d.batch + bz) * strideC;
     float* sc_f = reinterpret_cast<float*>(smem + STAGE + wave * SCR_WAVE);
     const int h_rr = lane >> 2, h_c8 = (lane & 3) * 8;
     float cbias[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
@@ -659,7 +684,7 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
           for (int e = 0; e < 8; ++e) y[e] = lrelu(y[e], g.cv.slope) * g.cv.act_scale;
         }
         if (row < M && col < N) {
-          float* q = d.C + cb + (long long)row * d.ldc + col;
+          float* q = d.C + cb + (long long)row * ldc + col;
           *reinterpret_cast<float4*>(q) = make_float4(y[0], y[1], y[2], y[3]);
           *reinterpret_cast<float4*>(q + 4) = make_float4(y[4], y[5], y[6], y[7]);
         }
@@ -768,6 +793,61 @@ extern "C" int cips_conv2d_x3(const cips_conv_x3_desc* c, cips_stream_t stream) 
                        reinterpret_cast<const float4*>(c->part), reinterpret_cast<float4*>(c->y), ks, n4, c->bias, act ? 1 : 0,
                        c->slope, c->act_scale, (int)(N / 4), c->O);
   }
+  return CIPS_CHECK_LAUNCH();
+}
+
+// Data gradient of a stride-2, unpadded convolution as four parity sub-convolutions in one launch (include/cips3d_hip.h)
+extern "C" int cips_conv2d_x3_dgrad_s2(const cips_conv_dgrad_s2_desc* c, cips_stream_t stream) {
+  if (!c || !c->w_hi || !c->w_lo || !c->dy_hi || !c->dy_lo || !c->dxp || c->B <= 0 || c->C <= 0 || c->O <= 0 || c->H <= 0 || c->W <= 0 ||
+      c->kh <= 0 || c->kw <= 0)
+    return (int)hipErrorInvalidValue;
+  if (c->H < c->kh || c->W < c->kw) return (int)hipErrorInvalidValue;
+  if ((c->O & 31) || (c->C & 7)) return (int)hipErrorNotSupported;
+  const int Ho = (c->H - c->kh) / 2 + 1, Wo = (c->W - c->kw) / 2 + 1;
+  const long long img = (long long)Ho * Wo * c->O;
+  if ((img * c->B + c->O) * 2 >= 0xffffffffLL) return (int)hipErrorNotSupported;          // 32-bit lane offsets
+  WArgs g = {};
+  cips_gemm_x3_desc& d = g.d;
+  d.A_hi = c->w_hi; d.A_lo = c->w_lo; d.B_hi = c->dy_hi; d.B_lo = c->dy_lo;
+  d.M = c->C; d.batch = c->B; d.C = c->dxp; d.slope = 0.2f;
+  g.cv.C = c->O; g.cv.H = Ho; g.cv.W = Wo; g.cv.stride = 1;
+  g.cv.img_stride = img; g.cv.zero_elem = img * c->B;
+  g.cv.bias = nullptr; g.cv.act = 0; g.cv.slope = 0.2f; g.cv.act_scale = 1.f;
+  g.tiles_m = (d.M + BM - 1) / BM;
+  g.ksplit = 1;
+  long long tile0 = 0;
+  int np = 0;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int Ta = (c->kh - a + 1) / 2, Tb = (c->kw - b + 1) / 2;     // taps ky = a, a+2, ... < kh
+      const int Hs = (c->H - a + 1) / 2, Ws = (c->W - b + 1) / 2;       // input rows / columns of this parity
+      if (Ta <= 0 || Tb <= 0 || Hs <= 0 || Ws <= 0) continue;          // (a 1-tap kernel has no odd class: its gradient there is zero — caller's fill)
+      ConvPart& cp = g.part[np++];
+      cp.kw = Tb; cp.pad_y = Ta - 1; cp.pad_x = Tb - 1; cp.Wo = Ws;
+      cp.N = (Hs * Ws + 7) & ~7;
+      cp.K = Ta * Tb * c->O; cp.lda = cp.K;
+      if (cp.K / BK < 2) return (int)hipErrorNotSupported;
+      cp.ldc = cp.N; cp.strideC = (long long)c->C * cp.N;
+      cp.a_off = c->w_off[2 * a + b]; cp.c_off = c->out_off[2 * a + b];
+      if ((cp.a_off & 7) || (cp.c_off & 3)) return (int)hipErrorInvalidValue;
+      cp.tiles_n = (cp.N + BN - 1) / BN;
+      cp.tile0 = (int)tile0;
+      tile0 += (long long)g.tiles_m * cp.tiles_n * c->B;
+    }
+  if (np == 0 || tile0 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  // longest contraction first: the persistent grid then ends on the short tiles
+  for (int i = 0; i < np; ++i)
+    for (int j = i + 1; j < np; ++j)
+      if (g.part[j].K > g.part[i].K) { ConvPart t = g.part[i]; g.part[i] = g.part[j]; g.part[j] = t; }
+  tile0 = 0;
+  for (int i = 0; i < np; ++i) { g.part[i].tile0 = (int)tile0; tile0 += (long long)g.tiles_m * g.part[i].tiles_n * c->B; }
+  g.nparts = np;
+  g.total = (int)tile0;
+  g.tiles_n = g.part[0].tiles_n;
+  static bool attr = false;
+  CIPS_PER_DEVICE(attr, false);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)conv2d_x3_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES); attr = true; }
+  hipLaunchKernelGGL(conv2d_x3_v3_kernel, dim3(wide_grid(g.total)), dim3(512), SMEM_BYTES, (hipStream_t)stream, g);
   return CIPS_CHECK_LAUNCH();
 }
 

@@ -1154,6 +1154,84 @@ def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad, ksplit=None, bias=None
     return y
 
 
+def dgrad_s2_banks(w):
+    """w (O, C, kh, kw) fp32 -> (Planes of the four parity filter banks back to back, element offsets [4]) for
+    conv2d_x3_dgrad_s2: bank (a, b) = [C][(ty, tx, o)] with w[o][c][a + 2(Ta-1-ty)][b + 2(Tb-1-tx)] (include/cips3d_hip.h)."""
+    O, C, kh, kw = w.shape
+    parts, offs, tot = [], [], 0
+    for a in range(2):
+        for b in range(2):
+            offs.append(tot)
+            sub = w[:, :, a::2, b::2]
+            if sub.numel() == 0:
+                continue
+            bank = sub.flip(2, 3).permute(1, 2, 3, 0).reshape(-1)          # (C, Ta, Tb, O)
+            parts.append(bank)
+            tot += bank.numel()
+    flat = torch.cat(parts).contiguous()
+    P, _ = split_planes(flat.view(1, tot // 32, 32), want_p=True, want_t=False)
+    return P, offs
+
+
+def dgrad_s2_layout(H, W):
+    """-> (element offsets [4] of the parity blocks per (B*C) planes, plane sizes Np[4]) for an (H, W) input"""
+    nps = []
+    for a in range(2):
+        for b in range(2):
+            hs, ws = (H - a + 1) // 2, (W - b + 1) // 2
+            nps.append((hs * ws + 7) // 8 * 8)
+    return nps
+
+
+def conv2d_x3_dgrad_s2(banks, w_off, dyP, B, C, H, W, O, kh, kw):
+    """Data gradient of a stride-2 unpadded convolution as four parity sub-convolutions in one launch (cips_conv2d_x3_dgrad_s2).
+    banks / w_off: dgrad_s2_banks(w); dyP: NHWC Planes of dy (B, O, Ho, Wo).  -> (dxp fp32 flat, out_off [4]): the gradient w.r.t.
+    the (B, C, H, W) input in parity-block layout, consumed by upfirdn2d_parity (or parity_to_nchw in tests)."""
+    lib = _lib.load()
+    from ._lib import ConvDgradS2Desc
+    nps = dgrad_s2_layout(H, W)
+    out_off, tot = [], 0
+    for n_ in nps:
+        out_off.append(tot)
+        tot += B * C * n_
+    dxp = torch.empty(tot, device=dyP.hi.device)
+    d = ConvDgradS2Desc()
+    d.w_hi, d.w_lo, d.dy_hi, d.dy_lo, d.dxp = _p(banks.hi), _p(banks.lo), _p(dyP.hi), _p(dyP.lo), _p(dxp)
+    d.B, d.C, d.H, d.W, d.O, d.kh, d.kw = B, C, H, W, O, kh, kw
+    for i in range(4):
+        d.w_off[i] = w_off[i]
+        d.out_off[i] = out_off[i]
+    check(lib.cips_conv2d_x3_dgrad_s2(_ct.byref(d), _stream()), "cips_conv2d_x3_dgrad_s2")
+    return dxp, out_off
+
+
+def parity_to_nchw(dxp, out_off, B, C, H, W):
+    """the parity-block layout of conv2d_x3_dgrad_s2 as an ordinary (B, C, H, W) tensor (tests / fallbacks: torch indexing)"""
+    out = torch.empty(B, C, H, W, device=dxp.device)
+    nps = dgrad_s2_layout(H, W)
+    for a in range(2):
+        for b in range(2):
+            hs, ws = (H - a + 1) // 2, (W - b + 1) // 2
+            i = 2 * a + b
+            blk = dxp[out_off[i]:out_off[i] + B * C * nps[i]].view(B, C, nps[i])[:, :, :hs * ws].reshape(B, C, hs, ws)
+            out[:, :, a::2, b::2] = blk
+    return out
+
+
+def upfirdn2d_parity(dxp, out_off, kernel, major, in_h, in_w, pad_x0, pad_x1, pad_y0, pad_y1):
+    """cips_upfirdn2d (4 x 4 kernel, up = down = 1) on planes stored as conv2d_x3_dgrad_s2's parity blocks -> (major, out_h, out_w)"""
+    lib = _lib.load()
+    k = _native_in(kernel, "kernel")
+    if tuple(k.shape) != (4, 4):
+        raise RuntimeError("upfirdn2d_parity: 4 x 4 kernels only")
+    out_h, out_w = in_h + pad_y0 + pad_y1 - 3, in_w + pad_x0 + pad_x1 - 3
+    out = torch.empty(major, out_h, out_w, device=dxp.device)
+    offs = (_ct.c_longlong * 4)(*out_off)
+    check(lib.cips_upfirdn2d_parity(_p(dxp), _ct.byref(offs), _p(k), _p(out), major, in_h, in_w, pad_x0, pad_x1, pad_y0, pad_y1,
+                                    _stream()), "cips_upfirdn2d_parity")
+    return out
+
+
 def conv2d_x3_wgrad(dyP, xP, B, C, H, W, O, kh, kw, stride, pad, scale=1.0, nch=None):
     """Weight gradient of conv2d_x3: dyP, xP NHWC Planes from split_planes_nhwc -> dW (O, C, kh, kw) fp32, or None when
     the pixel count does not split into 32-row k-tiles.  The pixel range is cut into chunks so that a 512x512 filter bank

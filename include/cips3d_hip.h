@@ -347,6 +347,25 @@ typedef struct cips_conv_x3_desc {
 } cips_conv_x3_desc;
 int cips_conv2d_x3(const cips_conv_x3_desc* d, cips_stream_t stream);
 int cips_conv2d_x3_ksplit(int B, int O, int N, int K);
+/* Data gradient of a STRIDE-2, UNPADDED convolution (the EqualConv2d behind a Blur: exp/cips3d/models/discriminator.py:190-203)
+ * without col2im: input pixel (P, Q) only receives the taps ky = P mod 2 (+2, ...), kx = Q mod 2 (+2, ...), so each of the four
+ * parity classes (a, b) = (P mod 2, Q mod 2) is a small STRIDE-1 convolution over dy with its own filter bank:
+ *   dxp_ab[i][c][U*Ws_b + V] = sum_{ty < Ta, tx < Tb, o} bank_ab[c][(ty*Tb + tx)*O + o] * dy[i][U - (Ta-1) + ty][V - (Tb-1) + tx][o]
+ *                            = dx[i][c][2U + a][2V + b]
+ * with Ta = ceil((kh-a)/2), Tb = ceil((kw-b)/2), Hs_a = ceil((H-a)/2), Ws_b = ceil((W-b)/2) and
+ *   bank_ab[c][(ty*Tb + tx)*O + o] = w[o][c][a + 2(Ta-1-ty)][b + 2(Tb-1-tx)]   (planes, row pitch Ta*Tb*O, at element offset w_off[2a+b]).
+ * All four run in ONE persistent launch of the implicit-GEMM kernel (longest contraction first).  dy: NHWC split planes
+ * [B*Ho*Wo + 1][O] with a ZERO LAST ROW (Ho = (H-kh)/2 + 1).  Output: four compact blocks, class (a, b) at element offset
+ * out_off[2a+b] of dxp as fp32 (B, C, Np_ab), Np_ab = Hs_a*Ws_b rounded up to a multiple of 8 (the padding elements are written
+ * as zeros); cips_upfirdn2d_parity reads them in place of the interleaved (B, C, H, W) tensor.  O % 32 == 0, C % 8 == 0. */
+typedef struct cips_conv_dgrad_s2_desc {
+  const void* w_hi; const void* w_lo;
+  const void* dy_hi; const void* dy_lo;
+  float* dxp;
+  int B, C, H, W, O, kh, kw;         /* H, W: the convolution's INPUT size */
+  long long w_off[4], out_off[4];
+} cips_conv_dgrad_s2_desc;
+int cips_conv2d_x3_dgrad_s2(const cips_conv_dgrad_s2_desc* d, cips_stream_t stream);
 /* Weight gradient of the same convolution on the K-major kernel (contraction over all B*Ho*Wo output pixels, split in
  * `nchunks` ranges whose partial sums the caller adds):
  *   part[chunk][ky*kw+kx][o][c] = sum_{q in chunk} dy[q][o] * x[pixel(q)*stride - pad + (ky,kx)][c]
@@ -495,6 +514,13 @@ int cips_upfirdn2d(const float* input, const float* kernel, float* out,
                    int major, int in_h, int in_w, int minor, int kernel_h, int kernel_w,
                    int up_x, int up_y, int down_x, int down_y,
                    int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream);
+/* The same op for a 4 x 4 kernel, up = down = 1, on `major` planes of in_h x in_w that are stored as the four parity blocks
+ * written by cips_conv2d_x3_dgrad_s2 (pixel (y, x) of plane m at dxp[blk_off[2(y&1) + (x&1)] + m * Np + (y>>1) * Ws + (x>>1)],
+ * Ws = ceil((in_w - (x&1)) / 2), Np = Hs * Ws rounded up to 8): the transpose of the Blur of a down-sampling ConvLayer
+ * (discriminator.py:57-82, 190-203) applied to the stride-2 convolution's data gradient without materialising it
+ * row-major.  Same taps in the same order as cips_upfirdn2d on the interleaved tensor: bit-identical results. */
+int cips_upfirdn2d_parity(const float* dxp, const long long* blk_off, const float* kernel, float* out, int major,
+                          int in_h, int in_w, int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream);
 
 /* EqualLinear (exp/cips3d/models/discriminator.py:254-288: F.linear(input, weight * scale) [+ bias * lr_mul]) and the two
  * other bilinear forms of its autograd (each form's gradients are the other two: the R1 double-backward closes):

@@ -461,3 +461,52 @@ def test_d_step_captured_in_a_hipgraph_replays_like_eager():
         oe_, _, _ = De(xs[0], alpha=1.0, use_aux_disc=False)
         og_, _, _ = Dg(xs[0], alpha=1.0, use_aux_disc=False)
     assert max_rel(og_, oe_) < 1e-5, (max_rel(og_, oe_), worst)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 96, 17, 3), (2, 64, 64, 33, 3), (3, 32, 64, 65, 3), (2, 96, 64, 18, 3), (2, 64, 64, 20, 4),
+                                 (1, 512, 512, 65, 3), (2, 64, 64, 16, 2)])
+def test_stride2_data_gradient_as_parity_subconvolutions(cfg):
+    """cips_conv2d_x3_dgrad_s2: the data gradient of a stride-2 unpadded convolution as four stride-1
+    sub-convolutions over dy, one per parity class of the input pixel, in one launch — no dcol, no col2im.  Against torch's
+    conv_transpose in fp64 (3e-5: the split-bf16 class) and against the K-major GEMM + col2im path it replaces (same class);
+    then the Blur's transpose straight from the parity blocks (cips_upfirdn2d_parity) against cips_upfirdn2d on the
+    interleaved tensor: bit-identical."""
+    from cips3d_amd import ops
+    from cips3d_amd import discriminator as dm
+    B, C, O, H, k = cfg
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H + C + k)
+    Ho = (H - k) // 2 + 1
+    w = torch.randn(O, C, k, k, generator=g, dtype=torch.float64) / (C * k * k) ** 0.5
+    dy = torch.randn(B, O, Ho, Ho, generator=g, dtype=torch.float64)
+    want = torch.nn.functional.conv_transpose2d(dy, w, stride=2, output_padding=(H - k) % 2)
+    assert want.shape == (B, C, H, H)
+    banks, w_off = ops.dgrad_s2_banks(w.float().to(d))
+    dyP = ops.split_planes_nhwc(dy.float().to(d))
+    dxp, out_off = ops.conv2d_x3_dgrad_s2(banks, w_off, dyP, B, C, H, H, O, k, k)
+    got = ops.parity_to_nchw(dxp, out_off, B, C, H, H)
+    e_new = rel_err(got, want)
+    try:
+        e_old = rel_err(dm._conv_bwd_data(dy.float().to(d), w.float().to(d), (B, C, H, H), 2, 0), want)
+    except RuntimeError:                       # shapes the GEMM + col2im path has no kernel for (odd pixel counts)
+        e_old = None
+    print(f"dgrad s2 {cfg}: parity {e_new:.2e}  col2im path {e_old if e_old is None else format(e_old, '.2e')}")
+    assert e_new < 3e-5 and (e_old is None or e_new < 2 * e_old + 1e-6)
+    # the padding elements of every block are zeros (they are written, not left uninitialised)
+    nps = ops.dgrad_s2_layout(H, H)
+    for a in range(2):
+        for b in range(2):
+            hs, ws = (H - a + 1) // 2, (H - b + 1) // 2
+            i = 2 * a + b
+            blk = dxp[out_off[i]:out_off[i] + B * C * nps[i]].view(B * C, nps[i])
+            assert not bool(blk[:, hs * ws:].any())
+    kern = dm.make_kernel([1, 3, 3, 1]).to(d)
+    kf = torch.flip(kern, [0, 1]).contiguous()
+    a1 = ops.upfirdn2d_parity(dxp, out_off, kf, B * C, H, H, 1, 1, 1, 1)
+    a0 = ops.upfirdn2d_op(got.reshape(B * C, H, H, 1), kf, 1, 1, 1, 1, 1, 1, 1, 1).view(B * C, H - 1, H - 1)
+    assert torch.equal(a1, a0)
+    if cfg == (2, 64, 96, 17, 3):
+        # a contraction of one k-tile (O = 32, the single-tap class) is refused, loudly: the caller keeps the col2im path
+        b32, o32 = ops.dgrad_s2_banks(w[:32].float().to(d))
+        with pytest.raises(RuntimeError):
+            ops.conv2d_x3_dgrad_s2(b32, o32, ops.split_planes_nhwc(dy[:, :32].float().to(d)), B, C, H, H, 32, k, k)
