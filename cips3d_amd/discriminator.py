@@ -275,9 +275,10 @@ class _share_planes:
     def __enter__(self):
         m = _memo()
         m.depth += 1
-        for t, p in self.pairs:
+        for ent in self.pairs:
+            t, p = ent[0], ent[1]
             if p is not None:
-                m.shared[_key(t)] = (t, p)
+                m.shared[_key(t) + _pre_sig(ent[2] if len(ent) > 2 else None)] = (t, p)
 
     def __exit__(self, *exc):
         m = _memo()
@@ -286,16 +287,77 @@ class _share_planes:
             m.shared.clear()
 
 
-def _nhwc(t):
+def _nhwc(t, pre=None):
+    """NHWC split planes of t — of Blur(t) when `pre` is given (one fused pass, cips_blur_nhwc_planes)"""
     m = _memo()
-    key = _key(t)
+    key = _key(t) + _pre_sig(pre)
     ent = m.shared.get(key)
     if ent is not None:
         return ent[1]
-    p = ops.split_planes_nhwc(t)
+    if pre is None:
+        p = ops.split_planes_nhwc(t)
+    else:
+        p, _, _ = ops.blur_nhwc_planes(t.contiguous(), pre[0], pre[3], pre[1], pre[2])
     if m.depth:
         m.shared[key] = (t, p)
     return p
+
+
+# ------------------------------------------------------------------------------------------
+# The Blur of a down-sampling ConvLayer folded into its convolution (VERDICT r5 next-1): `pre` = (kernel (4 x 4 buffer),
+# pad0, pad1, down) describes y = conv(upfirdn2d(x, kernel, down=down, pad=(pad0, pad1)), w).  The three convolution
+# Functions below carry it through every order of differentiation: forward and weight gradient read the blurred planes
+# straight from the fused blur + split kernel (the blurred fp32 tensor never exists), the data gradient ends in the
+# Blur's transpose — for the 3 x 3 stride-2 layers applied directly to the parity blocks of cips_conv2d_x3_dgrad_s2.
+# ------------------------------------------------------------------------------------------
+def _pre_sig(pre):
+    return () if pre is None else ("pre", int(pre[1]), int(pre[2]), int(pre[3]))
+
+
+def _pre_shape(H, W, pre):
+    if pre is None:
+        return H, W
+    _, p0, p1, down = pre
+    return (H + p0 + p1 - 4) // down + 1, (W + p0 + p1 - 4) // down + 1
+
+
+_FLIPPED = {}
+
+
+def _flipped(k):
+    """torch.flip(k, [0, 1]) of a Blur kernel buffer, cached per (storage, version)"""
+    key = (k.data_ptr(), k._version, str(k.device))
+    f = _FLIPPED.get(key)
+    if f is None:
+        if len(_FLIPPED) > 64:
+            _FLIPPED.clear()
+        f = _FLIPPED[key] = torch.flip(k, [0, 1]).contiguous()
+    return f
+
+
+def _pre_fp32(x, pre):
+    """upfirdn2d(x, kernel, down, pad) as an fp32 NCHW tensor (the paths without an implicit-GEMM form)"""
+    k, p0, p1, down = pre
+    B, C, H, W = x.shape
+    out = ops.upfirdn2d_op(x.contiguous().reshape(-1, H, W, 1), k, 1, 1, down, down, p0, p1, p0, p1)
+    Hb, Wb = _pre_shape(H, W, pre)
+    return out.view(B, C, Hb, Wb)
+
+
+def _pre_adjoint_pads(H, W, pre):
+    _, p0, p1, down = pre
+    Hb, Wb = _pre_shape(H, W, pre)
+    return (3 - p0, W - Wb * down + p0, 3 - p0, H - Hb * down + p0)          # (x0, x1, y0, y1): upfirdn2d.py:104-110
+
+
+def _pre_adjoint(dxb, pre, in_shape):
+    """transpose of the Blur: gradient w.r.t. its input from the gradient w.r.t. its output (upfirdn2d.py:18-52)"""
+    k, p0, p1, down = pre
+    B, C, H, W = in_shape
+    Hb, Wb = _pre_shape(H, W, pre)
+    gx0, gx1, gy0, gy1 = _pre_adjoint_pads(H, W, pre)
+    out = ops.upfirdn2d_op(dxb.contiguous().reshape(-1, Hb, Wb, 1), _flipped(k), down, down, 1, 1, gx0, gx1, gy0, gy1)
+    return out.view(B, C, H, W)
 
 
 # Operand planes of a convolution WEIGHT are a function of the parameter alone, but every conv call of a step needs
@@ -365,6 +427,11 @@ def _w_planes_flipT(w, scale=1.0):
     return _cached(w, scale, "flipT", lambda we: _w_planes_raw(we.flip(2, 3).transpose(0, 1)))
 
 
+def _w_banks_s2(w, scale=1.0):
+    """the four parity filter banks of the stride-2 data gradient (ops.dgrad_s2_banks): (Planes, offsets)"""
+    return _cached(w, scale, "s2banks", ops.dgrad_s2_banks)
+
+
 def _w_rows(w, scale, want_t):
     """(O, K) matrix of w * scale as planes (1, O, K) (want_t False) or transposed (1, K, O)"""
     def build(we):
@@ -378,11 +445,17 @@ def _scaled(w, scale):
     return w if scale == 1.0 else w * scale
 
 
-def _conv_fwd(x, w, stride, pad, scale=1.0):
-    """y = conv(x, w * scale); `w` may be the nn.Parameter itself (its operand planes are cached, see _cached)"""
+def _conv_fwd(x, w, stride, pad, scale=1.0, pre=None):
+    """y = conv(Blur(x), w * scale); `w` may be the nn.Parameter itself (its operand planes are cached, see _cached)"""
     B, C, H, W = x.shape
     O, _, kh, kw = w.shape
     x = x.contiguous()
+    if pre is not None:
+        Hb, Wb = _pre_shape(H, W, pre)
+        if _implicit_ok(C, ((Hb + 2 * pad - kh) // stride + 1) * ((Wb + 2 * pad - kw) // stride + 1), O):
+            return ops.conv2d_x3(_w_planes(w, scale), _nhwc(x, pre), B, C, Hb, Wb, O, kh, kw, stride, pad)
+        x = _pre_fp32(x, pre)
+        H, W = Hb, Wb
     Ho_, Wo_ = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     if kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
         return ops.conv1x1_smallk(x, _scaled(w, scale).reshape(O, C).contiguous())      # RGB input convs: streaming, no GEMM
@@ -420,7 +493,23 @@ def _conv_fwd(x, w, stride, pad, scale=1.0):
     return y
 
 
-def _conv_bwd_data(dy, w, in_shape, stride, pad, scale=1.0):
+def _s2_parity_ok(C, O, N):
+    """stride-2 data gradient as parity sub-convolutions: dy planes of at least one 256-pixel tile, O a multiple of 32 with
+    two k-tiles in the single-tap class"""
+    return CONV_MODE == "bf16x3" and O % 32 == 0 and O >= 64 and C % 8 == 0 and N >= 256
+
+
+def _conv_bwd_data(dy, w, in_shape, stride, pad, scale=1.0, pre=None):
+    if pre is not None:
+        B, C, H, W = in_shape
+        O, _, kh, kw = w.shape
+        Hb, Wb = _pre_shape(H, W, pre)
+        if (stride == 2 and pad == 0 and pre[3] == 1 and dy.is_cuda and _s2_parity_ok(C, O, dy.shape[2] * dy.shape[3])):
+            banks, w_off = _w_banks_s2(w, scale)
+            dxp, out_off = ops.conv2d_x3_dgrad_s2(banks, w_off, _nhwc(dy.contiguous()), B, C, Hb, Wb, O, kh, kw)
+            gx0, gx1, gy0, gy1 = _pre_adjoint_pads(H, W, pre)
+            return ops.upfirdn2d_parity(dxp, out_off, _flipped(pre[0]), B * C, Hb, Wb, gx0, gx1, gy0, gy1).view(B, C, H, W)
+        return _pre_adjoint(_conv_bwd_data(dy, w, (B, C, Hb, Wb), stride, pad, scale), pre, in_shape)
     B, C, H, W = in_shape
     O, _, kh, kw = w.shape
     dy = dy.contiguous()
@@ -454,8 +543,16 @@ def _conv_bwd_data(dy, w, in_shape, stride, pad, scale=1.0):
     return ops.col2im(dcol, B, C, H, W, kh, kw, stride, pad)
 
 
-def _conv_bwd_weight(dy, x, w_shape, stride, pad, scale=1.0):
-    """d/dw of conv(x, w * scale): scale * (dy correlated with x)"""
+def _conv_bwd_weight(dy, x, w_shape, stride, pad, scale=1.0, pre=None):
+    """d/dw of conv(Blur(x), w * scale): scale * (dy correlated with Blur(x))"""
+    if pre is not None:
+        O, C, kh, kw = w_shape
+        Hb, Wb = _pre_shape(x.shape[2], x.shape[3], pre)
+        if _implicit_ok(C, dy.shape[2] * dy.shape[3], O) and x.is_cuda:
+            dw = ops.conv2d_x3_wgrad(_nhwc(dy.contiguous()), _nhwc(x.contiguous(), pre), x.shape[0], C, Hb, Wb, O, kh, kw, stride, pad, scale)
+            if dw is not None:
+                return dw
+        x = _pre_fp32(x, pre)
     dw = _conv_bwd_weight_raw(dy, x, w_shape, stride, pad, scale)
     if isinstance(dw, tuple):            # (tensor,): the path applied the scale itself
         return dw[0]
@@ -498,13 +595,13 @@ class Conv2dFunction(Function):
     out of the tensor lets the parameter itself arrive here, so that its operand planes can be cached (_cached)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, pad, scale=1.0):
+    def forward(ctx, x, w, stride, pad, scale=1.0, pre=None):
         ctx.save_for_backward(x, w)
-        ctx.stride, ctx.pad, ctx.scale = stride, pad, scale
+        ctx.stride, ctx.pad, ctx.scale, ctx.pre = stride, pad, scale, pre
         ctx.w_obj = w if isinstance(w, nn.Parameter) else None       # the Parameter object: the cache key
         with _share_planes():
-            y = _conv_fwd(x, w, stride, pad, scale)
-            ctx.xP = _shared.get(_key(x)) if ctx.needs_input_grad[1] else None
+            y = _conv_fwd(x, w, stride, pad, scale, pre)
+            ctx.xP = _shared.get(_key(x) + _pre_sig(pre)) if ctx.needs_input_grad[1] else None
         return y
 
     @staticmethod
@@ -513,13 +610,13 @@ class Conv2dFunction(Function):
         w = ctx.w_obj if ctx.w_obj is not None else w
         dx = dw = None
         dy = dy.contiguous()
-        with _share_planes((x, ctx.xP)):
+        with _share_planes((x, ctx.xP, ctx.pre)):
             if ctx.needs_input_grad[0]:
-                dx = Conv2dBwdDataFunction.apply(dy, w, x.shape, ctx.stride, ctx.pad, ctx.scale)
+                dx = Conv2dBwdDataFunction.apply(dy, w, x.shape, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
             if ctx.needs_input_grad[1]:
-                dw = Conv2dBwdWeightFunction.apply(dy, x, w.shape, ctx.stride, ctx.pad, ctx.scale)
+                dw = Conv2dBwdWeightFunction.apply(dy, x, w.shape, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
         ctx.xP = None
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 class ConvBiasActFunction(Function):
@@ -528,16 +625,17 @@ class ConvBiasActFunction(Function):
     the composition of the two layers' own backward Functions, so every higher-order path (R1) is theirs."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, scale, slope, act_scale):
+    def forward(ctx, x, w, bias, stride, pad, scale, slope, act_scale, pre=None):
         B, C, H, W = x.shape
         O, _, kh, kw = w.shape
         x = x.contiguous()
+        Hb, Wb = _pre_shape(H, W, pre)
         with _share_planes():
-            out = ops.conv2d_x3(_w_planes(w, scale), _nhwc(x), B, C, H, W, O, kh, kw, stride, pad, bias=bias.detach().contiguous(),
+            out = ops.conv2d_x3(_w_planes(w, scale), _nhwc(x, pre), B, C, Hb, Wb, O, kh, kw, stride, pad, bias=bias.detach().contiguous(),
                                 act=True, slope=slope, act_scale=act_scale)
-            ctx.xP = _shared.get(_key(x)) if ctx.needs_input_grad[1] else None
+            ctx.xP = _shared.get(_key(x) + _pre_sig(pre)) if ctx.needs_input_grad[1] else None
         ctx.save_for_backward(x, w, out)
-        ctx.cfg = (stride, pad, scale, slope, act_scale)
+        ctx.cfg = (stride, pad, scale, slope, act_scale, pre)
         ctx.w_obj = w if isinstance(w, nn.Parameter) else None
         return out
 
@@ -545,28 +643,30 @@ class ConvBiasActFunction(Function):
     def backward(ctx, dout):
         x, w, out = ctx.saved_tensors
         w = ctx.w_obj if ctx.w_obj is not None else w
-        stride, pad, scale, slope, act_scale = ctx.cfg
+        stride, pad, scale, slope, act_scale, pre = ctx.cfg
         dpre, dbias = FusedLeakyReLUFunctionBackward.apply(dout.contiguous(), out, slope, act_scale)
         dx = dw = None
-        with _share_planes((x, ctx.xP)):
+        with _share_planes((x, ctx.xP, pre)):
             if ctx.needs_input_grad[0]:
-                dx = Conv2dBwdDataFunction.apply(dpre, w, x.shape, stride, pad, scale)
+                dx = Conv2dBwdDataFunction.apply(dpre, w, x.shape, stride, pad, scale, pre)
             if ctx.needs_input_grad[1]:
-                dw = Conv2dBwdWeightFunction.apply(dpre, x, w.shape, stride, pad, scale)
+                dw = Conv2dBwdWeightFunction.apply(dpre, x, w.shape, stride, pad, scale, pre)
         ctx.xP = None
-        return dx, dw, (dbias if ctx.needs_input_grad[2] else None), None, None, None, None, None
+        return dx, dw, (dbias if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
 
 
+FOLD_BLUR = True            # False: Blur as its own upfirdn2d node in front of the convolution (the folding's parity test flips it)
 _CONV_ACT_FUSED = True      # False: bias + LeakyReLU as a separate pass after the convolution (the fusion's parity test flips it)
 
 
-def _conv_act_fusable(x, conv, act):
+def _conv_act_fusable(x, conv, act, pre=None):
     """EqualConv2d (no bias of its own) + FusedLeakyReLU on a GPU batch whose conv takes the implicit-GEMM path"""
     if not (_CONV_ACT_FUSED and x.is_cuda and x.dtype == torch.float32 and conv.bias is None and isinstance(act, FusedLeakyReLU)):
         return False
     if GATE_PIN is not None or GATE_REC is not None:        # gate instrumentation works on the separate activation op
         return False
     B, C, H, W = x.shape
+    H, W = _pre_shape(H, W, pre)
     O, _, kh, kw = conv.weight.shape
     Ho, Wo = (H + 2 * conv.padding - kh) // conv.stride + 1, (W + 2 * conv.padding - kw) // conv.stride + 1
     rgb = kh == 1 and kw == 1 and C <= 4
@@ -575,11 +675,11 @@ def _conv_act_fusable(x, conv, act):
 
 class Conv2dBwdDataFunction(Function):
     @staticmethod
-    def forward(ctx, dy, w, in_shape, stride, pad, scale=1.0):
+    def forward(ctx, dy, w, in_shape, stride, pad, scale=1.0, pre=None):
         ctx.save_for_backward(dy, w)
-        ctx.in_shape, ctx.stride, ctx.pad, ctx.scale = in_shape, stride, pad, scale
+        ctx.in_shape, ctx.stride, ctx.pad, ctx.scale, ctx.pre = in_shape, stride, pad, scale, pre
         ctx.w_obj = w if isinstance(w, nn.Parameter) else None
-        return _conv_bwd_data(dy, w, in_shape, stride, pad, scale)
+        return _conv_bwd_data(dy, w, in_shape, stride, pad, scale, pre)
 
     @staticmethod
     def backward(ctx, ggx):
@@ -589,35 +689,36 @@ class Conv2dBwdDataFunction(Function):
         ggx = ggx.contiguous()
         with _share_planes():
             if ctx.needs_input_grad[0]:
-                g_dy = Conv2dFunction.apply(ggx, w, ctx.stride, ctx.pad, ctx.scale)
+                g_dy = Conv2dFunction.apply(ggx, w, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
             if ctx.needs_input_grad[1]:
-                g_w = Conv2dBwdWeightFunction.apply(dy, ggx, w.shape, ctx.stride, ctx.pad, ctx.scale)
-        return g_dy, g_w, None, None, None, None
+                g_w = Conv2dBwdWeightFunction.apply(dy, ggx, w.shape, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
+        return g_dy, g_w, None, None, None, None, None
 
 
 class Conv2dBwdWeightFunction(Function):
     """dw = scale * wgrad(dy, x): the gradient of conv(x, w * scale) w.r.t. w"""
 
     @staticmethod
-    def forward(ctx, dy, x, w_shape, stride, pad, scale=1.0):
+    def forward(ctx, dy, x, w_shape, stride, pad, scale=1.0, pre=None):
         ctx.save_for_backward(dy, x)
-        ctx.w_shape, ctx.stride, ctx.pad, ctx.scale = w_shape, stride, pad, scale
-        return _conv_bwd_weight(dy, x, w_shape, stride, pad, scale)
+        ctx.w_shape, ctx.stride, ctx.pad, ctx.scale, ctx.pre = w_shape, stride, pad, scale, pre
+        return _conv_bwd_weight(dy, x, w_shape, stride, pad, scale, pre)
 
     @staticmethod
     def backward(ctx, ggw):
         dy, x = ctx.saved_tensors
         g_dy = g_x = None
         if ctx.needs_input_grad[0]:
-            g_dy = Conv2dFunction.apply(x, ggw, ctx.stride, ctx.pad, ctx.scale)
+            g_dy = Conv2dFunction.apply(x, ggw, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
         if ctx.needs_input_grad[1]:
-            g_x = Conv2dBwdDataFunction.apply(dy, ggw, x.shape, ctx.stride, ctx.pad, ctx.scale)
-        return g_dy, g_x, None, None, None, None
+            g_x = Conv2dBwdDataFunction.apply(dy, ggw, x.shape, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
+        return g_dy, g_x, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, padding=0, scale=1.0):
-    """conv2d(x, w * scale) + bias; pass the raw nn.Parameter and its constant scale to get the plane cache"""
-    y = Conv2dFunction.apply(x, w, stride, padding, scale)
+def conv2d(x, w, bias=None, stride=1, padding=0, scale=1.0, pre=None):
+    """conv2d(Blur(x), w * scale) + bias; pass the raw nn.Parameter and its constant scale to get the plane cache.
+    pre = (4 x 4 kernel, pad0, pad1, down): the Blur of a down-sampling ConvLayer folded in (no blurred tensor exists)"""
+    y = Conv2dFunction.apply(x, w, stride, padding, scale, pre)
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
     return y
@@ -704,16 +805,28 @@ class ConvLayer(nn.Sequential):
         # the 1x1 conv at stride 1 on the quarter-size map — implicit GEMM forward and backward, no im2col / col2im.
         blur = getattr(self, "down_blur", None)
         conv = self.equal_conv
+        fold = (FOLD_BLUR and blur is not None and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+                and tuple(blur.kernel.shape) == (4, 4) and min(blur.pad) >= 0)
         if (blur is not None and input.is_cuda and conv.weight.shape[2] == 1 and conv.weight.shape[3] == 1
                 and conv.stride == 2 and conv.padding == 0):
-            x = upfirdn2d(input, blur.kernel, down=2, pad=blur.pad)
-            x = conv2d(x, conv.weight, bias=conv.bias, stride=1, padding=0, scale=conv.scale)
+            if fold:      # Blur (sampled at stride 2) + 1 x 1 convolution as one op: blurred planes straight from the fused kernel
+                x = conv2d(input, conv.weight, bias=conv.bias, stride=1, padding=0, scale=conv.scale,
+                           pre=(blur.kernel, blur.pad[0], blur.pad[1], 2))
+            else:
+                x = upfirdn2d(input, blur.kernel, down=2, pad=blur.pad)
+                x = conv2d(x, conv.weight, bias=conv.bias, stride=1, padding=0, scale=conv.scale)
             for name, m in self.named_children():
                 if name not in ("down_blur", "equal_conv"):
                     x = m(x)
             return x
         act = getattr(self, "flrelu", None)
         if act is not None and input.is_cuda:
+            if fold:
+                pre = (blur.kernel, blur.pad[0], blur.pad[1], 1)
+                if _conv_act_fusable(input, conv, act, pre):
+                    return ConvBiasActFunction.apply(input, conv.weight, act.bias, conv.stride, conv.padding, conv.scale,
+                                                     act.negative_slope, act.scale, pre)
+                return act(conv2d(input, conv.weight, bias=conv.bias, stride=conv.stride, padding=conv.padding, scale=conv.scale, pre=pre))
             x = blur(input) if blur is not None else input
             if _conv_act_fusable(x, conv, act):
                 return ConvBiasActFunction.apply(x, conv.weight, act.bias, conv.stride, conv.padding, conv.scale,
