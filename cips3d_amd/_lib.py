@@ -169,7 +169,6 @@ SIGNATURES = {
     "cips_axpby": (i32, [vp, vp, vp, f32, f32, i64, vp]),
     "cips_image_to_u8": (i32, [vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "cips_upfirdn2d": (i32, [vp, vp, vp] + [i32] * 14 + [vp]),
-    "cips_blur_nhwc_planes": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp]),
     "cips_upfirdn2d_parity": (i32, [vp, C.POINTER(i64 * 4), vp, vp] + [i32] * 7 + [vp]),
     "cips_im2col": (i32, [vp, vp] + [i32] * 8 + [vp]),
     "cips_im2col_x3": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -171,9 +171,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(UpfirArgs a, int 
       const bool rok = (unsigned)iy < (unsigned)a.in_h;
       float x[NX];
       if constexpr (PAR) {
-        const int iyc = min(max(iy, 0), a.in_h - 1), pa = iyc & 1, U = iyc >> 1;
-        const float* p0 = pin.blk[2 * pa] + mj * (long long)pin.np[2 * pa] + (long long)U * pin.ws[0];
-        const float* p1 = pin.blk[2 * pa + 1] + mj * (long long)pin.np[2 * pa + 1] + (long long)U * pin.ws[1];
+        // (no dynamic index into the by-value argument struct: that would move it to scratch)
+        const int iyc = min(max(iy, 0), a.in_h - 1), U = iyc >> 1;
+        const bool odd = iyc & 1;
+        const float* p0 = (odd ? pin.blk[2] : pin.blk[0]) + mj * (long long)(odd ? pin.np[2] : pin.np[0]) + (long long)U * pin.ws[0];
+        const float* p1 = (odd ? pin.blk[3] : pin.blk[1]) + mj * (long long)(odd ? pin.np[3] : pin.np[1]) + (long long)U * pin.ws[1];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = *((rok && cok[i]) ? ((colx[i] & 1) ? p1 : p0) + (colx[i] >> 1) : zp);
       } else {
@@ -789,150 +791,6 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
     }
   }
   hipLaunchKernelGGL(upfirdn2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
-  return CIPS_CHECK_LAUNCH();
-}
-
-// Blur + NHWC split planes in one pass: the 4 x 4 FIR of a down-sampling ConvLayer (up 1, down 1 in
-// front of the 3 x 3 stride-2 convolution, down 2 in front of the 1 x 1 skip convolution: discriminator.py:57-82, 190-203) read
-// from the NCHW fp32 activation and written as what the implicit-GEMM convolution consumes — the NHWC bf16 hi / lo planes of
-// the blurred map, zero last row included.  Replaces upfirdn2d (fp32 out) + split_nhwc (fp32 in): 12 B per element moved
-// instead of 20, one launch, and the blurred fp32 tensor never exists.
-// Workgroup = (image, 32 channels, R output rows x TX output columns).  Phase 1: the input window of every channel goes to
-// LDS, one (channel, row) segment per wave instruction with the lanes along x (coalesced, zero padding materialised).
-// Phase 2: thread = (channel, strip of 4 outputs along x): 4 x (3 DOWN + 4) LDS values, 64 FMAs in the tap order of the
-// stand-alone kernels (kernel rows outer, columns inner, one fma chain per output: bit-identical values).  Channel pitch = 2
-// (mod 64) words and an odd row pitch: the 32 channels of a half-wave hit the even banks, the other half-wave (next strip
-// row) the odd ones.  Phase 3: hi / lo through LDS (reusing the window), 16-byte stores of 8 channels per lane.
-struct BlurNhwcArgs {
-  const float *x, *k;
-  unsigned short *thi, *tlo;
-  int B, C, H, W, Ho, Wo, pad_x0, pad_y0;
-  int R, TX, ntx, rows_in, cols_in, cols_pad, S;     // tile rows / columns, tiles per row, window rows / columns, pitches (words)
-};
-__device__ __forceinline__ unsigned short bn_f2bf(float v) {
-  unsigned u = __float_as_uint(v);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-constexpr int BN_OP = 40;                             // phase-3 pixel pitch in u16 (80 B: 16-byte aligned rows)
-template <int DOWN, int MAXS>
-__global__ __launch_bounds__(256) void blur_nhwc_planes_kernel(BlurNhwcArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float bn_lds[];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int tx = blockIdx.x % a.ntx, ty = blockIdx.x / a.ntx;
-  const int c0 = blockIdx.y * 32, b = blockIdx.z;
-  const int ox0 = tx * a.TX, oy0 = ty * a.R;
-  const int ix0 = ox0 * DOWN - a.pad_x0, iy0 = oy0 * DOWN - a.pad_y0;
-  {
-    const float* xb = a.x + ((long long)b * a.C + c0) * a.H * a.W;
-    const int npairs = 32 * a.rows_in;
-    const int ix = ix0 + lane;
-    const bool cok = lane < a.cols_in && (unsigned)ix < (unsigned)a.W;
-    for (int pr = wave; pr < npairs; pr += 4) {
-      const int ch = pr / a.rows_in, r = pr - ch * a.rows_in;
-      const int iy = iy0 + r;
-      float v = 0.f;
-      if (cok && (unsigned)iy < (unsigned)a.H && c0 + ch < a.C) v = xb[((long long)ch * a.H + iy) * a.W + ix];
-      if (lane < a.cols_pad) bn_lds[ch * a.S + r * a.cols_pad + lane] = v;
-    }
-  }
-  float ck[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) ck[i] = a.k[15 - i];
-  __syncthreads();
-  const int cl = t & 31, s0 = t >> 5;
-  const int nsx = (a.TX + 3) >> 2, nstrips = a.R * nsx;
-  float outv[MAXS][4];
-#pragma unroll
-  for (int j = 0; j < MAXS; ++j) {
-    const int sidx = s0 + 8 * j;
-    const int sc = sidx < nstrips ? sidx : 0;
-    const int ry = sc / nsx, sx = sc - ry * nsx;
-    const float* base = bn_lds + cl * a.S + (ry * DOWN) * a.cols_pad + sx * 4 * DOWN;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky) {
-      float xr[3 * DOWN + 4];
-#pragma unroll
-      for (int i = 0; i < 3 * DOWN + 4; ++i) xr[i] = base[ky * a.cols_pad + i];
-#pragma unroll
-      for (int kx = 0; kx < 4; ++kx)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) acc[o] = fmaf(xr[o * DOWN + kx], ck[ky * 4 + kx], acc[o]);
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) outv[j][o] = acc[o];
-  }
-  __syncthreads();                                    // every window read is done: the window becomes the output tile
-  unsigned short* oh = reinterpret_cast<unsigned short*>(bn_lds);
-  const int txp = nsx * 4;
-  unsigned short* ol = oh + a.R * txp * BN_OP;
-#pragma unroll
-  for (int j = 0; j < MAXS; ++j) {
-    const int sidx = s0 + 8 * j;
-    if (sidx < nstrips) {
-      const int ry = sidx / nsx, sx = sidx - ry * nsx;
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        const float v = outv[j][o];
-        const unsigned short h = bn_f2bf(v);
-        const unsigned short l = bn_f2bf(v - __uint_as_float(((unsigned)h) << 16));
-        const int pix = ry * txp + sx * 4 + o;
-        oh[pix * BN_OP + cl] = h;
-        ol[pix * BN_OP + cl] = l;
-      }
-    }
-  }
-  __syncthreads();
-  const int nitems = a.R * a.TX * 4;
-  for (int it = t; it < nitems; it += 256) {
-    const int g8 = it & 3, pq = it >> 2;
-    const int ry = pq / a.TX, ox = pq - ry * a.TX;
-    const int oy = oy0 + ry, oxg = ox0 + ox;
-    if (oy < a.Ho && oxg < a.Wo && c0 + 8 * g8 < a.C) {
-      const long long o = (((long long)b * a.Ho + oy) * a.Wo + oxg) * a.C + c0 + 8 * g8;
-      *reinterpret_cast<uint4*>(a.thi + o) = *reinterpret_cast<const uint4*>(oh + (ry * txp + ox) * BN_OP + 8 * g8);
-      *reinterpret_cast<uint4*>(a.tlo + o) = *reinterpret_cast<const uint4*>(ol + (ry * txp + ox) * BN_OP + 8 * g8);
-    }
-  }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-    const long long z = (long long)a.B * a.Ho * a.Wo * a.C;
-    for (int i = t; i < a.C; i += 256) { a.thi[z + i] = 0; a.tlo[z + i] = 0; }
-  }
-}
-
-extern "C" int cips_blur_nhwc_planes(const float* x, const float* kernel, void* t_hi, void* t_lo, int B, int C, int H, int W,
-                                     int down, int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream) {
-  if (!x || !kernel || !t_hi || !t_lo || B <= 0 || C <= 0 || H <= 0 || W <= 0 || pad_x0 < 0 || pad_y0 < 0 || pad_x1 < 0 || pad_y1 < 0)
-    return (int)hipErrorInvalidValue;
-  if ((down != 1 && down != 2) || (C & 7)) return (int)hipErrorNotSupported;
-  BlurNhwcArgs a;
-  a.x = x; a.k = kernel; a.thi = (unsigned short*)t_hi; a.tlo = (unsigned short*)t_lo;
-  a.B = B; a.C = C; a.H = H; a.W = W; a.pad_x0 = pad_x0; a.pad_y0 = pad_y0;
-  a.Ho = (H + pad_y0 + pad_y1 - 4) / down + 1;
-  a.Wo = (W + pad_x0 + pad_x1 - 4) / down + 1;
-  if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
-  const int txmax = down == 1 ? 36 : 16, rmax = down == 1 ? 4 : 3;
-  a.ntx = (a.Wo + txmax - 1) / txmax;
-  a.TX = (a.Wo + a.ntx - 1) / a.ntx;
-  const int nty0 = (a.Ho + rmax - 1) / rmax;
-  a.R = (a.Ho + nty0 - 1) / nty0;
-  const int nty = (a.Ho + a.R - 1) / a.R;
-  const int nsx = (a.TX + 3) / 4;
-  a.rows_in = (a.R - 1) * down + 4;
-  a.cols_in = (a.TX - 1) * down + 4;
-  const int need = (nsx * 4 - 1) * down + 4;         // the last strip of a row reads past cols_in (its outputs are masked)
-  a.cols_pad = (need > a.cols_in ? need : a.cols_in) | 1;
-  if (a.cols_pad > 64) return (int)hipErrorNotSupported;
-  int S = a.rows_in * a.cols_pad;
-  while ((S & 63) != 2) ++S;
-  a.S = S;
-  const size_t lds_bytes = (size_t)32 * S * 4 + 64;
-  if ((size_t)2 * a.R * nsx * 4 * BN_OP * 2 > lds_bytes) return (int)hipErrorNotSupported;
-  if (a.R * nsx > 8 * (down == 1 ? 5 : 2)) return (int)hipErrorNotSupported;
-  dim3 grid((unsigned)(a.ntx * nty), (unsigned)((C + 31) / 32), (unsigned)B);
-  if (down == 1) hipLaunchKernelGGL((blur_nhwc_planes_kernel<1, 5>), grid, dim3(256), lds_bytes, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((blur_nhwc_planes_kernel<2, 2>), grid, dim3(256), lds_bytes, (hipStream_t)stream, a);
   return CIPS_CHECK_LAUNCH();
 }
 

@@ -65,7 +65,7 @@ struct ConvGeom {
 // stride-2 convolution is four (one per parity class of the input pixel: every class is a small stride-1 convolution over
 // dy with its own tap window, output plane and filter bank), run by ONE persistent launch.
 struct ConvPart {
-  int tile0, tiles_n;          // first tile of the range; tiles per output plane along the pixel dimension
+  int ntiles, tiles_n;         // tiles of the range; tiles per output plane along the pixel dimension
   int kw, pad_y, pad_x, Wo;    // tap window width, top / left padding, output plane width
   int N, K, lda;               // output pixels per image (rows of B; a multiple of 8), contraction length, A row pitch
   int ldc;                     // output row pitch
@@ -523,10 +523,25 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
       int bid = base + idx;
       int tiles_n = g.tiles_n;
       if (g.nparts > 0) {
-        int pi = 0;
-        while (pi + 1 < g.nparts && bid >= g.part[pi + 1].tile0) ++pi;
+        // several ranges with different contraction lengths: every XCD takes ITS eighth of EVERY range (contiguous inside
+        // the range, for L2 reuse of the operands), longest range first — one contiguous eighth of the whole sequence would
+        // hand XCD 0 only the long tiles and XCD 7 only the short ones.  g.total = 8 x the longest per-XCD sequence; a slot
+        // past an XCD's own count is empty.
+        int left = idx, pi = 0;
+        bool found = false;
+        for (; pi < g.nparts; ++pi) {
+          const int T = g.part[pi].ntiles, pq = T / nx, pr = T % nx;
+          const int share = pq + (xcd < pr ? 1 : 0);
+          if (left < share) {
+            bid = ((xcd < pr) ? xcd * (pq + 1) : pr * (pq + 1) + (xcd - pr) * pq) + left;
+            found = true;
+            break;
+          }
+          left -= share;
+        }
+        if (!found) continue;
         const ConvPart& cp = g.part[pi];
-        bid -= cp.tile0; tiles_n = cp.tiles_n;
+        tiles_n = cp.tiles_n;
         N = cp.N; K = cp.K; lda = cp.lda; ldc = cp.ldc; p_kw = cp.kw; pad_y = cp.pad_y; pad_x = cp.pad_x; p_Wo = cp.Wo;
         a_off = cp.a_off; c_off = cp.c_off; strideC = cp.strideC;
       }
@@ -831,18 +846,24 @@ extern "C" int cips_conv2d_x3_dgrad_s2(const cips_conv_dgrad_s2_desc* c, cips_st
       cp.a_off = c->w_off[2 * a + b]; cp.c_off = c->out_off[2 * a + b];
       if ((cp.a_off & 7) || (cp.c_off & 3)) return (int)hipErrorInvalidValue;
       cp.tiles_n = (cp.N + BN - 1) / BN;
-      cp.tile0 = (int)tile0;
-      tile0 += (long long)g.tiles_m * cp.tiles_n * c->B;
+      const long long nt = (long long)g.tiles_m * cp.tiles_n * c->B;
+      if (nt > 0x0fffffffLL) return (int)hipErrorInvalidValue;
+      cp.ntiles = (int)nt;
+      tile0 += nt;
     }
-  if (np == 0 || tile0 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  if (np == 0 || tile0 > 0x0fffffffLL) return (int)hipErrorInvalidValue;
   // longest contraction first: the persistent grid then ends on the short tiles
   for (int i = 0; i < np; ++i)
     for (int j = i + 1; j < np; ++j)
       if (g.part[j].K > g.part[i].K) { ConvPart t = g.part[i]; g.part[i] = g.part[j]; g.part[j] = t; }
-  tile0 = 0;
-  for (int i = 0; i < np; ++i) { g.part[i].tile0 = (int)tile0; tile0 += (long long)g.tiles_m * g.part[i].tiles_n * c->B; }
+  int longest = 0;                                    // slots per XCD: its share of every range
+  for (int x = 0; x < 8; ++x) {
+    int n = 0;
+    for (int i = 0; i < np; ++i) n += g.part[i].ntiles / 8 + (x < g.part[i].ntiles % 8 ? 1 : 0);
+    if (n > longest) longest = n;
+  }
   g.nparts = np;
-  g.total = (int)tile0;
+  g.total = 8 * longest;
   g.tiles_n = g.part[0].tiles_n;
   static bool attr = false;
   CIPS_PER_DEVICE(attr, false);

@@ -288,7 +288,8 @@ class _share_planes:
 
 
 def _nhwc(t, pre=None):
-    """NHWC split planes of t — of Blur(t) when `pre` is given (one fused pass, cips_blur_nhwc_planes)"""
+    """NHWC split planes of t — of Blur(t) when `pre` is given (upfirdn2d + split: a fused kernel was built, was bit-identical
+    and did not beat the two, profiles/r6_blur_nhwc_planes_experiment.txt)"""
     m = _memo()
     key = _key(t) + _pre_sig(pre)
     ent = m.shared.get(key)
@@ -297,7 +298,7 @@ def _nhwc(t, pre=None):
     if pre is None:
         p = ops.split_planes_nhwc(t)
     else:
-        p, _, _ = ops.blur_nhwc_planes(t.contiguous(), pre[0], pre[3], pre[1], pre[2])
+        p = ops.split_planes_nhwc(_pre_fp32(t, pre))
     if m.depth:
         m.shared[key] = (t, p)
     return p
@@ -307,7 +308,7 @@ def _nhwc(t, pre=None):
 # The Blur of a down-sampling ConvLayer folded into its convolution: `pre` = (kernel (4 x 4 buffer),
 # pad0, pad1, down) describes y = conv(upfirdn2d(x, kernel, down=down, pad=(pad0, pad1)), w).  The three convolution
 # Functions below carry it through every order of differentiation: forward and weight gradient read the blurred planes
-# straight from the fused blur + split kernel (the blurred fp32 tensor never exists), the data gradient ends in the
+# (made once per tensor and shared between them; the blurred tensor is a temporary of that step, not a node of the graph), the data gradient ends in the
 # Blur's transpose — for the 3 x 3 stride-2 layers applied directly to the parity blocks of cips_conv2d_x3_dgrad_s2.
 # ------------------------------------------------------------------------------------------
 def _pre_sig(pre):

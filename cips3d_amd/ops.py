@@ -1131,20 +1131,6 @@ def split_planes_nhwc(x):
     return Planes(hi, lo)
 
 
-def blur_nhwc_planes(x, kernel, down, pad0, pad1):
-    """upfirdn2d(x, kernel (4 x 4), up 1, down, pad (pad0, pad1)) written directly as NHWC split planes
-    (cips_blur_nhwc_planes) -> (Planes (B*Ho*Wo + 1, C), Ho, Wo)"""
-    lib = _lib.load()
-    B, C, H, W = x.shape
-    k = _native_in(kernel, "kernel")
-    Ho, Wo = (H + pad0 + pad1 - 4) // down + 1, (W + pad0 + pad1 - 4) // down + 1
-    hi = torch.empty(B * Ho * Wo + 1, C, device=x.device, dtype=BF)
-    lo = torch.empty(B * Ho * Wo + 1, C, device=x.device, dtype=BF)
-    check(lib.cips_blur_nhwc_planes(_p(x), _p(k), _p(hi), _p(lo), B, C, H, W, down, pad0, pad1, pad0, pad1, _stream()),
-          "cips_blur_nhwc_planes")
-    return Planes(hi, lo), Ho, Wo
-
-
 def conv2d_x3(wP, xP, B, C, H, W, O, kh, kw, stride, pad, ksplit=None, bias=None, act=False, slope=0.2, act_scale=1.0):
     """Implicit-GEMM convolution: wP Planes (O, kh*kw*C) with contraction index (tap, channel), xP NHWC Planes from
     split_planes_nhwc -> y (B, O, Ho, Wo) fp32."""
@@ -1204,8 +1190,11 @@ def conv2d_x3_dgrad_s2(banks, w_off, dyP, B, C, H, W, O, kh, kw):
     lib = _lib.load()
     from ._lib import ConvDgradS2Desc
     nps = dgrad_s2_layout(H, W)
+    # the four blocks are read TOGETHER by upfirdn2d_parity (one output needs all four parities); with B*C a power of two
+    # their natural offsets are congruent modulo 64 KiB and the four streams queue on the same memory channels — skew them
     out_off, tot = [], 0
-    for n_ in nps:
+    for i, n_ in enumerate(nps):
+        tot += i * 1184                     # floats: 4 736 B, 16-byte granular
         out_off.append(tot)
         tot += B * C * n_
     dxp = torch.empty(tot, device=dyP.hi.device)

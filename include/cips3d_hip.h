@@ -389,13 +389,6 @@ int cips_conv_wgrad_finish(const float* part, float* dw, int nchunks, int taps, 
  * 16-byte loads, any other n scalar loads). */
 int cips_split_planes_nhwc(const float* x, void* t_hi, void* t_lo, int B, int C, int n, cips_stream_t stream);
 
-/* Blur + cips_split_planes_nhwc in one pass: the 4 x 4 FIR `kernel` (up 1, down 1 or 2, non-negative padding — the Blur of
- * a down-sampling ConvLayer, exp/cips3d/models/discriminator.py:57-82, 190-203, upfirdn2d.py:87-149) applied to x (B, C, H, W)
- * fp32 NCHW and written as the NHWC split planes (B*Ho*Wo + 1, C) of the result, zero last row included, Ho = (H + pad_y0 +
- * pad_y1 - 4) / down + 1.  Values are those of cips_upfirdn2d followed by cips_split_planes_nhwc, bit for bit.  C % 8 == 0. */
-int cips_blur_nhwc_planes(const float* x, const float* kernel, void* t_hi, void* t_lo, int B, int C, int H, int W,
-                          int down, int pad_x0, int pad_x1, int pad_y0, int pad_y1, cips_stream_t stream);
-
 /* fp32 (rows, cols) [ldx] -> split bf16 planes row-major [rows][ldp] and/or transposed [cols][ldt]. */
 int cips_split_planes(const float* x, void* p_hi, void* p_lo, void* t_hi, void* t_lo, int rows, int cols,
                       int ldx, int ldp, int ldt, int batch, long long stride_x, long long stride_p,

@@ -512,30 +512,10 @@ def test_stride2_data_gradient_as_parity_subconvolutions(cfg):
             ops.conv2d_x3_dgrad_s2(b32, o32, ops.split_planes_nhwc(dy[:, :32].float().to(d)), B, C, H, H, 32, k, k)
 
 
-@pytest.mark.parametrize("cfg", [(2, 64, 64, 64, 1, 2, 2), (2, 64, 64, 64, 2, 1, 1), (3, 32, 32, 32, 1, 2, 2), (2, 96, 16, 16, 2, 1, 1),
-                                 (1, 40, 20, 28, 1, 2, 2), (2, 128, 130, 130, 1, 2, 2), (2, 64, 9, 9, 1, 2, 2), (1, 64, 130, 130, 2, 1, 1),
-                                 (2, 64, 17, 23, 2, 1, 1), (1, 512, 64, 64, 1, 2, 2)])
-def test_blur_written_as_nhwc_planes_is_the_two_kernels_bit_for_bit(cfg):
-    """cips_blur_nhwc_planes: the 4 x 4 Blur of a down-sampling ConvLayer written directly as the
-    NHWC split planes the implicit-GEMM convolution reads — against cips_upfirdn2d followed by cips_split_planes_nhwc: the
-    same bf16 hi / lo planes, bit for bit, zero row included (ragged tiles, channel counts that are not multiples of 32)."""
-    from cips3d_amd import ops
-    from cips3d_amd import discriminator as dm
-    B, C, H, W, down, p0, p1 = cfg
-    d = torch.device("cuda:0")
-    x = torch.randn(B, C, H, W, device=d, generator=torch.Generator(device=d).manual_seed(H * 7 + C))
-    k = dm.make_kernel([1, 3, 3, 1]).to(d)
-    P, Ho, Wo = ops.blur_nhwc_planes(x, k, down, p0, p1)
-    ref = ops.upfirdn2d_op(x.reshape(-1, H, W, 1), k, 1, 1, down, down, p0, p1, p0, p1).view(B, C, Ho, Wo)
-    R = ops.split_planes_nhwc(ref.contiguous())
-    assert P.hi.shape == R.hi.shape
-    assert torch.equal(P.hi.view(torch.int16), R.hi.view(torch.int16)) and torch.equal(P.lo.view(torch.int16), R.lo.view(torch.int16))
-
-
 @pytest.mark.parametrize("cfg", [(2, 64, 64, 64, False), (2, 64, 128, 32, False), (2, 64, 64, 32, True), (2, 64, 64, 16, False),
                                  (2, 32, 32, 64, True)])
 def test_resblock_with_the_blur_folded_into_its_convolutions(cfg, monkeypatch):
-    """ResBlock (discriminator.py:224-252) with FOLD_BLUR — blurred planes from the fused blur + split kernel, the stride-2
+    """ResBlock (discriminator.py:224-252) with FOLD_BLUR — the Blur inside the convolution Functions, the stride-2
     data gradient as parity sub-convolutions with the Blur's transpose read from the parity blocks, no UpFirDn2d node —
     against the same block with the Blur as its own op: output, R1-style input gradient, and the double backward into input,
     weights and biases.  The forward is bit-identical (same planes, same GEMM); gradients agree to the split-bf16 class."""
