@@ -289,9 +289,20 @@ class _share_planes:
 
 def _nhwc(t, pre=None):
     """NHWC split planes of t — of Blur(t) when `pre` is given (upfirdn2d + split: a fused kernel was built, was bit-identical
-    and did not beat the two, profiles/r6_blur_nhwc_planes_experiment.txt)"""
+    and did not beat the two, profiles/r6_blur_nhwc_planes_experiment.txt).
+
+    The planes travel WITH the tensor object (attribute `_cips_nhwc`, checked against the version counter): a convolution's
+    input keeps them from its forward to every later backward that needs them for the weight gradient (the tensor is saved by
+    the node anyway), and a gradient tensor keeps them from the data-gradient node to the weight-gradient node, which are
+    separate autograd nodes (_WeightGradPort).  They die with the tensor."""
+    sig = _pre_sig(pre)
+    att = getattr(t, "_cips_nhwc", None)
+    if att is not None and att[0] == t._version and att[1] == t.data_ptr():
+        hit = att[2].get(sig)
+        if hit is not None:
+            return hit
     m = _memo()
-    key = _key(t) + _pre_sig(pre)
+    key = _key(t) + sig
     ent = m.shared.get(key)
     if ent is not None:
         return ent[1]
@@ -301,6 +312,13 @@ def _nhwc(t, pre=None):
         p = ops.split_planes_nhwc(_pre_fp32(t, pre))
     if m.depth:
         m.shared[key] = (t, p)
+    if att is not None and att[0] == t._version and att[1] == t.data_ptr():
+        att[2][sig] = p
+    else:
+        try:
+            t._cips_nhwc = (t._version, t.data_ptr(), {sig: p})
+        except Exception:                            # noqa: BLE001 — a tensor subclass without a __dict__: no caching
+            pass
     return p
 
 
@@ -591,42 +609,83 @@ def _conv_bwd_weight_raw(dy, x, w_shape, stride, pad, scale):
     return part.sum(0).view(O, C, kh, kw)
 
 
-class Conv2dFunction(Function):
-    """y = conv(x, w * scale).  `scale` is EqualConv2d's constant 1/sqrt(C k^2) (discriminator.py:33, 44): keeping it
-    out of the tensor lets the parameter itself arrive here, so that its operand planes can be cached (_cached)."""
+class _WeightGradPort(Function):
+    """(w, x) -> a stride-0 zero tensor shaped like the convolution's output, handed to the convolution node as a third input.
+    Its only purpose is to be a SEPARATE NODE in front of the weight: the convolution node sends dy back through it, and the
+    engine runs this backward — the weight gradient — only in graph tasks that ask for d/dw.  torch.autograd.grad(r_preds.sum(),
+    real_imgs, create_graph=True) of the R1 penalty (train.py:387-394) does not; torch's own conv2d learns that from
+    task_should_compute_output, a Python Function's ctx.needs_input_grad is fixed at forward time and said "yes": before round
+    6 every convolution computed (and dropped) its weight gradient in that pass — a quarter of all weight-gradient GEMMs of
+    the D step.  The backward is Conv2dBwdWeightFunction, so every higher order is unchanged."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, pad, scale=1.0, pre=None):
+    def forward(ctx, w, xbox, out_shape, stride, pad, scale, pre):
+        # x arrives boxed, NOT as a graph input: with an edge to x this node would sit on every path to the images and run in
+        # the R1 pass after all.  The reference keeps x's own graph (the weight gradient's dependence on x is differentiated
+        # through Conv2dBwdWeightFunction when this backward runs under create_graph).
+        ctx.x = xbox[0]
+        ctx.cfg = (tuple(w.shape), stride, pad, scale, pre)
+        return w.new_zeros(1).expand(out_shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        w_shape, stride, pad, scale, pre = ctx.cfg
+        with _share_planes():
+            dw = Conv2dBwdWeightFunction.apply(g, ctx.x, w_shape, stride, pad, scale, pre)
+        return dw, None, None, None, None, None, None
+
+
+def _weight_port(x, w, out_shape, stride, pad, scale, pre):
+    if torch.is_grad_enabled() and w.requires_grad:
+        return _WeightGradPort.apply(w, (x,), out_shape, stride, pad, scale, pre)
+    return None
+
+
+def _conv_out_shape(x, w, stride, pad, pre):
+    Hb, Wb = _pre_shape(x.shape[2], x.shape[3], pre)
+    return (x.shape[0], w.shape[0], (Hb + 2 * pad - w.shape[2]) // stride + 1, (Wb + 2 * pad - w.shape[3]) // stride + 1)
+
+
+class Conv2dFunction(Function):
+    """y = conv(Blur(x), w * scale).  `scale` is EqualConv2d's constant 1/sqrt(C k^2) (discriminator.py:33, 44): keeping it
+    out of the tensor lets the parameter itself arrive here, so that its operand planes can be cached (_cached).  `port`: the
+    weight's _WeightGradPort (or None): dy goes back through it, the weight gradient is that node's."""
+
+    @staticmethod
+    def forward(ctx, x, w, port, stride, pad, scale=1.0, pre=None):
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.pad, ctx.scale, ctx.pre = stride, pad, scale, pre
         ctx.w_obj = w if isinstance(w, nn.Parameter) else None       # the Parameter object: the cache key
         with _share_planes():
             y = _conv_fwd(x, w, stride, pad, scale, pre)
-            ctx.xP = _shared.get(_key(x) + _pre_sig(pre)) if ctx.needs_input_grad[1] else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         w = ctx.w_obj if ctx.w_obj is not None else w
-        dx = dw = None
+        dx = None
         dy = dy.contiguous()
-        with _share_planes((x, ctx.xP, ctx.pre)):
+        with _share_planes():
             if ctx.needs_input_grad[0]:
                 dx = Conv2dBwdDataFunction.apply(dy, w, x.shape, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
-            if ctx.needs_input_grad[1]:
-                dw = Conv2dBwdWeightFunction.apply(dy, x, w.shape, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
-        ctx.xP = None
-        return dx, dw, None, None, None, None
+        return dx, None, (dy if ctx.needs_input_grad[2] else None), None, None, None, None
+
+
+def _conv_apply(x, w, stride, pad, scale=1.0, pre=None):
+    x = x.contiguous()
+    return Conv2dFunction.apply(x, w, _weight_port(x, w, _conv_out_shape(x, w, stride, pad, pre), stride, pad, scale, pre),
+                                stride, pad, scale, pre)
 
 
 class ConvBiasActFunction(Function):
     """out = leaky_relu(conv(x, w * scale) + bias, slope) * act_scale in ONE kernel (bias and activation in the epilogue
     of the implicit-GEMM convolution): EqualConv2d followed by FusedLeakyReLU (discriminator.py:205-215).  The backward is
-    the composition of the two layers' own backward Functions, so every higher-order path (R1) is theirs."""
+    the composition of the two layers' own backward Functions, so every higher-order path (R1) is theirs; the weight
+    gradient is the port's (see _WeightGradPort)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, scale, slope, act_scale, pre=None):
+    def forward(ctx, x, w, bias, port, stride, pad, scale, slope, act_scale, pre=None):
         B, C, H, W = x.shape
         O, _, kh, kw = w.shape
         x = x.contiguous()
@@ -634,7 +693,6 @@ class ConvBiasActFunction(Function):
         with _share_planes():
             out = ops.conv2d_x3(_w_planes(w, scale), _nhwc(x, pre), B, C, Hb, Wb, O, kh, kw, stride, pad, bias=bias.detach().contiguous(),
                                 act=True, slope=slope, act_scale=act_scale)
-            ctx.xP = _shared.get(_key(x) + _pre_sig(pre)) if ctx.needs_input_grad[1] else None
         ctx.save_for_backward(x, w, out)
         ctx.cfg = (stride, pad, scale, slope, act_scale, pre)
         ctx.w_obj = w if isinstance(w, nn.Parameter) else None
@@ -646,14 +704,18 @@ class ConvBiasActFunction(Function):
         w = ctx.w_obj if ctx.w_obj is not None else w
         stride, pad, scale, slope, act_scale, pre = ctx.cfg
         dpre, dbias = FusedLeakyReLUFunctionBackward.apply(dout.contiguous(), out, slope, act_scale)
-        dx = dw = None
-        with _share_planes((x, ctx.xP, pre)):
+        dx = None
+        with _share_planes():
             if ctx.needs_input_grad[0]:
                 dx = Conv2dBwdDataFunction.apply(dpre, w, x.shape, stride, pad, scale, pre)
-            if ctx.needs_input_grad[1]:
-                dw = Conv2dBwdWeightFunction.apply(dpre, x, w.shape, stride, pad, scale, pre)
-        ctx.xP = None
-        return dx, dw, (dbias if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
+        return (dx, None, (dbias if ctx.needs_input_grad[2] else None), (dpre if ctx.needs_input_grad[3] else None),
+                None, None, None, None, None, None)
+
+
+def _conv_bias_act_apply(x, w, bias, stride, pad, scale, slope, act_scale, pre=None):
+    x = x.contiguous()
+    return ConvBiasActFunction.apply(x, w, bias, _weight_port(x, w, _conv_out_shape(x, w, stride, pad, pre), stride, pad, scale, pre),
+                                     stride, pad, scale, slope, act_scale, pre)
 
 
 FOLD_BLUR = True            # False: Blur as its own upfirdn2d node in front of the convolution (the folding's parity test flips it)
@@ -690,7 +752,7 @@ class Conv2dBwdDataFunction(Function):
         ggx = ggx.contiguous()
         with _share_planes():
             if ctx.needs_input_grad[0]:
-                g_dy = Conv2dFunction.apply(ggx, w, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
+                g_dy = _conv_apply(ggx, w, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
             if ctx.needs_input_grad[1]:
                 g_w = Conv2dBwdWeightFunction.apply(dy, ggx, w.shape, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
         return g_dy, g_w, None, None, None, None, None
@@ -710,7 +772,7 @@ class Conv2dBwdWeightFunction(Function):
         dy, x = ctx.saved_tensors
         g_dy = g_x = None
         if ctx.needs_input_grad[0]:
-            g_dy = Conv2dFunction.apply(x, ggw, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
+            g_dy = _conv_apply(x, ggw, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
         if ctx.needs_input_grad[1]:
             g_x = Conv2dBwdDataFunction.apply(dy, ggw, x.shape, ctx.stride, ctx.pad, ctx.scale, ctx.pre)
         return g_dy, g_x, None, None, None, None, None
@@ -719,7 +781,7 @@ class Conv2dBwdWeightFunction(Function):
 def conv2d(x, w, bias=None, stride=1, padding=0, scale=1.0, pre=None):
     """conv2d(Blur(x), w * scale) + bias; pass the raw nn.Parameter and its constant scale to get the plane cache.
     pre = (4 x 4 kernel, pad0, pad1, down): the Blur of a down-sampling ConvLayer folded in (no blurred tensor exists)"""
-    y = Conv2dFunction.apply(x, w, stride, padding, scale, pre)
+    y = _conv_apply(x, w, stride, padding, scale, pre)
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
     return y
@@ -825,13 +887,13 @@ class ConvLayer(nn.Sequential):
             if fold:
                 pre = (blur.kernel, blur.pad[0], blur.pad[1], 1)
                 if _conv_act_fusable(input, conv, act, pre):
-                    return ConvBiasActFunction.apply(input, conv.weight, act.bias, conv.stride, conv.padding, conv.scale,
-                                                     act.negative_slope, act.scale, pre)
+                    return _conv_bias_act_apply(input, conv.weight, act.bias, conv.stride, conv.padding, conv.scale,
+                                                act.negative_slope, act.scale, pre)
                 return act(conv2d(input, conv.weight, bias=conv.bias, stride=conv.stride, padding=conv.padding, scale=conv.scale, pre=pre))
             x = blur(input) if blur is not None else input
             if _conv_act_fusable(x, conv, act):
-                return ConvBiasActFunction.apply(x, conv.weight, act.bias, conv.stride, conv.padding, conv.scale,
-                                                 act.negative_slope, act.scale)
+                return _conv_bias_act_apply(x, conv.weight, act.bias, conv.stride, conv.padding, conv.scale,
+                                            act.negative_slope, act.scale)
             return act(conv(x))
         return super().forward(input)
 
