@@ -55,6 +55,9 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
 // (oy*stride - pad + ky, ox*stride - pad + kx) of the NHWC planes, or the zero row behind the last image.
 struct ConvGeom {
   int C, H, W, kw, stride, pad, Wo;
+  int nimg;                    // conv2d_x3_v3_kernel: > 0 = the batch is FOLDED into the pixel dimension (output planes of fewer
+                               // than 256 pixels: one GEMM column range over B * nimg pixels instead of B mostly empty tiles);
+                               // nimg = pixels per image (a multiple of 8), d.N = B * nimg, d.batch = 1
   long long img_stride;        // H*W*C elements
   long long zero_elem;         // element offset of the zero row from the start of the planes
   const float* bias;           // optional per-output-channel bias (row of the GEMM), added before the activation
@@ -68,6 +71,7 @@ struct ConvPart {
   int ntiles, tiles_n;         // tiles of the range; tiles per output plane along the pixel dimension
   int kw, pad_y, pad_x, Wo;    // tap window width, top / left padding, output plane width
   int N, K, lda;               // output pixels per image (rows of B; a multiple of 8), contraction length, A row pitch
+  int nimg;                    // batch folding for this range (see ConvGeom::nimg): N = B * nimg then
   int ldc;                     // output row pitch
   long long a_off, c_off;      // element offsets of this range's filter bank (A planes) and output block (C)
   long long strideC;           // output elements per image
@@ -514,6 +518,7 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
     int tm, tn, bz, kc;
     // geometry of this tile's range (uniform values: scalar registers)
     int N = d.N, K = d.K, lda = d.lda, ldc = d.ldc, p_kw = g.cv.kw, pad_y = g.cv.pad, pad_x = g.cv.pad, p_Wo = g.cv.Wo;
+    int nimg = g.cv.nimg;
     long long a_off = 0, c_off = 0, strideC = d.strideC;
     {
       const int nx = 8;
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
         const ConvPart& cp = g.part[pi];
         tiles_n = cp.tiles_n;
         N = cp.N; K = cp.K; lda = cp.lda; ldc = cp.ldc; p_kw = cp.kw; pad_y = cp.pad_y; pad_x = cp.pad_x; p_Wo = cp.Wo;
-        a_off = cp.a_off; c_off = cp.c_off; strideC = cp.strideC;
+        a_off = cp.a_off; c_off = cp.c_off; strideC = cp.strideC; nimg = cp.nimg;
       }
       tn = bid % tiles_n;
       tm = (bid / tiles_n) % g.tiles_m;
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
     const u16* Bhi = (const u16*)d.B_hi + (long long)bz * g.cv.img_stride;
     const u16* Blo = (const u16*)d.B_lo + (long long)bz * g.cv.img_stride;
     const unsigned zero_rel = (unsigned)((g.cv.zero_elem - (long long)bz * g.cv.img_stride) * 2);
-    unsigned offA[2], offB[2], chunk[2];
+    unsigned offA[2], offB[2], chunk[2], imgoff[2];
     int iy0[2], ix0[2];
     {
       const int drow = lane >> 2, dslot = lane & 3;
@@ -572,7 +577,14 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
         const int kcsw = dslot ^ ((row >> 2) & 3);
         const int ra = (row < M - m0) ? row : (M - m0 - 1), rb = (row < N - n0) ? row : (N - n0 - 1);
         offA[p] = (unsigned)(ra * lda + kcsw * 8) * 2u;
-        const int pix = n0 + rb, oy = pix / p_Wo, ox = pix - oy * p_Wo;
+        int pix = n0 + rb;
+        imgoff[p] = 0u;
+        if (nimg > 0) {                                      // folded batch: this row's image
+          const int iq = pix / nimg;
+          pix -= iq * nimg;
+          imgoff[p] = (unsigned)((long long)iq * g.cv.img_stride * 2);
+        }
+        const int oy = pix / p_Wo, ox = pix - oy * p_Wo;
         iy0[p] = oy * g.cv.stride - pad_y;
         ix0[p] = ox * g.cv.stride - pad_x;
         chunk[p] = (unsigned)kcsw * 16u;
@@ -586,7 +598,7 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
       for (int p = 0; p < 2; ++p) {
         const int iy = iy0[p] + ky, ix = ix0[p] + kx;
         const bool ok = (unsigned)iy < (unsigned)g.cv.H && (unsigned)ix < (unsigned)g.cv.W;
-        offB[p] = (ok ? (unsigned)(((iy * g.cv.W + ix) * g.cv.C + c0) * 2) : zero_rel) + chunk[p];
+        offB[p] = (ok ? (unsigned)(((iy * g.cv.W + ix) * g.cv.C + c0) * 2) + imgoff[p] : zero_rel) + chunk[p];
       }
     };
     auto dma = [&](const u16* plane_k, unsigned off, unsigned la) {
@@ -700,6 +712,10 @@ __global__ __launch_bounds__(512) void conv2d_x3_v3_kernel(WArgs g) {
         }
         if (row < M && col < N) {
           float* q = d.C + cb + (long long)row * ldc + col;
+          if (nimg > 0) {                                    // folded batch: column = (image, pixel); 8 | nimg keeps the 8 of a lane in one image
+            const int iq = col / nimg;
+            q = d.C + cb + ((long long)iq * M + row) * nimg + (col - iq * nimg);
+          }
           *reinterpret_cast<float4*>(q) = make_float4(y[0], y[1], y[2], y[3]);
           *reinterpret_cast<float4*>(q + 4) = make_float4(y[4], y[5], y[6], y[7]);
         }
@@ -778,6 +794,13 @@ extern "C" int cips_conv2d_x3(const cips_conv_x3_desc* c, cips_stream_t stream) 
   d.C = c->y; d.ldc = (int)N; d.strideC = (long long)c->O * N; d.slope = 0.2f;
   g.cv.C = c->C; g.cv.H = c->H; g.cv.W = c->W; g.cv.kw = c->kw; g.cv.stride = c->stride; g.cv.pad = c->pad; g.cv.Wo = Wo;
   g.cv.img_stride = img; g.cv.zero_elem = img * c->B;
+  // small output planes: the batch folded into the pixel dimension (the two-register-set kernel only: every chunk of the
+  // contraction needs two k-tiles; a one-k-tile problem keeps the per-image tiles of the wide kernel)
+  const bool fold = N < BN && c->B > 1 && (K / 32) / (c->ksplit > 1 ? c->ksplit : 1) >= 2;
+  if (fold) {
+    if ((long long)c->B * N > 0x7fffffffLL) return (int)hipErrorNotSupported;
+    g.cv.nimg = (int)N; d.N = (int)(c->B * N); d.batch = 1; d.strideC = (long long)c->B * c->O * N;
+  }
   g.tiles_m = (d.M + BM - 1) / BM;
   g.tiles_n = (d.N + BN - 1) / BN;
   const int ks = c->ksplit > 1 ? c->ksplit : 1;
@@ -839,14 +862,17 @@ extern "C" int cips_conv2d_x3_dgrad_s2(const cips_conv_dgrad_s2_desc* c, cips_st
       if (Ta <= 0 || Tb <= 0 || Hs <= 0 || Ws <= 0) continue;          // (a 1-tap kernel has no odd class: its gradient there is zero — caller's fill)
       ConvPart& cp = g.part[np++];
       cp.kw = Tb; cp.pad_y = Ta - 1; cp.pad_x = Tb - 1; cp.Wo = Ws;
-      cp.N = (Hs * Ws + 7) & ~7;
+      const int np_img = (Hs * Ws + 7) & ~7;
+      const bool fold = np_img < BN && c->B > 1;       // small planes: the batch folded into the pixel dimension
+      cp.nimg = fold ? np_img : 0;
+      cp.N = fold ? np_img * c->B : np_img;
       cp.K = Ta * Tb * c->O; cp.lda = cp.K;
       if (cp.K / BK < 2) return (int)hipErrorNotSupported;
-      cp.ldc = cp.N; cp.strideC = (long long)c->C * cp.N;
+      cp.ldc = np_img; cp.strideC = (long long)c->C * np_img;
       cp.a_off = c->w_off[2 * a + b]; cp.c_off = c->out_off[2 * a + b];
       if ((cp.a_off & 7) || (cp.c_off & 3)) return (int)hipErrorInvalidValue;
       cp.tiles_n = (cp.N + BN - 1) / BN;
-      const long long nt = (long long)g.tiles_m * cp.tiles_n * c->B;
+      const long long nt = (long long)g.tiles_m * cp.tiles_n * (fold ? 1 : c->B);
       if (nt > 0x0fffffffLL) return (int)hipErrorInvalidValue;
       cp.ntiles = (int)nt;
       tile0 += nt;
@@ -874,7 +900,8 @@ extern "C" int cips_conv2d_x3_dgrad_s2(const cips_conv_dgrad_s2_desc* c, cips_st
 
 extern "C" int cips_conv2d_x3_ksplit(int B, int O, int N, int K) {
   // chunks of the contraction that fill the chip when the output has few 256 x 256 tiles (16 x 16 planes: 64 of 256 CUs)
-  const long long tiles = (long long)((O + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
+  const long long tiles = (N < BN && B > 1) ? (long long)((O + BM - 1) / BM) * (((long long)B * N + BN - 1) / BN)      // folded batch
+                                            : (long long)((O + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
   const int T = K / 32;
   int best = 1;
   long long best_cost = -1;

@@ -232,7 +232,9 @@ def _folded_rows_planes(t):
 
 
 def _implicit_ok(C, N, O):
-    return CONV_MODE == "bf16x3" and C % 32 == 0 and O % 32 == 0 and N >= 256 and N % 8 == 0
+    # any plane size: output planes of fewer than 256 pixels (8 x 8, 4 x 4) run with the batch folded into the pixel
+    # dimension of the same kernel (round 6; before, im2col + a K-major GEMM + col2im and their permuting copies)
+    return CONV_MODE == "bf16x3" and C % 32 == 0 and O % 32 == 0 and N % 8 == 0
 
 
 # NHWC planes of an activation / gradient are shared between the convolution ops that read the same tensor inside ONE
@@ -513,9 +515,9 @@ def _conv_fwd(x, w, stride, pad, scale=1.0, pre=None):
 
 
 def _s2_parity_ok(C, O, N):
-    """stride-2 data gradient as parity sub-convolutions: dy planes of at least one 256-pixel tile, O a multiple of 32 with
-    two k-tiles in the single-tap class"""
-    return CONV_MODE == "bf16x3" and O % 32 == 0 and O >= 64 and C % 8 == 0 and N >= 256
+    """stride-2 data gradient as parity sub-convolutions: O a multiple of 32 with two k-tiles in the single-tap class (small
+    planes: the batch folded into the pixel dimension)"""
+    return CONV_MODE == "bf16x3" and O % 32 == 0 and O >= 64 and C % 8 == 0 and N % 8 == 0
 
 
 def _conv_bwd_data(dy, w, in_shape, stride, pad, scale=1.0, pre=None):
@@ -625,7 +627,7 @@ class _WeightGradPort(Function):
         # through Conv2dBwdWeightFunction when this backward runs under create_graph).
         ctx.x = xbox[0]
         ctx.cfg = (tuple(w.shape), stride, pad, scale, pre)
-        return w.new_zeros(1).expand(out_shape)
+        return _zero1(w).expand(out_shape)
 
     @staticmethod
     def backward(ctx, g):
@@ -633,6 +635,18 @@ class _WeightGradPort(Function):
         with _share_planes():
             dw = Conv2dBwdWeightFunction.apply(g, ctx.x, w_shape, stride, pad, scale, pre)
         return dw, None, None, None, None, None, None
+
+
+_ZERO1 = {}
+
+
+def _zero1(like):
+    """one zero element per (device, dtype), made once (a fill launch per convolution call otherwise); never written"""
+    key = (like.device, like.dtype)
+    z = _ZERO1.get(key)
+    if z is None:
+        z = _ZERO1[key] = torch.zeros(1, device=like.device, dtype=like.dtype)
+    return z
 
 
 def _weight_port(x, w, out_shape, stride, pad, scale, pre):

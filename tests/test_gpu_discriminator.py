@@ -293,7 +293,10 @@ def test_conv_weight_gradient_ragged_chunks(cfg):
 
 @pytest.mark.parametrize("cfg", [(2, 64, 96, 16, 3, 1, 1, 4), (3, 32, 32, 16, 3, 1, 1, 3), (2, 64, 64, 17, 3, 2, 0, 5),
                                  (2, 96, 32, 16, 1, 1, 0, 3), (1, 32, 64, 24, 3, 1, 1, 7), (4, 512, 512, 32, 3, 1, 1, 2),
-                                 (2, 64, 320, 32, 1, 1, 0, 1)])
+                                 (2, 64, 320, 32, 1, 1, 0, 1),
+                                 # output planes under 256 pixels: the batch folded into the pixel dimension (round 6)
+                                 (8, 64, 96, 8, 3, 1, 1, 4), (32, 64, 64, 4, 3, 1, 1, 3), (6, 64, 64, 9, 3, 2, 0, 2), (5, 96, 32, 8, 1, 1, 0, 1),
+                                 (3, 32, 32, 12, 3, 1, 1, 2)])
 def test_implicit_conv_split_contraction(cfg):
     """cips_conv2d_x3 with ksplit > 1 (the contraction cut into ragged k-tile ranges computed by different workgroups,
     partial planes summed into y): same result as the unsplit launch to fp32 summation order, and as torch in fp64"""
