@@ -213,6 +213,72 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(UpfirArgs a, int 
   }
 }
 
+// The parity-block form with the lanes along the BLOCK column: thread = output columns 2V and 2V+1 of TH rows.  Its five input
+// columns 2V - pad .. 2V - pad + 4 alternate between the two column parities in an order that is the same for every thread, so
+// each of the five loads per input row reads ONE block at consecutive addresses (lane = V): fully coalesced, 2.5 loads per
+// output and row instead of 4.  (The column-per-lane form above reads both blocks with every instruction: 256 us against
+// 127 us for the row-major tensor on the 64 x 64 x 512 gradient.)  Same taps in the same order: bit-identical.
+template <int TH>
+__global__ __launch_bounds__(256) void upfirdn2d_parity2_kernel(UpfirArgs a, int hw2, int bh, ParityIn pin) {
+  float ck[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ck[i] = a.k[15 - i];
+  const long long per_plane = (long long)bh * hw2, nblk = a.major * per_plane;
+  const float* zp = cips_zero_word;
+  const int par0 = a.pad_x0 & 1;                       // parity of input column ixb + i is (par0 + i) & 1 for every thread
+  for (long long t = blockIdx.x * 256LL + threadIdx.x; t < nblk; t += gridDim.x * 256LL) {
+    const long long mj = t / per_plane;
+    const int rem = (int)(t - mj * per_plane), by = rem / hw2, V = rem - by * hw2;
+    const int oy0 = by * TH, ox0 = 2 * V;
+    const int iyb = oy0 - a.pad_y0, ixb = ox0 - a.pad_x0;
+    int cV[5];
+    bool cok[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int ix = ixb + i;
+      cok[i] = (unsigned)ix < (unsigned)a.in_w;
+      cV[i] = min(max(ix, 0), a.in_w - 1) >> 1;
+    }
+    float v[TH][2];
+#pragma unroll
+    for (int ry = 0; ry < TH; ++ry) { v[ry][0] = 0.f; v[ry][1] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < TH + 3; ++r) {
+      const int iy = iyb + r;
+      const bool rok = (unsigned)iy < (unsigned)a.in_h;
+      const int iyc = min(max(iy, 0), a.in_h - 1), U = iyc >> 1;
+      const bool odd = iyc & 1;
+      const float* p0 = (odd ? pin.blk[2] : pin.blk[0]) + mj * (long long)(odd ? pin.np[2] : pin.np[0]) + (long long)U * pin.ws[0];
+      const float* p1 = (odd ? pin.blk[3] : pin.blk[1]) + mj * (long long)(odd ? pin.np[3] : pin.np[1]) + (long long)U * pin.ws[1];
+      const float* pe = par0 ? p1 : p0;                // block of columns i = 0, 2, 4
+      const float* po = par0 ? p0 : p1;                // block of columns i = 1, 3
+      float x[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) x[i] = *((rok && cok[i]) ? ((i & 1) ? po : pe) + cV[i] : zp);
+#pragma unroll
+      for (int ry = 0; ry < TH; ++ry) {
+        const int ky = r - ry;
+        if (ky >= 0 && ky < 4) {
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx) {
+            v[ry][0] = fmaf(x[kx], ck[ky * 4 + kx], v[ry][0]);
+            v[ry][1] = fmaf(x[kx + 1], ck[ky * 4 + kx], v[ry][1]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ry = 0; ry < TH; ++ry) {
+      const int oy = oy0 + ry;
+      if (oy < a.out_h) {
+        float* q = a.out + (mj * a.out_h + oy) * (long long)a.out_w + ox0;
+        if (ox0 + 1 < a.out_w && (a.out_w & 1) == 0) *reinterpret_cast<float2*>(q) = make_float2(v[ry][0], v[ry][1]);
+        else { q[0] = v[ry][0]; if (ox0 + 1 < a.out_w) q[1] = v[ry][1]; }
+      }
+    }
+  }
+}
+
 // up 2, down 1, 4 x 4 kernel (the backward of the down-2 blur of the skip branch): each output has 2 x 2 taps; the
 // quarter-size input stays in L1 / L2.  Same polyphase arithmetic and tap order as the generic kernel.
 template <int TH>
@@ -814,11 +880,11 @@ extern "C" int cips_upfirdn2d_parity(const float* dxp, const long long* blk_off,
       pin.ws[pb] = ws;
     }
   const int th = a.out_h < 48 ? 8 : 16;
-  const int bw = a.out_w, bh = (a.out_h + th - 1) / th;
-  const long long nthreads = (long long)major * bw * bh;
+  const int hw2 = (a.out_w + 1) / 2, bh = (a.out_h + th - 1) / th;
+  const long long nthreads = (long long)major * hw2 * bh;
   const unsigned grid = (unsigned)((nthreads + 255) / 256 < 131072 ? (nthreads + 255) / 256 : 131072);
-  if (th == 8) hipLaunchKernelGGL((upfirdn2d_direct_kernel<1, 1, 8, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, bw, bh, pin);
-  else hipLaunchKernelGGL((upfirdn2d_direct_kernel<1, 1, 16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, bw, bh, pin);
+  if (th == 8) hipLaunchKernelGGL((upfirdn2d_parity2_kernel<8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, hw2, bh, pin);
+  else hipLaunchKernelGGL((upfirdn2d_parity2_kernel<16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, hw2, bh, pin);
   return CIPS_CHECK_LAUNCH();
 }
 
@@ -858,6 +924,19 @@ __global__ __launch_bounds__(256) void lrelu_bwd_bias_kernel(const float* __rest
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) part[(long long)blockIdx.x * gridDim.y + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// grad_bias[c] = sum over images and slices of part[b][c][s], in that fixed order (was a torch reduction per call: 60 launches of
+// 13-32 us per D step for C floats each)
+__global__ __launch_bounds__(256) void lrelu_bias_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int C, int S) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* q = part + ((long long)b * C + c) * S;
+    for (int s_ = 0; s_ < S; ++s_) acc += q[s_];
+  }
+  out[c] = acc;
 }
 
 // Weight gradient of the same layer: dw[o][c] = sum_{b,p} dy[b][o][p] x[b][c][p] — O*C dot products over B*HW pixels.
@@ -915,6 +994,12 @@ extern "C" int cips_lrelu_bwd_bias(const float* grad, const float* refer, float*
   per = (per + 3) & ~3;
   hipLaunchKernelGGL(lrelu_bwd_bias_kernel, dim3((unsigned)planes, S), dim3(256), 0, (hipStream_t)stream, grad, refer, grad_in,
                      part, HW, per, alpha, scale);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_lrelu_bwd_bias_finish(const float* part, float* grad_bias, int B, int C, int S, cips_stream_t stream) {
+  if (!part || !grad_bias || B <= 0 || C <= 0 || S <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(lrelu_bias_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, grad_bias, B, C, S);
   return CIPS_CHECK_LAUNCH();
 }
 

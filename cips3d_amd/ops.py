@@ -1735,7 +1735,9 @@ def lrelu_bwd_bias(grad, refer, alpha, scale):
     with torch.cuda.device(grad.device):
         check(lib.cips_lrelu_bwd_bias(_p(grad), _p(refer), _p(gin), _p(part), B * C, hw, float(alpha), float(scale), _stream()),
               "cips_lrelu_bwd_bias")
-    return gin, part.sum((0, 2))
+        gb = torch.empty(C, device=grad.device)
+        check(lib.cips_lrelu_bwd_bias_finish(_p(part), _p(gb), B, C, S, _stream()), "cips_lrelu_bwd_bias_finish")
+    return gin, gb
 
 
 def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):

@@ -565,6 +565,8 @@ int cips_image_to_u8(const float* x, unsigned char* out, int B, int C, int H, in
 int cips_lrelu_bwd_bias_slices(int HW);
 int cips_lrelu_bwd_bias(const float* grad, const float* refer, float* grad_in, float* part, long long planes, int HW,
                         float alpha, float scale, cips_stream_t stream);
+/* grad_bias[c] = sum over b < B, s < S of part[b][c][s] (fixed order): the tail of cips_lrelu_bwd_bias, planes = B * C */
+int cips_lrelu_bwd_bias_finish(const float* part, float* grad_bias, int B, int C, int S, cips_stream_t stream);
 
 /* 1x1 convolution with C <= 4 input channels (EqualConv2d of the RGB input layers, discriminator.py:457-459):
  * y (B, O, HW) = w (O, C) . x (B, C, HW); HW % 4 == 0.  Streaming kernel, no GEMM. */
