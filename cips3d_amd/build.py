@@ -18,6 +18,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 # (1 728 bytes per lane, measured).  The limit is raised for this file only (the other sources' code generation is unchanged).
 EXTRA_FLAGS = {"siren_bwd_x3.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 HIPCC_EXTRA = []      # scripts/probe/build_tuning.sh appends the probe-build define here; the product build passes nothing
+LIBDIR = "lib"        # ... and points this at "lib_tuning": a probe build never overwrites the product's objects or library
 
 
 def _stale(target, deps):
@@ -28,9 +29,15 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
-    os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
-    objdir = os.path.join(HERE, "lib", "obj")
+    out = os.path.join(HERE, LIBDIR, "libcips3d_hip.so")
+    os.makedirs(os.path.join(HERE, LIBDIR), exist_ok=True)
+    objdir = os.path.join(HERE, LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
+    # objects of sources that are no longer listed (removed experiments) are deleted, not left beside the product
+    keep = {src.replace(".hip", ".o") for src in SOURCES}
+    for f in os.listdir(objdir):
+        if f.endswith(".o") and f not in keep:
+            os.remove(os.path.join(objdir, f))
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "siren_fwd_chain.inc"), os.path.join(CSRC, "siren_bwd_x4.inc"), os.path.join(CSRC, "raygen.h"),
                os.path.join(HERE, "..", "include", "cips3d_hip.h")]
     objs = []
@@ -47,12 +54,12 @@ def build(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if force or procs or _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if force or procs or _stale(out, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -15,6 +15,10 @@ API, from the call sites (exp/cips3d/configs/ffhq_exp.yaml:103-114, exp/cips3d/s
       an endless DataLoader over an InfiniteSampler (rank-strided, windowed re-shuffling) with the GLOBAL batch size
       (train.py:302-305 passes batch_size * world_size), i.e. batch_size // num_gpus images per rank and step;
   to_norm_tensor(imgs, device) -> float32 in [-1, 1] (train.py:317).
+
+Provenance: the class layout (`Dataset` with `_raw_idx` / `_xflip` / `_get_raw_labels`, `ImageFolderDataset`, `InfiniteSampler`)
+restates NVIDIA StyleGAN3's `training/dataset.py` and `torch_utils/misc.py` from memory — that is the format's de-facto
+definition, and what tl2 itself wraps; it is not part of /root/reference and not on the measured path.
 """
 import json
 import os
@@ -173,6 +177,10 @@ class ImageFolderDataset_of_stylegan(Dataset):
         with self._open_file(fname) as f:
             img = PIL.Image.open(f)
             img.load()
+        if img.mode not in ("RGB", "L"):
+            # palette / RGBA / 16-bit / CMYK files: the training set is RGB (or grey) uint8 — normalise here instead of handing D a
+            # wrong channel count or tripping the uint8 assert in the middle of training
+            img = img.convert("L" if img.mode in ("1", "I;16", "I", "F", "LA") else "RGB")
         if self._resize is not None and img.size != (self._resize, self._resize):
             img = img.resize((self._resize, self._resize), PIL.Image.LANCZOS)
         image = np.array(img)

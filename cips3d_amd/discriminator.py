@@ -1010,7 +1010,7 @@ class EqualLinear(nn.Module):
     """discriminator.py:254-288.  (b x 8192) @ (8192 x 512) and (b x 512) @ (512 x 1) on the HIP library
     (cips_equal_linear: the exact-fp32 MFMA GEMM with the long contraction cut into chunks, streaming kernels for the
     one-column output layer), double-differentiable through _EqLinFwd / _EqLinDx / _EqLinDw; the activation is the fused
-    bias + LeakyReLU op.  CIPS_D_LINEAR_HIP=0: torch.nn.functional.linear (hipBLASLt), for A/B runs."""
+    bias + LeakyReLU op.  Inputs of more than two dimensions (not what the discriminator feeds it) take torch's linear."""
 
     def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
         super().__init__()
