@@ -723,6 +723,16 @@ def main():
                     r["measured"] = "in situ: " + ins["how"]
                 r["in_situ"] = ins
             try:
+                # the shader clock the family runs at INSIDE the step (per-dispatch counters: profiles/r6_step_clock.txt) and the
+                # family priced against the roof at that clock; a tracked record, `frac` stays priced against the nominal peak
+                sc = json.load(open(os.path.join(ROOT, "profiles", "r6_step_clock.json")))
+                if mode == "bf16x3" and isinstance(r.get("achieved"), (int, float)):
+                    r["sclk_ghz_in_step"] = sc["head_gemm_family_sclk_ghz"]
+                    r["frac_at_step_clock"] = round(r["achieved"] / (r["peak"] * sc["head_gemm_family_sclk_ghz"] / sc["nominal_sclk_ghz"]), 4)
+                    r["step_clock_source"] = sc["source"]
+            except Exception:                       # noqa: BLE001
+                pass
+            try:
                 # what the board's 1400 W limit leaves of the nominal (2.4 GHz) roof on real operands: a tracked record of the
                 # power probe, not a measurement of this run — `frac` above stays priced against the nominal peak
                 pw = json.load(open(os.path.join(ROOT, "profiles", "r5_power_envelope.json")))
