@@ -64,9 +64,10 @@ def parse():
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
 
 
-def _time_launches(fn, reps=20):
-    """average launch duration (s) with HIP events on the launch stream (torch's current stream)"""
-    for _ in range(3):
+def _time_launches(fn, reps=60, warm=60):
+    """average launch duration (s) with HIP events on the launch stream (torch's current stream); the warm-up is longer than the
+    ~50 launches the clock controller takes to settle on a looped matrix-bound kernel (profiles/r5_power_envelope.txt)"""
+    for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
