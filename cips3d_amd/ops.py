@@ -1398,7 +1398,7 @@ def _bsl(t, b0, b1):
 
 
 def _chunk_ranges(B):
-    """image ranges the head's launch chain is cut into: one (two chains on two streams measured slower)"""
+    """image ranges the head's launch chain is cut into: one (two chains on two streams measured slower, profiles/HISTORY.md section 3)"""
     return [(0, B)]
 
 

@@ -412,7 +412,7 @@ def test_c3_r128_pair_forward_backward_vs_oracle():
     to the oracle's choices — LeakyReLU gates, placement of the fine samples, and the branch of `relu(sigma + noise)`
     (pigan_utils.py fancy_integration: the product's split-bf16 SIREN forward carries sigma to ~1e-5 where the oracle's fp32
     carries 1e-7, so at 786 432 samples a handful land on the other side of the clamp and the sigma head's two gradients —
-    sums of d sigma with heavy cancellation — moved by 4.4e-3 free-running).  Bars against the fp64 evaluation of
+    sums of d sigma with heavy cancellation — moved by 4.4e-3 free-running, profiles/HISTORY.md §0).  Bars against the fp64 evaluation of
     the same network with the same three pins: max(2e-4, 4 x the fp32 oracle's own distance from fp64), see _grad_compare."""
     _g_forward_backward_vs_oracle("C3 geometry b=2 r128 S=12+12, aux, nerf_noise 0.1", 2, 128, 12, True, True, 0.1, 1283,
                                   pin_fine=True, pin_clamp=True, tol=2e-4, free_bar=1e-3)
