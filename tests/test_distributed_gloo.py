@@ -315,6 +315,20 @@ def _late_worker(rank, world, port, q):
             red._check_pending(block=True)
             steps.append([None if p.grad is None else p.grad.clone().numpy() for p in params])
         out[mode] = steps
+        if mode == "overlap":
+            # gradient accumulation over two backward passes is refused in overlap mode (it used to come out as
+            # mean(g1) + mean(g1 + g2), ~40 % off, with the plan checksum passing) — on every rank, before any collective
+            for p in params:
+                p.grad = None
+            x = torch.randn(32, 16, generator=torch.Generator().manual_seed(900 + rank))
+            net(x, detach_a=False).square().mean().backward()
+            try:
+                net(x, detach_a=False).square().mean().backward()
+                out["second_backward"] = "no error"
+            except RuntimeError as e:
+                out["second_backward"] = "raised" if "twice" in str(e) else str(e)
+            red()                                  # the first backward's buckets are in flight on both ranks: finish them
+            red._check_pending(block=True)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -351,6 +365,7 @@ def test_gradient_arriving_after_its_bucket_was_issued_is_not_lost_world2_gloo()
             break
     assert res is not None
     for r in range(world):
+        assert res[r]["second_backward"] == "raised", res[r]["second_backward"]
         for step, (gc, go) in enumerate(zip(res[r]["classic"], res[r]["overlap"])):
             for k, (a, b) in enumerate(zip(gc, go)):
                 assert (a is None) == (b is None), (r, step, k)
