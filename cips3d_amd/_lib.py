@@ -92,6 +92,11 @@ class ConvDgradS2Desc(C.Structure):
                 ("w_off", i64 * 4), ("out_off", i64 * 4)]
 
 
+class WPrepJob(C.Structure):
+    _fields_ = [("w", vp), ("fwd_hi", vp), ("fwd_lo", vp), ("alt_hi", vp), ("alt_lo", vp), ("scale", f32),
+                ("O", i32), ("C", i32), ("kh", i32), ("kw", i32), ("alt_kind", i32), ("bank_off", i32 * 4)]
+
+
 class ConvWgradDesc(C.Structure):
     _fields_ = [("dy_hi", vp), ("dy_lo", vp), ("x_hi", vp), ("x_lo", vp), ("part", vp),
                 ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("O", i32), ("kh", i32), ("kw", i32),
@@ -139,6 +144,8 @@ SIGNATURES = {
     "cips_split_planes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, vp]),
     "cips_split_planes_nhwc": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "cips_conv2d_x3_ksplit": (i32, [i32, i32, i32, i32]),
+    "cips_conv_weight_prep_max_jobs": (i32, []),
+    "cips_conv_weight_prep_batch": (i32, [C.POINTER(WPrepJob), i32, vp]),
     "cips_conv2d_x3_dgrad_s2": (i32, [C.POINTER(ConvDgradS2Desc), vp]),
     "cips_conv_wgrad_finish": (i32, [vp, vp, i32, i32, i32, i32, f32, vp]),
     "cips_modfc_prep_x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),

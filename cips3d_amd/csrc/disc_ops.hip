@@ -870,6 +870,86 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
   return CIPS_CHECK_LAUNCH();
 }
 
+// Operand planes of the convolution WEIGHTS, all layers of a network in one launch (round 6): for every job the scaled weight
+// w * scale (O, C, kh, kw) is split into bf16 hi / lo and written (a) as the forward filter bank [O][(ky, kx, c)] and (b) in ONE
+// alternate form — the flipped, channel-transposed bank of the stride-1 data gradient [C][(kh-1-ky, kw-1-kx, o)] or the four
+// parity banks of the stride-2 data gradient (cips_conv2d_x3_dgrad_s2).  Before, every layer built each form with its own
+// multiply, permuting copy, flip and split: ~12 launches per layer, ~480 per GAN step, after every optimizer step.  Values are
+// those launches' bit for bit (fp32 multiply, round-to-nearest-even splits).
+// Workgroup = 32 output x 32 input channels of one job: per tap the tile is read with the lanes along c (the forward bank's
+// contiguous dimension) and written back through LDS with the lanes along o (the alternate forms' contiguous dimension).
+__device__ __forceinline__ unsigned short wp_f2bf(float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+struct WPrepArgs { cips_wprep_job job[CIPS_WPREP_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void conv_weight_prep_kernel(WPrepArgs a) {
+  __shared__ unsigned short th[32][33], tl[32][33];
+  const cips_wprep_job& j = a.job[blockIdx.z];
+  const int c0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+  if (c0 >= j.C || o0 >= j.O) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+  const int T = j.kh * j.kw;
+  unsigned short* fh = (unsigned short*)j.fwd_hi; unsigned short* fl = (unsigned short*)j.fwd_lo;
+  unsigned short* ah = (unsigned short*)j.alt_hi; unsigned short* al = (unsigned short*)j.alt_lo;
+  for (int t = 0; t < T; ++t) {
+    const int ky = t / j.kw, kx = t - ky * j.kw;
+    for (int rr = ty; rr < 32; rr += 8) {
+      const int o = o0 + rr, c = c0 + tx;
+      unsigned short h = 0, l = 0;
+      if (o < j.O && c < j.C) {
+        float v = j.w[((long long)o * j.C + c) * T + t] * j.scale;
+        asm volatile("" : "+v"(v));           // the ROUNDED product: without the barrier hipcc contracts `w * scale - hi` into one fma (lo planes 1-2 ulp off in 1.6 % of the elements)
+        h = wp_f2bf(v);
+        l = wp_f2bf(v - __uint_as_float(((unsigned)h) << 16));
+        if (fh) { const long long q = (long long)o * T * j.C + (long long)t * j.C + c; fh[q] = h; fl[q] = l; }
+      }
+      th[rr][tx] = h; tl[rr][tx] = l;
+    }
+    __syncthreads();
+    if (j.alt_kind) {
+      long long base;                                               // element offset of (c = 0, o = 0) of this tap in the alternate form
+      long long pitch;                                              // elements per c row
+      if (j.alt_kind == 1) {
+        const int tf = (j.kh - 1 - ky) * j.kw + (j.kw - 1 - kx);
+        pitch = (long long)T * j.O; base = (long long)tf * j.O;
+      } else {
+        const int pa = ky & 1, pb = kx & 1;
+        const int Ta = (j.kh - pa + 1) / 2, Tb = (j.kw - pb + 1) / 2;
+        const int ty_ = Ta - 1 - (ky >> 1), tx_ = Tb - 1 - (kx >> 1);
+        pitch = (long long)Ta * Tb * j.O; base = j.bank_off[2 * pa + pb] + (long long)(ty_ * Tb + tx_) * j.O;
+      }
+      for (int cc = ty; cc < 32; cc += 8) {
+        const int c = c0 + cc, o = o0 + tx;
+        if (c < j.C && o < j.O) {
+          const long long q = base + (long long)c * pitch + o;
+          ah[q] = th[tx][cc]; al[q] = tl[tx][cc];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int cips_conv_weight_prep_max_jobs(void) { return CIPS_WPREP_MAX_JOBS; }
+extern "C" int cips_conv_weight_prep_batch(const cips_wprep_job* jobs, int njobs, cips_stream_t stream) {
+  if (!jobs || njobs <= 0 || njobs > CIPS_WPREP_MAX_JOBS) return (int)hipErrorInvalidValue;
+  WPrepArgs a;
+  int maxO = 0, maxC = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const cips_wprep_job& j = jobs[i];
+    if (!j.w || j.O <= 0 || j.C <= 0 || j.kh <= 0 || j.kw <= 0 || j.alt_kind < 0 || j.alt_kind > 2) return (int)hipErrorInvalidValue;
+    if ((j.fwd_hi == nullptr) != (j.fwd_lo == nullptr) || (j.alt_kind && (!j.alt_hi || !j.alt_lo))) return (int)hipErrorInvalidValue;
+    a.job[i] = j;
+    if (j.O > maxO) maxO = j.O;
+    if (j.C > maxC) maxC = j.C;
+  }
+  dim3 grid((unsigned)((maxC + 31) / 32), (unsigned)((maxO + 31) / 32), (unsigned)njobs);
+  hipLaunchKernelGGL(conv_weight_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return CIPS_CHECK_LAUNCH();
+}
+
 // The 4 x 4 FIR (up 1, down 1) over a plane stored as the four parity blocks of cips_conv2d_x3_dgrad_s2: the transpose of
 // the Blur in front of a stride-2 convolution, applied straight to that convolution's data gradient (include/cips3d_hip.h).
 extern "C" int cips_upfirdn2d_parity(const float* dxp, const long long* blk_off, const float* kernel, float* out, int major,

@@ -432,6 +432,89 @@ def _cached(w, scale, kind, build):
     return val
 
 
+def _bank_offsets(O, C, kh, kw):
+    """element offsets of the four parity banks (ops.dgrad_s2_banks' layout) and their total size"""
+    offs, tot = [], 0
+    for a in range(2):
+        for b in range(2):
+            offs.append(tot)
+            tot += C * O * len(range(a, kh, 2)) * len(range(b, kw, 2))
+    return offs, tot
+
+
+def prepare_weight_planes(layers):
+    """layers: iterable of (EqualConv2d, alt) with alt "flipT" (stride-1 data gradient) or "s2banks" (stride-2 data gradient behind a
+    Blur).  Builds every stale operand form of every listed weight in ONE launch per 24 layers (cips_conv_weight_prep_batch) and
+    files them in the weight-plane cache under the keys the convolution Functions look up — after an optimizer step the whole
+    network's planes used to be rebuilt layer by layer, form by form (multiply, permuting copy, flip, split: ~12 launches per
+    layer, ~480 per GAN step).  Same values bit for bit.  Not under hipGraph capture (planes built there live in the graph's pool and
+    are rebuilt by every replay: _cached handles that case per layer)."""
+    if CONV_MODE != "bf16x3" or torch.cuda.is_current_stream_capturing():
+        return
+    import ctypes as C
+    from . import _lib
+    from ._lib import WPrepJob
+    todo = []
+    want_alt = torch.is_grad_enabled()
+    for conv, alt in layers:
+        w = conv.weight
+        if not (isinstance(w, nn.Parameter) and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+            continue
+        O, Cc, kh, kw = w.shape
+        if Cc % 32 or O % 32 or (alt == "s2banks" and O < 64):
+            continue
+        slot = _WCACHE.get(id(w))
+        if slot is None or slot[0]() is not w:
+            key_id = id(w)
+            slot = _WCACHE[key_id] = (_weakref.ref(w, lambda _r, k=key_id: _WCACHE.pop(k, None)), {})
+        ent = slot[1]
+        sc = float(conv.scale)
+
+        def stale(kind):
+            hit = ent.get((kind, sc))
+            return hit is None or hit[0] != w._version or hit[1] != w.data_ptr()
+        need_fwd, need_alt = stale("fwd"), bool(alt) and want_alt and w.requires_grad is not None and stale(alt)
+        if need_fwd or need_alt:
+            todo.append((w, ent, sc, alt if need_alt else None, need_fwd))
+    if not todo:
+        return
+    lib = _lib.load()
+    mx = lib.cips_conv_weight_prep_max_jobs()
+    dev = todo[0][0].device
+    with torch.no_grad(), torch.cuda.device(dev):
+        for c0 in range(0, len(todo), mx):
+            chunk = todo[c0:c0 + mx]
+            jobs = (WPrepJob * len(chunk))()
+            made = []
+            for j, (w, ent, sc, alt, need_fwd) in zip(jobs, chunk):
+                O, Cc, kh, kw = w.shape
+                K = kh * kw * Cc
+                j.w, j.scale, j.O, j.C, j.kh, j.kw = w.data_ptr(), sc, O, Cc, kh, kw
+                fwd = altv = None
+                if need_fwd:
+                    fwd = ops.Planes.empty(1, O, K, device=dev)
+                    j.fwd_hi, j.fwd_lo = fwd.hi.data_ptr(), fwd.lo.data_ptr()
+                if alt == "flipT":
+                    P = ops.Planes.empty(1, Cc, kh * kw * O, device=dev)
+                    j.alt_kind, j.alt_hi, j.alt_lo = 1, P.hi.data_ptr(), P.lo.data_ptr()
+                    altv = P
+                elif alt == "s2banks":
+                    offs, tot = _bank_offsets(O, Cc, kh, kw)
+                    P = ops.Planes.empty(1, tot // 32, 32, device=dev)
+                    j.alt_kind, j.alt_hi, j.alt_lo = 2, P.hi.data_ptr(), P.lo.data_ptr()
+                    for i in range(4):
+                        j.bank_off[i] = offs[i]
+                    altv = (P, offs)
+                made.append((w, ent, sc, alt, fwd, altv))
+            _lib.check(lib.cips_conv_weight_prep_batch(jobs, len(chunk), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "cips_conv_weight_prep_batch")
+            for w, ent, sc, alt, fwd, altv in made:
+                if fwd is not None:
+                    ent[("fwd", sc)] = (w._version, w.data_ptr(), fwd)
+                if altv is not None:
+                    ent[(alt, sc)] = (w._version, w.data_ptr(), altv)
+
+
 def _w_planes_raw(w):
     O, C, kh, kw = w.shape
     P, _ = ops.split_planes(w.permute(0, 2, 3, 1).reshape(1, O, kh * kw * C).contiguous(), want_p=True, want_t=False)
@@ -1207,11 +1290,25 @@ class Discriminator_MultiScale(nn.Module):
     def diff_aug_img(self, img):
         return DiffAugment(img, policy='color,translation,cutout')
 
+    def _conv_layers(self, log_size):
+        """(EqualConv2d, alternate operand form of its weight) for every convolution a forward at 2^log_size runs"""
+        out = []
+        for i in range(log_size, 2, -1):
+            blk = self.convs[f"{2 ** i}"]
+            for layer in (blk.conv1, blk.conv2, blk.skip):
+                conv = layer.equal_conv
+                s2 = hasattr(layer, "down_blur") and conv.weight.shape[2] > 1 and FOLD_BLUR
+                out.append((conv, "s2banks" if s2 else "flipT"))
+        out.append((self.final_conv.equal_conv, "flipT"))
+        return out
+
     def forward(self, input, alpha, summary_ddict=None):
         if self.diffaug:
             input = self.diff_aug_img(input)
         size = input.shape[-1]
         log_size = int(math.log(size, 2))
+        if input.is_cuda:
+            prepare_weight_planes(self._conv_layers(log_size))
         cur = self.conv_in[f"{2 ** log_size}"](input)
         cur = self.convs[f"{2 ** log_size}"](cur)
         if alpha < 1:

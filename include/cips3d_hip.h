@@ -366,6 +366,25 @@ typedef struct cips_conv_dgrad_s2_desc {
   long long w_off[4], out_off[4];
 } cips_conv_dgrad_s2_desc;
 int cips_conv2d_x3_dgrad_s2(const cips_conv_dgrad_s2_desc* d, cips_stream_t stream);
+/* Operand planes of convolution WEIGHTS for cips_conv2d_x3 / cips_conv2d_x3_dgrad_s2, up to cips_conv_weight_prep_max_jobs() layers
+ * per launch (EqualConv2d: `weight * scale`, exp/cips3d/models/discriminator.py:33, 44): w (O, C, kh, kw) fp32 ->
+ *   fwd_hi / fwd_lo: planes [O][kh*kw*C], contraction index (ky, kx, c)                                   (NULL: not written)
+ *   alt_kind 1: alt_hi / alt_lo = planes [C][kh*kw*O] of the flipped, channel-transposed bank: element (c, (kh-1-ky, kw-1-kx, o))
+ *               — the stride-1 data gradient's filter bank;
+ *   alt_kind 2: alt_hi / alt_lo = the four parity banks of cips_conv2d_x3_dgrad_s2 at element offsets bank_off[2a+b];
+ *   alt_kind 0: no alternate form.
+ * hi = bf16(w * scale) (round to nearest even), lo = bf16(w * scale - hi): the values of a separate multiply + cips_split_planes. */
+#define CIPS_WPREP_MAX_JOBS 24
+typedef struct cips_wprep_job {
+  const float* w;
+  void* fwd_hi; void* fwd_lo;
+  void* alt_hi; void* alt_lo;
+  float scale;
+  int O, C, kh, kw, alt_kind;
+  int bank_off[4];
+} cips_wprep_job;
+int cips_conv_weight_prep_max_jobs(void);
+int cips_conv_weight_prep_batch(const cips_wprep_job* jobs, int njobs, cips_stream_t stream);
 /* Weight gradient of the same convolution on the K-major kernel (contraction over all B*Ho*Wo output pixels, split in
  * `nchunks` ranges whose partial sums the caller adds):
  *   part[chunk][ky*kw+kx][o][c] = sum_{q in chunk} dy[q][o] * x[pixel(q)*stride - pad + (ky,kx)][c]

@@ -546,3 +546,45 @@ def test_resblock_with_the_blur_folded_into_its_convolutions(cfg, monkeypatch):
     assert torch.equal(res[True][0], res[False][0])
     for a, b, what in zip(res[True], res[False], names):
         assert a.shape == b.shape and rel_err(a, b) < 2e-5, (what, float(rel_err(a, b)))
+
+
+def test_batched_weight_planes_are_the_per_layer_ones_bit_for_bit():
+    """cips_conv_weight_prep_batch (round 6): the forward bank, the flipped / transposed bank and the four parity banks of every
+    convolution weight of a network in one launch per 24 layers, against the per-layer builders they replace (multiply, permuting
+    copy, flip, split_planes; ops.dgrad_s2_banks): identical bf16 planes; and the cache serves them until the weight changes."""
+    from cips3d_amd import ops
+    from cips3d_amd import discriminator as dm
+    d = torch.device("cuda:0")
+    torch.manual_seed(3)
+    D = dm.Discriminator_MultiScale(**dict(D_CFG)).to(d)
+    layers = D._conv_layers(6)
+    dm.invalidate_weight_cache(D)
+    dm.prepare_weight_planes(layers)
+    n = 0
+    for conv, alt in layers:
+        w, sc = conv.weight, conv.scale
+        O, C, kh, kw = w.shape
+        ent = dm._WCACHE[id(w)][1]
+        got = ent[("fwd", float(sc))][2]
+        want = dm._w_planes_raw((w.detach() * sc))
+        assert torch.equal(got.hi.view(torch.int16).reshape(-1), want.hi.view(torch.int16).reshape(-1))
+        assert torch.equal(got.lo.view(torch.int16).reshape(-1), want.lo.view(torch.int16).reshape(-1))
+        if alt == "flipT":
+            g2 = ent[("flipT", float(sc))][2]
+            w2 = dm._w_planes_raw((w.detach() * sc).flip(2, 3).transpose(0, 1))
+        else:
+            g2, offs = ent[("s2banks", float(sc))][2]
+            w2, offs2 = ops.dgrad_s2_banks(w.detach() * sc)
+            assert list(offs) == list(offs2)
+        assert torch.equal(g2.hi.view(torch.int16).reshape(-1), w2.hi.view(torch.int16).reshape(-1)), (alt, tuple(w.shape))
+        assert torch.equal(g2.lo.view(torch.int16).reshape(-1), w2.lo.view(torch.int16).reshape(-1)), (alt, tuple(w.shape))
+        n += 1
+    assert n == 13
+    # served from the cache: the lookups of the convolution Functions return the very objects
+    conv, _ = layers[0]
+    assert dm._w_planes(conv.weight, conv.scale) is dm._WCACHE[id(conv.weight)][1][("fwd", float(conv.scale))][2]
+    with torch.no_grad():
+        conv.weight.mul_(1.5)                          # version bump: stale
+    before = dm._WCACHE[id(conv.weight)][1][("fwd", float(conv.scale))][2]
+    dm.prepare_weight_planes(layers)
+    assert dm._WCACHE[id(conv.weight)][1][("fwd", float(conv.scale))][2] is not before
