@@ -135,6 +135,8 @@ SIGNATURES = {
     "cips_lrelu_bwd_bias_slices": (i32, [i32]),
     "cips_lrelu_bwd_bias": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, vp]),
     "cips_lrelu_bwd_bias_finish": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cips_lrelu_bwd_bias_nhwc_tiles": (i32, [i32]),
+    "cips_lrelu_bwd_bias_nhwc": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp]),
     "cips_conv1x1_smallk": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_conv1x1_smallk_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "cips_conv1x1_smallk_bwd_weight_splits": (i32, [i32, i32]),

@@ -1019,14 +1019,19 @@ __global__ __launch_bounds__(256) void lrelu_bwd_bias_kernel(const float* __rest
 // grad_bias[c] = sum over images and slices of part[b][c][s], in that fixed order (was a torch reduction per call: 60 launches of
 // 13-32 us per D step for C floats each)
 __global__ __launch_bounds__(256) void lrelu_bias_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int C, int S) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  // one wave per channel: the B * S partials of a channel are strided over the lanes and reduced by shuffles (a thread per channel
+  // walking them serially took 50 us once the NHWC form made S = pixel tiles: 2 048 dependent adds on two workgroups)
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
+  const int n = B * S;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* q = part + ((long long)b * C + c) * S;
-    for (int s_ = 0; s_ < S; ++s_) acc += q[s_];
+  for (int i = lane; i < n; i += 64) {
+    const int b = i / S, s_ = i - b * S;
+    acc += part[((long long)b * C + c) * S + s_];
   }
-  out[c] = acc;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) out[c] = acc;
 }
 
 // Weight gradient of the same layer: dw[o][c] = sum_{b,p} dy[b][o][p] x[b][c][p] — O*C dot products over B*HW pixels.
@@ -1089,7 +1094,7 @@ extern "C" int cips_lrelu_bwd_bias(const float* grad, const float* refer, float*
 
 extern "C" int cips_lrelu_bwd_bias_finish(const float* part, float* grad_bias, int B, int C, int S, cips_stream_t stream) {
   if (!part || !grad_bias || B <= 0 || C <= 0 || S <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(lrelu_bias_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, grad_bias, B, C, S);
+  hipLaunchKernelGGL(lrelu_bias_finish_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, part, grad_bias, B, C, S);
   return CIPS_CHECK_LAUNCH();
 }
 

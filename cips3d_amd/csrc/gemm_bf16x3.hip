@@ -743,6 +743,70 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict
   }
 }
 
+// FusedLeakyReLU backward written DIRECTLY as the NHWC split planes of the gated gradient (round 6): for the convolutions that
+// read their incoming gradient only through those planes (implicit-GEMM data and weight gradients) the fp32 NCHW tensor
+//   gin = (ref > 0 ? g : g * alpha) * scale            (exp/comm/op/fused_act.py:26-44, fused_bias_act_kernel.cu:36-47)
+// never exists: one pass reads g and ref (8 B per element) and writes the planes (4 B) — cips_lrelu_bwd_bias (12 B) followed by
+// cips_split_planes_nhwc (8 B) moved 20.  Same tile as split_nhwc_kernel (64 channels x 64 pixels, float4 reads along n,
+// 16-byte writes along C); per (image, channel, pixel tile) one partial bias sum (the 16 lanes of a channel row reduce by
+// shuffles), added over images and tiles by cips_lrelu_bwd_bias_finish.  Plane values are the two kernels' bit for bit.
+__global__ __launch_bounds__(256) void lrelu_bwd_nhwc_kernel(const float* __restrict__ g, const float* __restrict__ ref,
+                                                             u16* __restrict__ thi, u16* __restrict__ tlo, float* __restrict__ part,
+                                                             int C, int n, int B, int ntiles, float alpha, float scale) {
+  __shared__ __attribute__((aligned(16))) u16 sh[64][72], sl[64][72];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  const bool vec = (n & 3) == 0;
+  const long long ib = (long long)b * C * n;
+  {
+    const int col4 = t & 15, r_ = t >> 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cl = r_ + 16 * k, c = c0 + cl, nn = n0 + 4 * col4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C && nn < n) {
+        const long long o = ib + (long long)c * n + nn;
+        if (vec) { v = *reinterpret_cast<const float4*>(g + o); r = *reinterpret_cast<const float4*>(ref + o); }
+        else {
+          v.x = g[o]; r.x = ref[o];
+          if (nn + 1 < n) { v.y = g[o + 1]; r.y = ref[o + 1]; }
+          if (nn + 2 < n) { v.z = g[o + 2]; r.z = ref[o + 2]; }
+          if (nn + 3 < n) { v.w = g[o + 3]; r.w = ref[o + 3]; }
+        }
+      }
+      float4 q;
+      q.x = (r.x > 0.f ? v.x : v.x * alpha) * scale; q.y = (r.y > 0.f ? v.y : v.y * alpha) * scale;
+      q.z = (r.z > 0.f ? v.z : v.z * alpha) * scale; q.w = (r.w > 0.f ? v.w : v.w * alpha) * scale;
+      float acc = (q.x + q.y) + (q.z + q.w);
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);        // the 16 lanes of this channel row
+      if (col4 == 0 && c < C) part[((long long)b * C + c) * ntiles + blockIdx.x] = acc;
+      u16 h, l;
+      split2(q.x, h, l); sh[4 * col4 + 0][cl] = h; sl[4 * col4 + 0][cl] = l;
+      split2(q.y, h, l); sh[4 * col4 + 1][cl] = h; sl[4 * col4 + 1][cl] = l;
+      split2(q.z, h, l); sh[4 * col4 + 2][cl] = h; sl[4 * col4 + 2][cl] = l;
+      split2(q.w, h, l); sh[4 * col4 + 3][cl] = h; sl[4 * col4 + 3][cl] = l;
+    }
+  }
+  __syncthreads();
+  {
+    const int c8 = t & 7, r_ = t >> 3;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int nl = r_ + 32 * k, nn = n0 + nl, c = c0 + 8 * c8;
+      if (nn < n && c < C) {
+        const long long o = ((long long)b * n + nn) * C + c;
+        *reinterpret_cast<uint4*>(thi + o) = *reinterpret_cast<const uint4*>(&sh[nl][8 * c8]);
+        *reinterpret_cast<uint4*>(tlo + o) = *reinterpret_cast<const uint4*>(&sl[nl][8 * c8]);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    const long long z = (long long)B * n * C;
+    for (int i = t; i < C; i += 256) { thi[z + i] = 0; tlo[z + i] = 0; }
+  }
+}
+
 // dw[o][c][tap] = scale * sum_chunk part[chunk][tap][o][c]: the tail of the implicit-GEMM weight gradient (was a torch
 // reduction, a permuting copy and a scalar multiply per convolution)
 __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int nch,
@@ -892,6 +956,18 @@ extern "C" int cips_split_planes_nhwc(const float* x, void* t_hi, void* t_lo, in
   if (!x || !t_hi || !t_lo || B <= 0 || C <= 0 || n <= 0 || (C & 7)) return (int)hipErrorInvalidValue;
   dim3 grid((n + 63) / 64, (C + 63) / 64, B);
   hipLaunchKernelGGL(split_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (u16*)t_hi, (u16*)t_lo, C, n, B);
+  return CIPS_CHECK_LAUNCH();
+}
+
+extern "C" int cips_lrelu_bwd_bias_nhwc_tiles(int HW) { return HW > 0 ? (HW + 63) / 64 : 0; }
+extern "C" int cips_lrelu_bwd_bias_nhwc(const float* grad, const float* refer, void* t_hi, void* t_lo, float* part, int B, int C,
+                                        int HW, float alpha, float scale, cips_stream_t stream) {
+  if (!grad || !refer || !t_hi || !t_lo || !part || B <= 0 || C <= 0 || HW <= 0 || (C & 7)) return (int)hipErrorInvalidValue;
+  if (B > 65535 || (C + 63) / 64 > 65535) return (int)hipErrorInvalidValue;
+  const int ntiles = (HW + 63) / 64;
+  dim3 grid((unsigned)ntiles, (unsigned)((C + 63) / 64), (unsigned)B);
+  hipLaunchKernelGGL(lrelu_bwd_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, grad, refer, (u16*)t_hi, (u16*)t_lo, part, C, HW, B,
+                     ntiles, alpha, scale);
   return CIPS_CHECK_LAUNCH();
 }
 

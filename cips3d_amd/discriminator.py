@@ -55,9 +55,19 @@ class gate_debug:
 
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
-    def forward(ctx, grad_output, out, negative_slope, scale):
+    def forward(ctx, grad_output, out, negative_slope, scale, planes_only=False):
         ctx.save_for_backward(out)
         ctx.negative_slope, ctx.scale = negative_slope, scale
+        if planes_only:
+            # the gated gradient as NHWC split planes ONLY (cips_lrelu_bwd_bias_nhwc): the tensor handed on is a stride-0 zero
+            # placeholder of the right shape that carries the planes (attribute `_cips_nhwc`); its consumers — the implicit-GEMM
+            # data and weight gradient of ONE convolution, chosen by ConvBiasActFunction.backward — read nothing else (_nhwc
+            # refuses a placeholder that lost its planes; _dense refuses to materialise one)
+            P, gb = ops.lrelu_bwd_bias_nhwc(grad_output, out, negative_slope, scale)
+            ph = _zero1(grad_output).expand(grad_output.shape)
+            ph._cips_nhwc = (ph._version, ph.data_ptr(), {(): P})
+            ph._cips_planes_only = True
+            return ph, gb
         if (grad_output.dim() == 4 and grad_output.dtype == torch.float32 and out.dtype == torch.float32
                 and grad_output.is_cuda and grad_output.is_contiguous() and out.is_contiguous()):
             return ops.lrelu_bwd_bias(grad_output, out, negative_slope, scale)     # one pass: gated gradient + bias sums
@@ -71,7 +81,7 @@ class FusedLeakyReLUFunctionBackward(Function):
     def backward(ctx, gradgrad_input, gradgrad_bias):
         out, = ctx.saved_tensors
         gradgrad_out = ops.fused_bias_act(gradgrad_input, gradgrad_bias, out, 3, 1, ctx.negative_slope, ctx.scale)
-        return gradgrad_out, None, None, None
+        return gradgrad_out, None, None, None, None
 
 
 class FusedLeakyReLUFunction(Function):
@@ -289,6 +299,18 @@ class _share_planes:
             m.shared.clear()
 
 
+def _is_planes_only(t):
+    return getattr(t, "_cips_planes_only", False) or (t.dim() == 4 and t.numel() > 1 and t.stride() == (0, 0, 0, 0))
+
+
+def _dense(t):
+    """t.contiguous() for a tensor whose VALUES are about to be read: a planes-only gradient has none"""
+    if _is_planes_only(t):
+        raise RuntimeError("cips3d_amd: a planes-only gradient (FusedLeakyReLU backward written as NHWC planes) reached a path that "
+                           "reads fp32 values — ConvBiasActFunction.backward chose it for a convolution that is not on the implicit-GEMM path")
+    return t.contiguous()
+
+
 def _nhwc(t, pre=None):
     """NHWC split planes of t — of Blur(t) when `pre` is given (upfirdn2d + split: a fused kernel was built, was bit-identical
     and did not beat the two, profiles/r6_blur_nhwc_planes_experiment.txt).
@@ -303,6 +325,8 @@ def _nhwc(t, pre=None):
         hit = att[2].get(sig)
         if hit is not None:
             return hit
+    if _is_planes_only(t):
+        raise RuntimeError("cips3d_amd: a planes-only gradient lost its planes")
     m = _memo()
     key = _key(t) + sig
     ent = m.shared.get(key)
@@ -610,20 +634,24 @@ def _conv_bwd_data(dy, w, in_shape, stride, pad, scale=1.0, pre=None):
         Hb, Wb = _pre_shape(H, W, pre)
         if (stride == 2 and pad == 0 and pre[3] == 1 and dy.is_cuda and _s2_parity_ok(C, O, dy.shape[2] * dy.shape[3])):
             banks, w_off = _w_banks_s2(w, scale)
-            dxp, out_off = ops.conv2d_x3_dgrad_s2(banks, w_off, _nhwc(dy.contiguous()), B, C, Hb, Wb, O, kh, kw)
+            dxp, out_off = ops.conv2d_x3_dgrad_s2(banks, w_off, _nhwc(dy if _is_planes_only(dy) else dy.contiguous()), B, C, Hb, Wb, O, kh, kw)
             gx0, gx1, gy0, gy1 = _pre_adjoint_pads(H, W, pre)
             return ops.upfirdn2d_parity(dxp, out_off, _flipped(pre[0]), B * C, Hb, Wb, gx0, gx1, gy0, gy1).view(B, C, H, W)
         return _pre_adjoint(_conv_bwd_data(dy, w, (B, C, Hb, Wb), stride, pad, scale), pre, in_shape)
     B, C, H, W = in_shape
     O, _, kh, kw = w.shape
-    dy = dy.contiguous()
+    po = _is_planes_only(dy)
+    if not po:
+        dy = dy.contiguous()
     Ho, Wo = dy.shape[2], dy.shape[3]
     K, N = C * kh * kw, Ho * Wo
-    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
-        return ops.conv1x1_smallk_bwd_data(dy, _scaled(w, scale).reshape(O, C).contiguous(), C)
-    if stride == 1 and _implicit_ok(O, H * W, C) and Ho + kh - 1 - 2 * pad == H and kh - 1 - pad >= 0:
+    if stride == 1 and _implicit_ok(O, H * W, C) and Ho + kh - 1 - 2 * pad == H and kh - 1 - pad >= 0 and not (kh == 1 and kw == 1 and C <= 4):
         # dx = conv(dy, flipped weights with the channel roles swapped), padding kh-1-pad
         return ops.conv2d_x3(_w_planes_flipT(w, scale), _nhwc(dy), B, O, Ho, Wo, C, kh, kw, 1, kh - 1 - pad)
+    if po:
+        dy = _dense(dy)                   # raises: every path below reads values
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and (H * W) % 4 == 0:
+        return ops.conv1x1_smallk_bwd_data(dy, _scaled(w, scale).reshape(O, C).contiguous(), C)
     if _fold_ok(K, N, B, O):
         wP = _w_rows(w, scale, False)                                                            # (1, O, K)
         dcol2 = torch.empty(K, B * N, device=dy.device)
@@ -653,7 +681,7 @@ def _conv_bwd_weight(dy, x, w_shape, stride, pad, scale=1.0, pre=None):
         O, C, kh, kw = w_shape
         Hb, Wb = _pre_shape(x.shape[2], x.shape[3], pre)
         if _implicit_ok(C, dy.shape[2] * dy.shape[3], O) and x.is_cuda:
-            dw = ops.conv2d_x3_wgrad(_nhwc(dy.contiguous()), _nhwc(x.contiguous(), pre), x.shape[0], C, Hb, Wb, O, kh, kw, stride, pad, scale)
+            dw = ops.conv2d_x3_wgrad(_nhwc(dy if _is_planes_only(dy) else dy.contiguous()), _nhwc(x.contiguous(), pre), x.shape[0], C, Hb, Wb, O, kh, kw, stride, pad, scale)
             if dw is not None:
                 return dw
         x = _pre_fp32(x, pre)
@@ -667,14 +695,18 @@ def _conv_bwd_weight_raw(dy, x, w_shape, stride, pad, scale):
     O, C, kh, kw = w_shape
     B = x.shape[0]
     x = x.contiguous()
-    dy = dy.contiguous()
+    po = _is_planes_only(dy)
+    if not po:
+        dy = dy.contiguous()
     K, N = C * kh * kw, dy.shape[2] * dy.shape[3]
-    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and N % 4 == 0:
-        return ops.conv1x1_smallk_bwd_weight(dy, x).view(O, C, 1, 1)       # RGB input convs: streaming reduction
     if _implicit_ok(C, N, O):
         dw = ops.conv2d_x3_wgrad(_nhwc(dy), _nhwc(x), B, C, x.shape[2], x.shape[3], O, kh, kw, stride, pad, scale)
         if dw is not None:
             return (dw,)
+    if po:
+        dy = _dense(dy)                   # raises: every path below reads values
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and C <= 4 and N % 4 == 0:
+        return ops.conv1x1_smallk_bwd_weight(dy, x).view(O, C, 1, 1)       # RGB input convs: streaming reduction
     if _fold_ok(K, N, B, O):
         colP, _, _ = _folded_col_planes(x, kh, kw, stride, pad)
         nch = _split_count(((O + 255) // 256) * ((K + 127) // 128), B * N)
@@ -800,13 +832,39 @@ class ConvBiasActFunction(Function):
         x, w, out = ctx.saved_tensors
         w = ctx.w_obj if ctx.w_obj is not None else w
         stride, pad, scale, slope, act_scale, pre = ctx.cfg
-        dpre, dbias = FusedLeakyReLUFunctionBackward.apply(dout.contiguous(), out, slope, act_scale)
+        po = PLANES_ONLY_GRADIENT and _planes_only_ok(x.shape, w.shape, stride, pad, pre, ctx.needs_input_grad[0], dout)
+        dpre, dbias = FusedLeakyReLUFunctionBackward.apply(dout.contiguous(), out, slope, act_scale, po)
         dx = None
         with _share_planes():
             if ctx.needs_input_grad[0]:
                 dx = Conv2dBwdDataFunction.apply(dpre, w, x.shape, stride, pad, scale, pre)
         return (dx, None, (dbias if ctx.needs_input_grad[2] else None), (dpre if ctx.needs_input_grad[3] else None),
                 None, None, None, None, None, None)
+
+
+PLANES_ONLY_GRADIENT = True      # False: FusedLeakyReLU's backward writes the fp32 gradient and the convolution splits it (the parity test flips it)
+
+
+def _planes_only_ok(x_shape, w_shape, stride, pad, pre, need_dx, dout):
+    """may the gated gradient of this ConvBiasAct layer exist as NHWC planes only?  Yes when BOTH of its consumers — the
+    convolution's data gradient (if asked for) and weight gradient — take their implicit-GEMM forms, which read planes and
+    nothing else (the conditions of _conv_bwd_data / _conv_bwd_weight, restated)"""
+    if not (CONV_MODE == "bf16x3" and dout.is_cuda and dout.dtype == torch.float32 and dout.dim() == 4):
+        return False
+    B, C, H, W = x_shape
+    O, _, kh, kw = w_shape
+    Hb, Wb = _pre_shape(H, W, pre)
+    Ho, Wo = dout.shape[2], dout.shape[3]
+    N = Ho * Wo
+    if not _implicit_ok(C, N, O) or (B * N) % 32 or O % 8:
+        return False                                                     # weight gradient: cips_conv2d_x3_wgrad's conditions
+    if need_dx:
+        if stride == 1:
+            if pre is not None or not (_implicit_ok(O, Hb * Wb, C) and Ho + kh - 1 - 2 * pad == Hb and kh - 1 - pad >= 0):
+                return False
+        elif not (stride == 2 and pad == 0 and pre is not None and pre[3] == 1 and _s2_parity_ok(C, O, N)):
+            return False
+    return True
 
 
 def _conv_bias_act_apply(x, w, bias, stride, pad, scale, slope, act_scale, pre=None):

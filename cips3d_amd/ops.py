@@ -1740,6 +1740,23 @@ def lrelu_bwd_bias(grad, refer, alpha, scale):
     return gin, gb
 
 
+def lrelu_bwd_bias_nhwc(grad, refer, alpha, scale):
+    """lrelu_bwd_bias with the gated gradient written as NHWC split planes only (cips_lrelu_bwd_bias_nhwc) -> (Planes, grad_bias)"""
+    lib = _lib.load()
+    B, C, H, W = grad.shape
+    hw = H * W
+    S = lib.cips_lrelu_bwd_bias_nhwc_tiles(hw)
+    hi = torch.empty(B * hw + 1, C, device=grad.device, dtype=BF)
+    lo = torch.empty(B * hw + 1, C, device=grad.device, dtype=BF)
+    part = torch.empty(B, C, S, device=grad.device)
+    gb = torch.empty(C, device=grad.device)
+    with torch.cuda.device(grad.device):
+        check(lib.cips_lrelu_bwd_bias_nhwc(_p(grad), _p(refer), _p(hi), _p(lo), _p(part), B, C, hw, float(alpha), float(scale), _stream()),
+              "cips_lrelu_bwd_bias_nhwc")
+        check(lib.cips_lrelu_bwd_bias_finish(_p(part), _p(gb), B, C, S, _stream()), "cips_lrelu_bwd_bias_finish")
+    return Planes(hi, lo), gb
+
+
 def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
     """upfirdn2d_op.upfirdn2d(input[N,H,W,minor], kernel, ...) -> Tensor of input's dtype
     (exp/comm/op/upfirdn2d.cpp:12-23)."""

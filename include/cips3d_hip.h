@@ -586,6 +586,13 @@ int cips_lrelu_bwd_bias(const float* grad, const float* refer, float* grad_in, f
                         float alpha, float scale, cips_stream_t stream);
 /* grad_bias[c] = sum over b < B, s < S of part[b][c][s] (fixed order): the tail of cips_lrelu_bwd_bias, planes = B * C */
 int cips_lrelu_bwd_bias_finish(const float* part, float* grad_bias, int B, int C, int S, cips_stream_t stream);
+/* cips_lrelu_bwd_bias written directly as the NHWC split planes (B*HW + 1, C; zero last row) of the gated gradient — for
+ * convolutions that read their incoming gradient only through those planes the fp32 tensor never exists.  part: (B, C,
+ * cips_lrelu_bwd_bias_nhwc_tiles(HW)) partial bias sums for cips_lrelu_bwd_bias_finish.  C % 8 == 0.  Plane values are those of
+ * cips_lrelu_bwd_bias followed by cips_split_planes_nhwc, bit for bit. */
+int cips_lrelu_bwd_bias_nhwc_tiles(int HW);
+int cips_lrelu_bwd_bias_nhwc(const float* grad, const float* refer, void* t_hi, void* t_lo, float* part, int B, int C, int HW,
+                             float alpha, float scale, cips_stream_t stream);
 
 /* 1x1 convolution with C <= 4 input channels (EqualConv2d of the RGB input layers, discriminator.py:457-459):
  * y (B, O, HW) = w (O, C) . x (B, C, HW); HW % 4 == 0.  Streaming kernel, no GEMM. */

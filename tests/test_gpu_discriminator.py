@@ -588,3 +588,47 @@ def test_batched_weight_planes_are_the_per_layer_ones_bit_for_bit():
     before = dm._WCACHE[id(conv.weight)][1][("fwd", float(conv.scale))][2]
     dm.prepare_weight_planes(layers)
     assert dm._WCACHE[id(conv.weight)][1][("fwd", float(conv.scale))][2] is not before
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 32, False), (2, 64, 96, 32, True), (4, 64, 64, 16, True), (2, 32, 64, 64, False), (8, 64, 64, 8, False)])
+def test_gated_gradient_as_planes_only(cfg, monkeypatch):
+    """ConvLayer (EqualConv2d + FusedLeakyReLU) with its gated gradient written as NHWC planes only (cips_lrelu_bwd_bias_nhwc, round 6)
+    against the fp32 gradient + split path: the planes are the same bit for bit, so input gradient, R1-style double backward,
+    weight and bias gradients are identical up to the bias sums' order; and a planes-only gradient that reaches a value-reading
+    path raises instead of reading zeros."""
+    from cips3d_amd import ops
+    from cips3d_amd import discriminator as dm
+    B, C, O, H, down = cfg
+    d = torch.device("cuda:0")
+    torch.manual_seed(7)
+    layer = dm.ConvLayer(C, O, 3, downsample=down).to(d)
+    with torch.no_grad():
+        layer.flrelu.bias.copy_(torch.randn(O, device=d) * 0.3)
+    x0 = torch.randn(B, C, H, H, device=d)
+    res = {}
+    for po in (True, False):
+        monkeypatch.setattr(dm, "PLANES_ONLY_GRADIENT", po)
+        layer.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        y = layer(x)
+        up = torch.randn(y.shape, device=d, generator=torch.Generator(device=d).manual_seed(1))
+        gx, = torch.autograd.grad((y * up).sum(), x, create_graph=True)
+        ((gx ** 2).sum() + (y ** 2).sum()).backward()
+        res[po] = (gx.detach(), x.grad.clone(), layer.equal_conv.weight.grad.clone(), layer.flrelu.bias.grad.clone())
+    for a, b, what in zip(res[True], res[False], ("dx", "x.grad", "w.grad", "bias.grad")):
+        if what == "bias.grad":
+            assert rel_err(a, b) < 1e-6, (what, float(rel_err(a, b)))
+        else:
+            assert torch.equal(a, b), (what, float(rel_err(a, b)))
+    # the kernel against the two it replaces, and the guard
+    g = torch.randn(B, O, 16, 16, device=d); r = torch.randn(B, O, 16, 16, device=d)
+    P, gb = ops.lrelu_bwd_bias_nhwc(g, r, 0.2, 2 ** 0.5)
+    gin, gb0 = ops.lrelu_bwd_bias(g, r, 0.2, 2 ** 0.5)
+    R = ops.split_planes_nhwc(gin)
+    assert torch.equal(P.hi.view(torch.int16), R.hi.view(torch.int16)) and torch.equal(P.lo.view(torch.int16), R.lo.view(torch.int16))
+    assert rel_err(gb, gb0) < 1e-6
+    ph, _ = dm.FusedLeakyReLUFunctionBackward.apply(g, r, 0.2, 2 ** 0.5, True)
+    with pytest.raises(RuntimeError):
+        dm._dense(ph)
+    with pytest.raises(RuntimeError):
+        dm._conv_bwd_data(ph, torch.randn(O, 3, 1, 1, device=d), (B, 3, 16, 16), 1, 0)
