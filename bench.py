@@ -627,44 +627,62 @@ def main():
     ms = dt / a.steps * 1e3
     value = world * b * a.steps / dt
     exact = None
+    f32_all = None
     if mode == "bf16x3" and not a.no_exact:
-        # the same step with the head GEMMs (forward and backward) and the SIREN forward on exact fp32 MFMA
-        # (v_mfma_f32_32x32x2_f32); the SIREN backward has no fused fp32 form and stays on the split-bf16 kernel — the key says
-        # so (rounds 1-4 called this leg "exact_f32").  Same launch mode, step count and warm-up as the headline.
-        ops.INR_MODE = "f32"
-        fwd_was = ops.SIREN_FWD_MODE
-        ops.SIREN_FWD_MODE = "f32"
+        # two extra legs, timed like the headline (same launch mode, step count and warm-up):
+        #  * f32_mfma_head_and_siren_forward: head GEMMs (forward and backward) and the SIREN forward on exact fp32 MFMA
+        #    (v_mfma_f32_32x32x2_f32); the SIREN backward stays the fused split-bf16 kernel — the key says so;
+        #  * f32_all (round 6): additionally the SIREN backward as an fp32 data pass with fp32-staged activations and fp32-MFMA
+        #    weight-gradient GEMMs (CIPS_SIREN_BWD=staged_f32): no split operand anywhere in the step.
+        fwd_was, bwd_was = ops.SIREN_FWD_MODE, ops.SIREN_BWD_MODE
         was, g_was = use_graph[0], graph
-        g32 = None
-        if was:
+
+        def leg(siren_bwd):
+            nonlocal graph
+            ops.INR_MODE = "f32"
+            ops.SIREN_FWD_MODE = "f32"
+            ops.SIREN_BWD_MODE = siren_bwd
+            g32 = None
+            if was:
+                try:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        fwd_bwd()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    g32 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g32, capture_error_mode="thread_local" if pg else "global"):
+                        fwd_bwd()
+                except Exception as e:                  # noqa: BLE001
+                    print(f"[bench] hipGraph capture of the fp32 leg ({siren_bwd}) failed ({type(e).__name__}: {e}); eager", file=sys.stderr)
+                    g32 = None
+                    torch.cuda.synchronize()
+            graph = g32
+            use_graph[0] = g32 is not None
             try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    fwd_bwd()
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                g32 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g32, capture_error_mode="thread_local" if pg else "global"):
-                    fwd_bwd()
-            except Exception as e:                  # noqa: BLE001
-                print(f"[bench] hipGraph capture of the fp32-MFMA leg failed ({type(e).__name__}: {e}); eager", file=sys.stderr)
-                g32 = None
-                torch.cuda.synchronize()
-        graph = g32
-        use_graph[0] = g32 is not None
-        dte = timed(a.steps, a.warmup)
-        launch32 = "hipGraph replay" if use_graph[0] else "eager"
-        graph = g_was
-        use_graph[0] = was
-        ops.INR_MODE = mode
-        ops.SIREN_FWD_MODE = fwd_was
-        exact = {"value": round(world * b * a.steps / dte, 2), "ms_per_step": round(dte / a.steps * 1e3, 3), "steps": a.steps,
-                 "warmup": a.warmup, "launch": launch32,
-                 "fp32_mfma": ["INR head GEMMs, forward and backward (gemm_f32_kernel)", "SIREN forward (siren.hip)"],
-                 "split_bf16": ["SIREN backward (siren_bwd_x4_kernel: no fused fp32 form exists; CIPS_SIREN_BWD=staged runs an fp32 "
-                                "data pass but contracts the weight gradients on the split-bf16 K-major GEMM)"],
-                 "note": "CIPS_INR_MODE=f32 CIPS_SIREN_FWD=f32"}
+                dte = timed(a.steps, a.warmup)
+                launch32 = "hipGraph replay" if use_graph[0] else "eager"
+            finally:
+                graph = g_was
+                use_graph[0] = was
+                ops.INR_MODE = mode
+                ops.SIREN_FWD_MODE, ops.SIREN_BWD_MODE = fwd_was, bwd_was
+            return {"value": round(world * b * a.steps / dte, 2), "ms_per_step": round(dte / a.steps * 1e3, 3), "steps": a.steps,
+                    "warmup": a.warmup, "launch": launch32}
+
+        exact = leg("x3")
+        exact.update({"fp32_mfma": ["INR head GEMMs, forward and backward (gemm_f32_kernel)", "SIREN forward (siren.hip)"],
+                      "split_bf16": ["SIREN backward (siren_bwd_x4_kernel, the fused form)"],
+                      "note": "CIPS_INR_MODE=f32 CIPS_SIREN_FWD=f32"})
+        try:
+            f32_all = leg("staged_f32")
+            f32_all.update({"fp32_mfma": ["INR head GEMMs, forward and backward", "SIREN forward", "SIREN backward: fp32 data pass "
+                                          "(siren_bwd_kernel, activations staged as fp32) + weight-gradient GEMMs on gemm_f32_kernel (k-major A)"],
+                            "split_operand": [], "note": "CIPS_INR_MODE=f32 CIPS_SIREN_FWD=f32 CIPS_SIREN_BWD=staged_f32; rays, SIREN and "
+                            "composite as separate launches (the fused march exists in the split-operand form only)"})
+        except Exception as e:                          # noqa: BLE001 — an extra leg must never cost the headline line
+            f32_all = {"error": f"{type(e).__name__}: {e}"}
     E = 2 * S if a.hier else S
     line = {
         "metric": "rendered imgs/sec (G fwd+bwd)", "value": round(value, 2), "unit": "img/s", "n_gpus": world,
@@ -687,6 +705,8 @@ def main():
     }
     if exact:
         line["f32_mfma_head_and_siren_forward"] = exact
+    if f32_all:
+        line["f32_all"] = f32_all
     if pg and ar_events:
         # gradient exchange as the stream sees it (events around the all-reduce of every timed step; with the overlapped
         # form this is what is left exposed after the backward): median ms, bytes per rank, ring bus bandwidth

@@ -301,7 +301,23 @@ __device__ __forceinline__ void store_layoutN(unsigned short* base_hi, unsigned 
     }
 }
 
-template <bool HW>
+// F32OUT (round 6, the all-fp32 leg): the same values stored as fp32 rows [point][Q * 32] through the hi pointers (the lo pointers
+// are unused) — the operands of fp32-MFMA weight-gradient GEMMs, so that no split operand takes part anywhere in that leg
+template <int Q, bool F32OUT>
+__device__ __forceinline__ void store_act(unsigned short* base_hi, unsigned short* base_lo, long long row, int hf, const float (&v)[Q][16]) {
+  if constexpr (F32OUT) {
+    float* pf = reinterpret_cast<float*>(base_hi) + row * (Q * 32) + 4 * hf;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(pf + q * 32 + 8 * g) = make_float4(v[q][4 * g], v[q][4 * g + 1], v[q][4 * g + 2], v[q][4 * g + 3]);
+  } else {
+    store_layoutN<Q>(base_hi, base_lo, row, hf, v);
+  }
+}
+
+template <bool HW, bool F32OUT = false>
 __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.y;
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     // ---- recompute layer 0 ----
     float h[4][16];
     layer0<HW, false>(L0, hf, px, py, pz, h, h);   // cos of layer 0 is recomputed at the end (saves 64 live VGPRs)
-    if (valid) store_layoutN<4>(a.h1h, a.h1l, gp, hf, h);
+    if (valid) store_act<4, F32OUT>(a.h1h, a.h1l, gp, hf, h);
 
     // ---- recompute layer 1 ----
     f32x16 acc[4];
@@ -341,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     mfma_layer<4, 4>(W1s, 32 * LD1, 1, h, acc);
     float cs2[4][16];
     film_act<HW, true, 4>(acc, sm + OFF_G1, sm + OFF_C1, hf, h, cs2);
-    if (valid) store_layoutN<4>(a.h2h, a.h2l, gp, hf, h);
+    if (valid) store_act<4, F32OUT>(a.h2h, a.h2l, gp, hf, h);
     // sum_p dsigma * h2  (gradient of final_layer.weight)
 #pragma unroll
     for (int gI = 0; gI < 2; ++gI) {
@@ -357,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     mfma_layer<2, 4>(Wcs, 32 * LDC, 1, h, accc);
     float hc[2][16], csc[2][16];
     film_act<HW, true, 2>(accc, sm + OFF_GC, sm + OFF_CC, hf, hc, csc);
-    if (valid) store_layoutN<2>(a.hch, a.hcl, gp, hf, hc);
+    if (valid) store_act<2, F32OUT>(a.hch, a.hcl, gp, hf, hc);
 
     // ---- d hc = Wf^T dfeat   (K = 32 channels, M = 64) ----
     float df[1][16];
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
           dpc[q][r] = sm[OFF_GC + featidx(q, r, 0) + 4 * hf] * d;
           if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-      if (valid) store_layoutN<2>(a.dach, a.dacl, gp, hf, hc);
+      if (valid) store_act<2, F32OUT>(a.dach, a.dacl, gp, hf, hc);
       r_dac += reduce32(v, lane);
     }
 
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
         dp2[q][r] = sm[OFF_G1 + f] * d;
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
-    if (valid) store_layoutN<4>(a.da2h, a.da2l, gp, hf, h);
+    if (valid) store_act<4, F32OUT>(a.da2h, a.da2l, gp, hf, h);
 #pragma unroll
     for (int gI = 0; gI < 2; ++gI) {
       float v[32];
@@ -499,10 +515,27 @@ extern "C" int cips_siren_bwd_rows(int B, int P) {
   return B * chunks * 4;
 }
 
+static int siren_bwd_data_launch(const cips_siren_weights* w, const float* points, const float* dfeat, const float* dsigma, void* h1_hi,
+                                 void* h1_lo, void* h2_hi, void* h2_lo, void* hc_hi, void* hc_lo, void* da2_hi, void* da2_lo, void* dac_hi,
+                                 void* dac_lo, float* red, int B, int P, bool f32out, cips_stream_t stream);
+
 extern "C" int cips_siren_bwd_data(const cips_siren_weights* w, const float* points,
                                    const float* dfeat, const float* dsigma, void* h1_hi, void* h1_lo, void* h2_hi,
                                    void* h2_lo, void* hc_hi, void* hc_lo, void* da2_hi, void* da2_lo, void* dac_hi,
                                    void* dac_lo, float* red, int B, int P, cips_stream_t stream) {
+  return siren_bwd_data_launch(w, points, dfeat, dsigma, h1_hi, h1_lo, h2_hi, h2_lo, hc_hi, hc_lo, da2_hi, da2_lo, dac_hi, dac_lo, red, B, P,
+                               false, stream);
+}
+
+extern "C" int cips_siren_bwd_data_f32(const cips_siren_weights* w, const float* points, const float* dfeat, const float* dsigma, float* h1,
+                                       float* h2, float* hc, float* da2, float* dac, float* red, int B, int P, cips_stream_t stream) {
+  if (!h1 || !h2 || !hc || !da2 || !dac) return (int)hipErrorInvalidValue;
+  return siren_bwd_data_launch(w, points, dfeat, dsigma, h1, nullptr, h2, nullptr, hc, nullptr, da2, nullptr, dac, nullptr, red, B, P, true, stream);
+}
+
+static int siren_bwd_data_launch(const cips_siren_weights* w, const float* points, const float* dfeat, const float* dsigma, void* h1_hi,
+                                 void* h1_lo, void* h2_hi, void* h2_lo, void* hc_hi, void* hc_lo, void* da2_hi, void* da2_lo, void* dac_hi,
+                                 void* dac_lo, float* red, int B, int P, bool f32out, cips_stream_t stream) {
   if (!w || B <= 0 || P <= 0) return (int)hipErrorInvalidValue;
   BwdArgs a;
   a.w = *w; a.points = points; a.dfeat = dfeat; a.dsigma = dsigma;
@@ -515,13 +548,16 @@ extern "C" int cips_siren_bwd_data(const cips_siren_weights* w, const float* poi
   static bool attr_set = false;
   CIPS_PER_DEVICE(attr_set, false);
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)siren_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)siren_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)siren_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)siren_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)siren_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)siren_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  if ((w->trig_mode & 1))
-    hipLaunchKernelGGL(siren_bwd_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(siren_bwd_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);
+  const bool hw = (w->trig_mode & 1);
+  if (hw && f32out) hipLaunchKernelGGL((siren_bwd_kernel<true, true>), grid, dim3(256), smem, (hipStream_t)stream, a);
+  else if (hw) hipLaunchKernelGGL((siren_bwd_kernel<true, false>), grid, dim3(256), smem, (hipStream_t)stream, a);
+  else if (f32out) hipLaunchKernelGGL((siren_bwd_kernel<false, true>), grid, dim3(256), smem, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((siren_bwd_kernel<false, false>), grid, dim3(256), smem, (hipStream_t)stream, a);
   return CIPS_CHECK_LAUNCH();
 }

@@ -170,7 +170,8 @@ def _split_k(P, target=8):
 
 # The exact-fp32 mode of the path (the only environment variables the package reads besides
 # CIPS_INR_MODE and CIPS_D_CONV_MODE).  Forward "x3": split-operand matrix-core chain (default: fp16 planes, sigma to fp32
-# class); "f32": exact fp32 MFMA.  Backward "x3": fused split-bf16 kernel; "staged": fp32 data pass + GEMMs.
+# class); "f32": exact fp32 MFMA.  Backward "x3": fused split-bf16 kernel; "staged": fp32 data pass + split-bf16 K-major GEMMs;
+# "staged_f32" (round 6): fp32 data pass with fp32-staged activations + fp32-MFMA weight-gradient GEMMs (the all-fp32 leg).
 SIREN_FWD_MODE = __import__("os").environ.get("CIPS_SIREN_FWD", "x3")
 SIREN_BWD_MODE = __import__("os").environ.get("CIPS_SIREN_BWD", "x3")
 
@@ -250,6 +251,32 @@ def _siren_backward(t, dfeat, dsigma, B, P, points=None, rays=None):
                   "cips_siren_bwd_x3_finalize")
             return tuple(outs[k] for k in ("dg0", "dp0", "dg1", "dp1", "dgc", "dpc", "dw0", "db0", "dw1", "db1", "dws",
                                            "dbs", "dwc", "dbc", "dwf", "dbf"))
+        elif SIREN_BWD_MODE == "staged_f32":
+            # the all-fp32 leg (round 6): the data pass stages fp32 rows, every weight-gradient contraction runs on the exact-fp32
+            # MFMA GEMM (k-major A): no split operand anywhere in the SIREN backward
+            BP = B * P
+            h1, h2, da2 = (torch.empty(BP, 128, device=dev) for _ in range(3))
+            hc, dac = (torch.empty(BP, 64, device=dev) for _ in range(2))
+            rows = lib.cips_siren_bwd_rows(B, P)
+            red = torch.empty(rows, 868, device=dev)
+            check(lib.cips_siren_bwd_data_f32(C.byref(sw), _p(points), _p(dfeat), _p(dsigma), _p(h1), _p(h2), _p(hc), _p(da2), _p(dac),
+                                              _p(red), B, P, _stream()), "cips_siren_bwd_data_f32")
+            R = red.view(B, rows // B, 868).sum(1)
+            sp = _split_k(P, 16)
+            Kc = P // sp
+            G1 = torch.empty(B * sp, 128, 128, device=dev)   # da2^T @ h1 per image and point chunk
+            gemm(da2, h1, G1, 128, 128, Kc, 128, 128, 128, batch=B * sp, strideA=Kc * 128, strideB=Kc * 128, strideC=128 * 128,
+                 a_kmajor=True)
+            G1 = G1.view(B, sp, 128, 128).sum(1)
+            Gc = torch.empty(B * sp, 64, 128, device=dev)    # dac^T @ h2
+            gemm(dac, h2, Gc, 64, 128, Kc, 64, 128, 128, batch=B * sp, strideA=Kc * 64, strideB=Kc * 128, strideC=64 * 128,
+                 a_kmajor=True)
+            Gc = Gc.view(B, sp, 64, 128).sum(1)
+            spf = _split_k(BP, 1024)
+            Kf = BP // spf
+            Gf = torch.empty(spf, 32, 64, device=dev)        # dfeat^T @ hc (no per-image scale)
+            gemm(dfeat, hc, Gf, 32, 64, Kf, 32, 64, 64, batch=spf, strideA=Kf * 32, strideB=Kf * 64, strideC=32 * 64, a_kmajor=True)
+            dwf = Gf.sum(0)
         else:
             BP = B * P
             h1, h2, da2 = (Planes.empty(BP, 128, device=dev) for _ in range(3))

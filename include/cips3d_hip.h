@@ -97,6 +97,11 @@ int cips_siren_bwd_data(const cips_siren_weights* w, const float* points,
                         void* h1_hi, void* h1_lo, void* h2_hi, void* h2_lo, void* hc_hi, void* hc_lo,
                         void* da2_hi, void* da2_lo, void* dac_hi, void* dac_lo,
                         float* red, int B, int P, cips_stream_t stream);
+/* The same data pass with the five staged tensors written as fp32 rows — h1, h2, da2: (B*P, 128); hc, dac: (B*P, 64) — for
+ * weight-gradient contractions on the exact-fp32 MFMA GEMM (cips_gemm_f32, a_kmajor): the all-fp32 leg, in which no split
+ * operand takes part (CIPS_SIREN_BWD=staged_f32 with CIPS_INR_MODE=f32 CIPS_SIREN_FWD=f32). */
+int cips_siren_bwd_data_f32(const cips_siren_weights* w, const float* points, const float* dfeat, const float* dsigma, float* h1,
+                            float* h2, float* hc, float* da2, float* dac, float* red, int B, int P, cips_stream_t stream);
 
 /* Forward on the split-bf16 matrix-core chain (the default of the Python layer; same contract as cips_siren_fwd;
  * ~1e-5 relative instead of ~1e-6, 2.3x faster): */

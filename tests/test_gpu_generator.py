@@ -16,16 +16,19 @@ CASES = ["g_r16_hier", "g_r8_flat_noise", "g_r8_hier_noise", "g_r8_freeze", "g_r
          "g_r16_part_odd"]   # _part: part_grad_forward (96 of 256 pixels; _odd: 100, not a multiple of the 32-pixel GEMM granule)
 
 
-@pytest.fixture(params=["f32", "bf16x3"])
+@pytest.fixture(params=["f32", "bf16x3", "f32_all"])
 def inr_mode(request):
-    """Run under both numeric modes: exact fp32 MFMA (head GEMMs and SIREN forward) and the 3-pass split-bf16 MFMA
-    path (default)."""
+    """Run under the numeric modes: exact fp32 MFMA for the head GEMMs and the SIREN forward ("f32"; the SIREN backward stays
+    the fused split-bf16 kernel), the 3-pass split-operand MFMA path (default), and — round 6 — "f32_all": additionally the SIREN
+    backward as the fp32 data pass with fp32-staged activations and fp32-MFMA weight-gradient GEMMs (CIPS_SIREN_BWD=staged_f32):
+    no split operand anywhere in the generator."""
     from cips3d_amd import ops
-    old = (ops.INR_MODE, ops.SIREN_FWD_MODE)
-    ops.INR_MODE = request.param
-    ops.SIREN_FWD_MODE = "f32" if request.param == "f32" else "x3"
+    old = (ops.INR_MODE, ops.SIREN_FWD_MODE, ops.SIREN_BWD_MODE)
+    ops.INR_MODE = "bf16x3" if request.param == "bf16x3" else "f32"
+    ops.SIREN_FWD_MODE = "x3" if request.param == "bf16x3" else "f32"
+    ops.SIREN_BWD_MODE = "staged_f32" if request.param == "f32_all" else "x3"
     yield request.param
-    ops.INR_MODE, ops.SIREN_FWD_MODE = old
+    ops.INR_MODE, ops.SIREN_FWD_MODE, ops.SIREN_BWD_MODE = old
 
 
 def _oracle64(fix, gates, keep_preact=False):
@@ -142,6 +145,9 @@ def test_generator_matches_reference_golden(tag, inr_mode):
           f"{wa[2]:.3e} vs the reference's fp32 digest, at {wa[0]} ({len(rows_a)} parameters)")
     bad = [r for r in rows_a if max(r[1], r[2]) > GRAD_TOL]
     assert not bad, bad
+    if inr_mode == "f32_all":
+        # no split operand anywhere: every gradient in the fp32 class against the fp64 oracle (2e-5)
+        assert wa[1] <= 2e-5, wa
 
     # ---- (B) free-running ----
     rec = []
