@@ -380,9 +380,11 @@ def _flipped(k):
     key = (k.data_ptr(), k._version, str(k.device))
     f = _FLIPPED.get(key)
     if f is None:
-        if len(_FLIPPED) > 64:
-            _FLIPPED.clear()
-        f = _FLIPPED[key] = torch.flip(k, [0, 1]).contiguous()
+        f = torch.flip(k, [0, 1]).contiguous()
+        if not (k.is_cuda and torch.cuda.is_current_stream_capturing()):      # a tensor made inside a capture lives in the graph's pool
+            if len(_FLIPPED) > 64:
+                _FLIPPED.clear()
+            _FLIPPED[key] = f
     return f
 
 
@@ -503,7 +505,8 @@ def prepare_weight_planes(layers):
         def stale(kind):
             hit = ent.get((kind, sc))
             return hit is None or hit[0] != w._version or hit[1] != w.data_ptr()
-        need_fwd, need_alt = stale("fwd"), bool(alt) and want_alt and w.requires_grad is not None and stale(alt)
+        # the alternate form serves the DATA gradient: needed whenever a backward may run, frozen weights included (the G step)
+        need_fwd, need_alt = stale("fwd"), bool(alt) and want_alt and stale(alt)
         if need_fwd or need_alt:
             todo.append((w, ent, sc, alt if need_alt else None, need_fwd))
     if not todo:
@@ -766,7 +769,10 @@ def _zero1(like):
     key = (like.device, like.dtype)
     z = _ZERO1.get(key)
     if z is None:
-        z = _ZERO1[key] = torch.zeros(1, device=like.device, dtype=like.dtype)
+        z = torch.zeros(1, device=like.device, dtype=like.dtype)
+        if like.is_cuda and torch.cuda.is_current_stream_capturing():
+            return z                                   # not cached: it lives in the capturing graph's pool
+        _ZERO1[key] = z
     return z
 
 
