@@ -318,6 +318,109 @@ __global__ __launch_bounds__(256) void upfirdn2d_up2_kernel(UpfirArgs a, int bh)
   }
 }
 
+// Round 6: the two blurs of the skip branch (down 2 forward, up 2 backward) with the lanes along the HALF-resolution column and
+// every input element loaded once.  The column-per-lane forms above issue 9 (down 2) and 4 (up 2) dword loads per output whose
+// addresses stride by two columns or repeat: 24 / 14 clocks per memory instruction on the texture path, 110 us / 144 us for the
+// 64 x 64 x 512 maps whose bytes need ~35.  Here a thread owns output column V (down 2: one 8-byte load of input columns 2V, 2V+1
+// per row; up 2: one dword load of input column V per row) and takes columns 2V-1 / 2V+2 (V-1 / V+1) from its neighbour lanes
+// by shuffles; a row segment is min(width, 64) lanes, its edges are the image edge (zero padding) or, for rows wider than a
+// wave, a single extra load by the edge lane.  Same taps in the same order, one fma chain per output: the values of the
+// generic kernel bit for bit.  Shapes: 4 x 4 kernel, pad_x0 = 1 and in_w = 2 out_w (down 2) / pad_x0 = 2 and out_w = 2 in_w
+// (up 2), a power-of-two half width; everything else keeps the forms above.
+template <int TH>
+__global__ __launch_bounds__(256) void upfirdn2d_down2_pairs_kernel(UpfirArgs a, int bh, int seg) {
+  float ck[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ck[i] = a.k[15 - i];
+  const long long per_plane = (long long)bh * a.out_w, nblk = a.major * per_plane;
+  const int lane = threadIdx.x & 63, ls = lane & (seg - 1);
+  for (long long t = blockIdx.x * 256LL + threadIdx.x; t < nblk; t += gridDim.x * 256LL) {
+    const long long mj = t / per_plane;
+    const int rem = (int)(t - mj * per_plane), by = rem / a.out_w, ox = rem - by * a.out_w;
+    const int oy0 = by * TH, iyb = oy0 * 2 - a.pad_y0;
+    const float* src = a.in + mj * (long long)a.in_h * a.in_w + 2 * ox;
+    float acc[TH];
+#pragma unroll
+    for (int ry = 0; ry < TH; ++ry) acc[ry] = 0.f;
+    constexpr int NR = 2 * (TH - 1) + 4;
+    float2 v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)                       // every row's load is issued before the first shuffle waits for one
+      v[r] = *reinterpret_cast<const float2*>(src + (long long)min(max(iyb + r, 0), a.in_h - 1) * a.in_w);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int iy = iyb + r;
+      const bool rok = (unsigned)iy < (unsigned)a.in_h;
+      const float* rowp = src + (long long)min(max(iy, 0), a.in_h - 1) * a.in_w;
+      if (!rok) v[r] = make_float2(0.f, 0.f);
+      float xl = __shfl_up(v[r].y, 1), xr = __shfl_down(v[r].x, 1);
+      if (ls == 0) xl = (ox == 0 || !rok) ? 0.f : rowp[-1];
+      if (ls == seg - 1) xr = (ox == a.out_w - 1 || !rok) ? 0.f : rowp[2];
+      const float x[4] = {xl, v[r].x, v[r].y, xr};
+#pragma unroll
+      for (int ry = 0; ry < TH; ++ry) {
+        const int ky = r - 2 * ry;
+        if (ky >= 0 && ky < 4) {
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx) acc[ry] = fmaf(x[kx], ck[ky * 4 + kx], acc[ry]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ry = 0; ry < TH; ++ry) {
+      const int oy = oy0 + ry;
+      if (oy < a.out_h) a.out[(mj * a.out_h + oy) * (long long)a.out_w + ox] = acc[ry];
+    }
+  }
+}
+
+template <int TU>        // TU input rows = 2 TU output rows per thread
+__global__ __launch_bounds__(256) void upfirdn2d_up2_pairs_kernel(UpfirArgs a, int bh, int seg) {
+  float ck[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ck[i] = a.k[15 - i];
+  const long long per_plane = (long long)bh * a.in_w, nblk = a.major * per_plane;
+  const int lane = threadIdx.x & 63, ls = lane & (seg - 1);
+  for (long long t = blockIdx.x * 256LL + threadIdx.x; t < nblk; t += gridDim.x * 256LL) {
+    const long long mj = t / per_plane;
+    const int rem = (int)(t - mj * per_plane), by = rem / a.in_w, V = rem - by * a.in_w;
+    const int U0 = by * TU;
+    const float* src = a.in + mj * (long long)a.in_h * a.in_w + V;
+    float xl[TU + 2], xc[TU + 2], xr[TU + 2];
+#pragma unroll
+    for (int i = 0; i < TU + 2; ++i) xc[i] = src[(long long)min(max(U0 - 1 + i, 0), a.in_h - 1) * a.in_w];
+#pragma unroll
+    for (int i = 0; i < TU + 2; ++i) {
+      const int iy = U0 - 1 + i;
+      const bool rok = (unsigned)iy < (unsigned)a.in_h;
+      const float* rowp = src + (long long)min(max(iy, 0), a.in_h - 1) * a.in_w;
+      float c = xc[i];
+      if (!rok) c = 0.f;
+      float l = __shfl_up(c, 1), r = __shfl_down(c, 1);
+      if (ls == 0) l = (V == 0 || !rok) ? 0.f : rowp[-1];
+      if (ls == seg - 1) r = (V == a.in_w - 1 || !rok) ? 0.f : rowp[1];
+      xl[i] = l; xc[i] = c; xr[i] = r;
+    }
+    // output row 2U + s_: input rows U - 1 + s_ (kernel row s_) and U + s_ (kernel row s_ + 2); output column 2V: input columns
+    // V - 1, V with kernel columns 0, 2; column 2V + 1: input columns V, V + 1 with kernel columns 1, 3  (pad 2 on the low side)
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const int oy = 2 * (U0 + u) + s_;
+        float e = 0.f, o = 0.f;
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy) {
+          const int i = u + s_ + yy, ky = s_ + 2 * yy;
+          e = fmaf(xl[i], ck[ky * 4 + 0], e); e = fmaf(xc[i], ck[ky * 4 + 2], e);
+          o = fmaf(xc[i], ck[ky * 4 + 1], o); o = fmaf(xr[i], ck[ky * 4 + 3], o);
+        }
+        if (oy < a.out_h) *reinterpret_cast<float2*>(a.out + (mj * a.out_h + oy) * (long long)a.out_w + 2 * V) = make_float2(e, o);
+      }
+    }
+  }
+}
+
 // Occupancy: the band lives in DYNAMIC LDS sized to what the launch needs and small planes run in one-wave workgroups —
 // with a fixed 32 KiB tile and 256 threads per plane the 32x32 / 16x16 / 8x8 stages (16 384 planes of a few KiB each)
 // ran 4 workgroups per CU, one plane each, and took 116 us per call where their bytes need 3-20 us.
@@ -823,6 +926,23 @@ extern "C" int cips_upfirdn2d(const float* input, const float* kernel, float* ou
   if (total <= 0) return 0;
   if (minor == 1 && kernel_h == 4 && kernel_w == 4 && up_x == up_y && down_x == down_y) {
     hipStream_t st = (hipStream_t)stream;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (up_x == 1 && down_x == 2 && pad_x0 == 1 && in_w == 2 * a.out_w && pow2(a.out_w) && a.out_w >= 2 && pad_y0 >= 0) {
+      const int th = a.out_h < 48 ? 4 : 8, bh = (a.out_h + th - 1) / th, seg = a.out_w < 64 ? a.out_w : 64;
+      const long long nthreads = (long long)major * a.out_w * bh;
+      const unsigned grid = (unsigned)((nthreads + 255) / 256 < 131072 ? (nthreads + 255) / 256 : 131072);
+      if (th == 4) hipLaunchKernelGGL(upfirdn2d_down2_pairs_kernel<4>, dim3(grid), dim3(256), 0, st, a, bh, seg);
+      else hipLaunchKernelGGL(upfirdn2d_down2_pairs_kernel<8>, dim3(grid), dim3(256), 0, st, a, bh, seg);
+      return CIPS_CHECK_LAUNCH();
+    }
+    if (up_x == 2 && down_x == 1 && pad_x0 == 2 && pad_y0 == 2 && a.out_w == 2 * in_w && pow2(in_w) && in_w >= 2 && a.out_h <= 2 * in_h) {
+      const int tu = in_h < 24 ? 2 : 4, bh = (in_h + tu - 1) / tu, seg = in_w < 64 ? in_w : 64;
+      const long long nthreads = (long long)major * in_w * bh;
+      const unsigned grid = (unsigned)((nthreads + 255) / 256 < 131072 ? (nthreads + 255) / 256 : 131072);
+      if (tu == 2) hipLaunchKernelGGL(upfirdn2d_up2_pairs_kernel<2>, dim3(grid), dim3(256), 0, st, a, bh, seg);
+      else hipLaunchKernelGGL(upfirdn2d_up2_pairs_kernel<4>, dim3(grid), dim3(256), 0, st, a, bh, seg);
+      return CIPS_CHECK_LAUNCH();
+    }
     if (up_x == 1 && (down_x == 1 || down_x == 2)) {
       // thread tile: 1 x 16 outputs with the lanes along x (fully coalesced loads; the 4 x 4 tile of round 2 put neighbouring
       // lanes 16 B apart and moved 12.5x the output bytes through the texture path), 1 x 8 on short planes (fewer wasted rows)
