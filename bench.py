@@ -144,7 +144,7 @@ def gemm_roofline(dev, b, n, mode):
                  "algorithmic bytes / time / 8 TB/s"}
     # HBM bytes per launch of the forward flavour from the PMC counters, collected in their own rocprofv3 --pmc passes
     # (scripts/pmc_roofline.sh -> profiles/r2_roofline_pmc.json, r1 as fallback); null if absent
-    for f in ("r5_roofline_pmc.json", "r4_roofline_pmc.json", "r3_roofline_pmc.json", "r2_roofline_pmc.json", "r1_roofline_pmc.json"):
+    for f in ("r6_roofline_pmc.json", "r5_roofline_pmc.json", "r4_roofline_pmc.json", "r3_roofline_pmc.json", "r2_roofline_pmc.json", "r1_roofline_pmc.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", f)))
             if b == 32 and n == 4096:
