@@ -863,7 +863,9 @@ extern "C" int cips_conv2d_x3_dgrad_s2(const cips_conv_dgrad_s2_desc* c, cips_st
       ConvPart& cp = g.part[np++];
       cp.kw = Tb; cp.pad_y = Ta - 1; cp.pad_x = Tb - 1; cp.Wo = Ws;
       const int np_img = (Hs * Ws + 7) & ~7;
-      const bool fold = np_img < BN && c->B > 1;       // small planes: the batch folded into the pixel dimension
+      // the batch folded into the pixel dimension whenever a plane does not fill whole 256-pixel tiles (33 x 33 -> 1 096 pixels: 5 tiles
+      // per image hold 1 280, folded 32 images take 137 tiles instead of 160; 17 x 17: 37 instead of 64)
+      const bool fold = c->B > 1 && (np_img % BN) != 0;
       cp.nimg = fold ? np_img : 0;
       cp.N = fold ? np_img * c->B : np_img;
       cp.K = Ta * Tb * c->O; cp.lda = cp.K;
