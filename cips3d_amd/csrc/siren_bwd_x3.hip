@@ -37,6 +37,13 @@
 #include "raygen.h"
 #include <type_traits>
 
+// wave priority of the forward chain's MFMA phases (probe builds: -DCIPS_X3_PRIO)
+#ifdef CIPS_X3_PRIO
+#define X3_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define X3_PRIO(p)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -543,6 +550,7 @@ __device__ __forceinline__ void stage_weights_x3(uchar* sm, const cips_siren_wei
 #endif
 
 #include "siren_bwd_x4.inc"
+#define X3F_TS(i)
 
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -630,9 +638,22 @@ struct MarchArgs {
   int B, rays_per_wg;
   const unsigned char* clamp_pin;   // optional branch masks of the relu clamp (cips_march_fwd_x3's clamp_in / clamp_out):
   unsigned char* clamp_rec;         // branch per (ray, sample) supplied / recorded; both NULL in production
+  int desync;                       // probe builds: shader cycles the second wave of every SIMD starts late (0 = together)
+  int one_wave;                     // probe builds: waves 4-7 leave at once (one wave per SIMD; half the rays are not marched)
+  unsigned long long* prof;         // probe builds: phase timestamps of workgroup (0,0), samples 8..11
 };
 
 
+#undef X3F_TS
+#ifdef CIPS_TUNING
+#define X3F_TS(i)                                                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                               \
+  if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && lane0 == 0 && (s >> 2) == 2)                 \
+    a.prof[(((s & 3) * 8 + wave) * 8) + (i)] = __builtin_amdgcn_s_memtime();                       \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define X3F_TS(i)
+#endif
 template <bool HW, bool DBG, bool F16>
 __global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
   extern __shared__ __attribute__((aligned(1024))) uchar smem[];
@@ -650,6 +671,11 @@ __global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
   const float* M = g.c2w + (long long)b * 16;
   const float* bfv = reinterpret_cast<const float*>(smem + O_AUX);
   const float isf = F16 ? bfv[32] : 1.f;        // 2^-k of the colour head's weight image
+  if (CIPS_TUNE(a.one_wave) && wave >= 4) return;
+  if (CIPS_TUNE(a.desync) > 0 && wave >= 4) {
+    const long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (long long)a.desync) __builtin_amdgcn_s_sleep(8);
+  }
   for (int rbase = cstart + wave * 32; rbase < cend; rbase += 8 * 32) {
     const int l31s = lane0 & 31, hfs = lane0 >> 5;
     const int ray_raw = rbase + l31s;
@@ -724,6 +750,7 @@ __global__ __launch_bounds__(512) void siren_march_x3_kernel(MarchArgs a) {
         }
       }
       wx = nx; wy = ny; wz = nz; zs = zn;
+      X3F_TS(7)
       __builtin_amdgcn_sched_barrier(0);
     }
     if (a.flags & 1) {           // last_back: weights[:, :, -1] += 1 - weights_sum (pigan_utils.py:261-263)
@@ -979,6 +1006,13 @@ static int siren_fwd_x3_launch(const cips_siren_weights* w, const float* points,
   return CIPS_CHECK_LAUNCH();
 }
 
+#ifdef CIPS_TUNING
+static unsigned long long* g_mprof = nullptr;
+extern "C" int cips_march_x3_prof(unsigned long long* host_out) {       // tuning aid: copies the 4x8x8 timestamps
+  if (!g_mprof) return (int)hipErrorNotReady;
+  return (int)hipMemcpy(host_out, g_mprof, 4 * 8 * 8 * 8, hipMemcpyDeviceToHost);
+}
+#endif
 extern "C" int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_params* rays, const float* noise,
                                  float noise_std, int clamp_mode, int flags, float* fea, float* depth, float* weights,
                                  float* feat, float* sigma, float* z, int B, const unsigned char* clamp_in,
@@ -991,6 +1025,15 @@ extern "C" int cips_march_fwd_x3(const cips_siren_weights* w, const cips_ray_par
   a.noise = noise; a.noise_std = noise_std; a.clamp_mode = clamp_mode; a.flags = flags;
   a.fea = fea; a.depth = depth; a.weights = weights; a.feat = feat; a.sigma = sigma; a.zout = z; a.B = B;
   a.clamp_pin = clamp_in; a.clamp_rec = clamp_out;
+  a.desync = 0; a.one_wave = 0; a.prof = nullptr;
+#ifdef CIPS_TUNING
+  a.desync = cips_tune_env("CIPS_X3_MDESYNC", 0);
+  a.one_wave = cips_tune_env("CIPS_X3_MONE", 0);
+  if (cips_tune_env("CIPS_X3_MPROF", 0)) {
+    if (!g_mprof && hipMalloc(&g_mprof, 4 * 8 * 8 * 8) != hipSuccess) g_mprof = nullptr;
+    a.prof = g_mprof;
+  }
+#endif
   // a workgroup's 8 waves take 32 rays each: 256-ray chunks keep all of them busy; halve only for small images
   a.rays_per_wg = 256;
   const int n = a.rg.n;
