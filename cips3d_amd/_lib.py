@@ -159,6 +159,8 @@ SIGNATURES = {
     "cips_modfc_max_jobs": (i32, []),
     "cips_modfc_prep_x3_batch": (i32, [C.POINTER(ModfcPrepJob), i32, i32, C.c_float, vp]),
     "cips_modfc_prep_bwd_batch": (i32, [C.POINTER(ModfcBwdJob), i32, i32, vp]),
+    "cips_modfc_prep_bwd_batch_cores": (i32, [C.POINTER(ModfcBwdJob), i32, i32, vp]),
+    "cips_cores_colsum_parts": (i32, []),
     "cips_opt_chunk": (i32, []),
     "cips_opt_step": (i32, [vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]),
     "cips_camera_pose": (i32, [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, i32, vp]),
@@ -173,6 +175,7 @@ SIGNATURES = {
     "cips_torgb_bwd_w": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
     "cips_torgb_bwd_x": (i32, [vp, vp, vp, vp, f32, vp, vp, i64, i32, vp]),
     "cips_torgb_bwd_w_x3_batch": (i32, [vp, vp, i32, vp, vp, vp, vp, i64, i32, vp]),
+    "cips_torgb_bwd_w_x3_batch_cores": (i32, [vp, vp, i32, vp, vp, vp, vp, i64, i32, vp]),
     "cips_torgb_bwd_x_x3": (i32, [vp, vp, vp, f32, vp, vp, vp, i64, i32, vp]),
     "cips_fused_bias_act": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, vp]),
     "cips_diffaug": (i32, [vp] * 10 + [i32] * 8 + [vp]),

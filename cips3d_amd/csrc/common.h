@@ -27,6 +27,18 @@ static inline int cips_current_device() { int d = 0; (void)hipGetDevice(&d); ret
   do { static int cips_dev_ = -1; const int cips_d_ = cips_current_device();             \
        if (cips_d_ != cips_dev_) { flag = zero; cips_dev_ = cips_d_; } } while (0)
 
+// wave-wide sum without LDS or index registers: DPP row / bank steps in a fixed order, the total read from lane 63
+#define CIPS_DPP_ADD(v, ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  CIPS_DPP_ADD(v, 0xB1, 0xF);       // quad_perm [1,0,3,2]
+  CIPS_DPP_ADD(v, 0x4E, 0xF);       // quad_perm [2,3,0,1]
+  CIPS_DPP_ADD(v, 0x141, 0xF);      // row_half_mirror
+  CIPS_DPP_ADD(v, 0x140, 0xF);      // row_mirror: every lane of a row holds the row's sum
+  CIPS_DPP_ADD(v, 0x142, 0xA);      // row_bcast:15 into rows 1 and 3
+  CIPS_DPP_ADD(v, 0x143, 0xC);      // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

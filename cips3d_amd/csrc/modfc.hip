@@ -819,6 +819,175 @@ __global__ __launch_bounds__(256) void modfc_prep_bwd_ws_batch_kernel(BwdJobs J,
   if (lane < B) J.ds[job][(long long)lane * in_dim + k] = dsv;
 }
 
+
+// ---- co-resident forms (round 6) ----------------------------------------------------------------------------------
+// The fused SIREN backward holds every CU for 2.4 ms with the whole LDS (160 KiB) and 472 of the 512 registers of each SIMD
+// lane: a kernel that uses NO LDS and at most 40 VGPRs still gets a wave slot beside it (profiles/r6_coresidency_probe.txt:
+// LDS-free launches on a side stream complete at their usual latency while it runs, LDS users wait for it to end).  The
+// style / ToRGB weight-gradient tail of the INR head's backward depends on nothing the SIREN backward produces, so these
+// forms of its three streaming kernels let it run underneath: one wave per work item, reductions by shuffles and by
+// fixed-order partial sums in HBM, few loads in flight per wave (the waves are many).
+// loads addressed as SGPR base + 32-bit VGPR byte offset, issued by hand: hipcc otherwise carries one 64-bit VGPR address per load
+// stream through these loops and the kernels leave the 40-register budget.  The caller waits with cores_wait().
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f4v cores_ld16(const void* base, unsigned voff) {
+  f4v r;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(base) : "memory");
+  return r;
+}
+__device__ __forceinline__ u2v cores_ld8(const void* base, unsigned voff) {
+  u2v r;
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(base) : "memory");
+  return r;
+}
+
+constexpr int CS_KS = 4;                 // row segments of the column sums: cbuf holds CS_KS partial planes (CS_KS, B, out)
+
+__global__ __launch_bounds__(64) void modfc_colsum4_cores_kernel(ColJobs J, int B) {
+  const int job = blockIdx.z / CS_KS, seg = blockIdx.z % CS_KS, b = blockIdx.y;
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  const int n = blockIdx.x * 256 + 4 * threadIdx.x;
+  if (n >= out_dim) return;
+  const int k0 = (int)((long long)in_dim * seg / CS_KS), k1 = (int)((long long)in_dim * (seg + 1) / CS_KS);
+  const float* __restrict__ W = J.W[job] + n;
+  const float* __restrict__ sb = J.s[job] + (long long)b * in_dim;
+  const float* __restrict__ Gb = J.G[job] + (long long)b * in_dim * out_dim + n;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+  for (int k = k0; k < k1; ++k) {
+    const float4 w = *reinterpret_cast<const float4*>(W + (long long)k * out_dim);
+    const float4 g = *reinterpret_cast<const float4*>(Gb + (long long)k * out_dim);
+    const float m = sb[k] + 1.f;
+    q.x = fmaf(g.x, w.x * m, q.x); q.y = fmaf(g.y, w.y * m, q.y); q.z = fmaf(g.z, w.z * m, q.z); q.w = fmaf(g.w, w.w * m, q.w);
+  }
+  *reinterpret_cast<float4*>(J.out[job] + ((long long)seg * B + b) * out_dim + n) = q;
+}
+
+// cbuf plane 0 += planes 1 .. CS_KS-1 (fixed order): the column sums the next kernel reads
+__global__ __launch_bounds__(256) void modfc_colsum_fold_cores_kernel(ColJobs J, int B) {
+  const int job = blockIdx.y;
+  const int n4 = B * J.out_dim[job] / 4;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4* c = reinterpret_cast<float4*>(J.out[job]);
+  float4 a = c[i];
+#pragma unroll
+  for (int j = 1; j < CS_KS; ++j) { const float4 t = c[j * n4 + i]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+  c[i] = a;
+}
+
+// one wave per weight row k, one 256-column chunk at a time (registers are reused from chunk to chunk; lane b keeps ds[b][k]);
+// uniform base pointers + one per-lane offset, so the loads address as SGPR base + VGPR offset
+__global__ __launch_bounds__(256) void modfc_prep_bwd_ws_cores_kernel(BwdJobs J, int B) {
+  const int job = blockIdx.y;
+  const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (k >= in_dim) return;
+  const float* __restrict__ s = J.s[job] + k;
+  const int gstep = in_dim * out_dim;
+  float dsv = 0.f;
+#pragma unroll 1
+  for (int c0 = 0; c0 < out_dim; c0 += 256) {
+    const bool ok = c0 + 4 * lane < out_dim;
+    const float4* __restrict__ Wp = reinterpret_cast<const float4*>(J.W[job] + k * out_dim + c0);
+    const float4* __restrict__ Gp = reinterpret_cast<const float4*>(J.G[job] + k * out_dim + c0);
+    const float4* __restrict__ Dp = reinterpret_cast<const float4*>(J.demod[job] + c0);
+    const float4* __restrict__ Cp = reinterpret_cast<const float4*>(J.cbuf[job] + c0);
+    const float4 w = ok ? Wp[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned voff = ok ? 16u * lane : 0u;           // lanes past the row's end read (and discard) its first columns
+#pragma unroll 1
+    for (int b = 0; b < B; ++b) {
+      const float m = s[b * in_dim] + 1.f;
+      f4v g = cores_ld16(Gp, voff), d = cores_ld16(Dp, voff), cb = cores_ld16(Cp, voff);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(g), "+v"(d), "+v"(cb) :: "memory");
+      const float dx = d.x * (g.x - d.x * d.x * (w.x * m) * cb.x), dy = d.y * (g.y - d.y * d.y * (w.y * m) * cb.y);
+      const float dz = d.z * (g.z - d.z * d.z * (w.z * m) * cb.z), dw = d.w * (g.w - d.w * d.w * (w.w * m) * cb.w);
+      float part = 0.f;
+      if (ok) {
+        acc.x = fmaf(m, dx, acc.x); acc.y = fmaf(m, dy, acc.y); acc.z = fmaf(m, dz, acc.z); acc.w = fmaf(m, dw, acc.w);
+        part = fmaf(w.x, dx, part); part = fmaf(w.y, dy, part); part = fmaf(w.z, dz, part); part = fmaf(w.w, dw, part);
+      }
+      Gp += gstep / 4; Dp += out_dim / 4; Cp += out_dim / 4;
+      const float tot = wave_sum_dpp(part);
+      if (lane == b) dsv += tot;
+    }
+    if (ok) reinterpret_cast<float4*>(J.dW[job] + k * out_dim + c0)[lane] = acc;
+  }
+  if (lane < B) J.ds[job][lane * in_dim + k] = dsv;
+}
+
+// ToRGB weight gradient, K = 512: a wave owns one 128-row chunk and one half of the 512 columns (4 per lane), rows in order,
+// two in flight; drgb through scalar loads.  Same partial layout as torgb_bwd_w_partial_x3_k512_kernel.
+__global__ __launch_bounds__(256) void torgb_bwd_w_partial_cores_kernel(TorgbJobs J, const float* __restrict__ drgb,
+                                                                        float* __restrict__ partial, long long M, int chunks) {
+  constexpr int K = 512;
+  const u16* __restrict__ xh = J.xh[blockIdx.y];
+  const u16* __restrict__ xl = J.xl[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int chunk = blockIdx.x * 2 + (wave >> 1);
+  if (chunk >= chunks) return;
+  const int kk = (wave & 1) * 256 + lane * 4;
+  const long long m0 = (long long)chunk * TORGB_ROWS;
+  const long long m1 = (m0 + TORGB_ROWS < M) ? m0 + TORGB_ROWS : M;
+  float acc[3][4];
+  float gs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[c][q] = 0.f;
+#pragma unroll 1
+  for (long long m = m0; m < m1; m += 2) {
+    const bool two = m + 1 < m1;
+    const long long mb = two ? m + 1 : m;
+    u2v ha = cores_ld8(xh + m * K, 2u * kk), la = cores_ld8(xl + m * K, 2u * kk);
+    u2v hb = cores_ld8(xh + mb * K, 2u * kk), lb = cores_ld8(xl + mb * K, 2u * kk);
+    float ga[3], gb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { ga[c] = drgb[m * 3 + c]; gb[c] = two ? drgb[mb * 3 + c] : 0.f; }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ha), "+v"(la), "+v"(hb), "+v"(lb) :: "memory");
+    const float va[4] = {__uint_as_float(ha.x << 16) + __uint_as_float(la.x << 16), __uint_as_float(ha.x & 0xffff0000u) + __uint_as_float(la.x & 0xffff0000u),
+                         __uint_as_float(ha.y << 16) + __uint_as_float(la.y << 16), __uint_as_float(ha.y & 0xffff0000u) + __uint_as_float(la.y & 0xffff0000u)};
+    const float vb[4] = {__uint_as_float(hb.x << 16) + __uint_as_float(lb.x << 16), __uint_as_float(hb.x & 0xffff0000u) + __uint_as_float(lb.x & 0xffff0000u),
+                         __uint_as_float(hb.y << 16) + __uint_as_float(lb.y << 16), __uint_as_float(hb.y & 0xffff0000u) + __uint_as_float(lb.y & 0xffff0000u)};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      gs[c] += ga[c]; gs[c] += gb[c];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[c][q] = fmaf(gb[c], vb[q], fmaf(ga[c], va[q], acc[c][q]));
+    }
+  }
+  float* out = partial + ((long long)blockIdx.y * chunks + chunk) * 4 * K;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    *reinterpret_cast<float4*>(out + c * K + kk) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+    if (kk == 0) out[3 * K + c] = gs[c];
+  }
+}
+
+// partial (njobs, chunks, 4, K) -> dw (njobs, 3, K), dbias (njobs, 3): a wave owns 4 consecutive entries, its lanes take the
+// chunks lane, lane + 64, ... in order and are combined by a shuffle tree (fixed order)
+__global__ __launch_bounds__(64) void torgb_bwd_w_reduce_cores_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                      float* __restrict__ dbias, int chunks, int K) {
+  const int idx = blockIdx.x * 4;                         // 0 .. 3K (+3 bias sums): 3K is a multiple of 4
+  partial += (long long)blockIdx.y * chunks * 4 * K;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ch = threadIdx.x; ch < chunks; ch += 64) {
+    const float4 t = *reinterpret_cast<const float4*>(partial + (long long)ch * 4 * K + idx);
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    a.x += __shfl_xor(a.x, off); a.y += __shfl_xor(a.y, off); a.z += __shfl_xor(a.z, off); a.w += __shfl_xor(a.w, off);
+  }
+  if (threadIdx.x == 0) {
+    if (idx < 3 * K) *reinterpret_cast<float4*>(dw + (long long)blockIdx.y * 3 * K + idx) = a;
+    else { float* o = dbias + blockIdx.y * 3; o[0] = a.x; o[1] = a.y; o[2] = a.z; }
+  }
+}
+
 }  // namespace
 
 extern "C" int cips_modfc_prep(const float* weight, const float* s, float* wb, float* wbt, float* demod,
@@ -958,6 +1127,50 @@ extern "C" int cips_torgb_bwd_w_x3_batch(const void* const* x_hi, const void* co
   hipLaunchKernelGGL(torgb_bwd_w_reduce_kernel, dim3((3 * K + 3 + 7) / 8, njobs), dim3(256), 0, st, partials, dw, dbias, chunks, K);
   return CIPS_CHECK_LAUNCH();
 }
+
+extern "C" int cips_cores_colsum_parts(void) { return CS_KS; }
+
+// co-resident form of cips_modfc_prep_bwd_batch (no LDS, <= 40 VGPRs: see the kernels): cbuf is (cips_cores_colsum_parts(), B, out)
+extern "C" int cips_modfc_prep_bwd_batch_cores(const cips_modfc_bwd_job* jobs, int njobs, int B, cips_stream_t stream) {
+  if (!jobs || njobs <= 0 || njobs > MAXJOBS || B <= 0) return (int)hipErrorInvalidValue;
+  if (B > 64) return (int)hipErrorNotSupported;
+  BwdJobs J;
+  ColJobs Cj = {};
+  int max_in = 0, max_out = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const cips_modfc_bwd_job& j = jobs[i];
+    if (j.in_dim <= 0 || j.out_dim <= 0) return (int)hipErrorInvalidValue;
+    if (j.out_dim % 4) return (int)hipErrorNotSupported;
+    J.W[i] = j.weight; J.s[i] = j.s; J.demod[i] = j.demod; J.G[i] = j.gwb;
+    J.cbuf[i] = j.cbuf; J.dW[i] = j.dweight; J.ds[i] = j.ds;
+    J.in_dim[i] = j.in_dim; J.out_dim[i] = j.out_dim;
+    Cj.W[i] = j.weight; Cj.s[i] = j.s; Cj.G[i] = j.gwb; Cj.out[i] = j.cbuf; Cj.in_dim[i] = j.in_dim; Cj.out_dim[i] = j.out_dim;
+    max_in = j.in_dim > max_in ? j.in_dim : max_in; max_out = j.out_dim > max_out ? j.out_dim : max_out;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(modfc_colsum4_cores_kernel, dim3((max_out + 255) / 256, B, njobs * CS_KS), dim3(64), 0, st, Cj, B);
+  hipLaunchKernelGGL(modfc_colsum_fold_cores_kernel, dim3((B * max_out / 4 + 255) / 256, njobs), dim3(256), 0, st, Cj, B);
+  hipLaunchKernelGGL(modfc_prep_bwd_ws_cores_kernel, dim3((max_in + 3) / 4, njobs), dim3(256), 0, st, J, B);
+  return CIPS_CHECK_LAUNCH();
+}
+
+// co-resident form of cips_torgb_bwd_w_x3_batch: same arguments, layouts and partial scratch
+extern "C" int cips_torgb_bwd_w_x3_batch_cores(const void* const* x_hi, const void* const* x_lo, int njobs, const float* drgb,
+                                               float* partials, float* dw, float* dbias, long long M, int K, cips_stream_t stream) {
+  if (!x_hi || !x_lo || njobs <= 0 || M <= 0) return (int)hipErrorInvalidValue;
+  if (njobs > TORGB_MAXJOBS || K != 512) return (int)hipErrorNotSupported;
+  TorgbJobs J = {};
+  for (int i = 0; i < njobs; ++i) {
+    if (!x_hi[i] || !x_lo[i]) return (int)hipErrorInvalidValue;
+    J.xh[i] = (const u16*)x_hi[i]; J.xl[i] = (const u16*)x_lo[i];
+  }
+  const int chunks = cips_torgb_bwd_partials(M);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(torgb_bwd_w_partial_cores_kernel, dim3((chunks + 1) / 2, njobs), dim3(256), 0, st, J, drgb, partials, M, chunks);
+  hipLaunchKernelGGL(torgb_bwd_w_reduce_cores_kernel, dim3((3 * K + 4) / 4, njobs), dim3(64), 0, st, partials, dw, dbias, chunks, K);
+  return CIPS_CHECK_LAUNCH();
+}
+
 
 extern "C" int cips_torgb_bwd_x(const float* drgb, const float* w, const float* add, const float* mask,
                                 float slope, float* out_unmasked, float* out, long long M, int K,

@@ -109,40 +109,32 @@ __global__ __launch_bounds__(256) void glin_fwd_kernel(GLJobs J, int B, int opw)
   }
 }
 
-// dw[o][i] = sum_b dy[b][o] x[b][i];  db[o] = sum_b dy[b][o].  Thread = one 16-byte column group of x, held in
-// registers for 32 batch rows at a time; the workgroup's dy tile (32 rows x 16 outputs) sits in LDS and is read as
-// broadcasts; 16 outputs per workgroup.
-template <int OT>      // outputs per workgroup: 16, or 4 when the launch would otherwise have too few workgroups
+// dw[o][i] = sum_b dy[b][o] x[b][i];  db[o] = sum_b dy[b][o].  Thread = one 16-byte column group of x; the workgroup's 4 outputs
+// share every x row it reads; dy[b][o] is uniform over the workgroup and comes through scalar loads.  No LDS and a small register
+// footprint on purpose (round 6): the mapping networks' backward runs on a side stream next to the fused SIREN backward, which
+// owns the whole LDS of every CU — a kernel like this one still finds a wave slot beside it (see modfc.hip, co-resident forms).
+template <int OT>      // outputs per workgroup
 __global__ __launch_bounds__(128) void glin_bwd_w_kernel(GLJobs J, int B) {
-  __shared__ float dys[GL_ROWS][OT];
   const int job = find_job(J, blockIdx.x);
   const int in_dim = J.in_dim[job], out_dim = J.out_dim[job];
   const int o0 = (blockIdx.x - J.tile0[job]) * OT;
   const float* __restrict__ x = J.x[job];
-  const float* __restrict__ dy = J.dy[job];
+  const float* __restrict__ dy = J.dy[job] + o0;
   const int i4 = threadIdx.x;                                       // in_dim / 4 <= 128
   const bool on = i4 < in_dim / 4;
   float4 acc[OT];
   float sb[OT];
 #pragma unroll
   for (int oo = 0; oo < OT; ++oo) { acc[oo] = make_float4(0.f, 0.f, 0.f, 0.f); sb[oo] = 0.f; }
-  for (int b0 = 0; b0 < B; b0 += GL_ROWS) {
-    const int nb = min(GL_ROWS, B - b0);
-    __syncthreads();
-    for (int e = threadIdx.x; e < GL_ROWS * OT; e += 128) {
-      const int r = e / OT, oo = e % OT;
-      dys[r][oo] = (r < nb && o0 + oo < out_dim) ? dy[(long long)(b0 + r) * out_dim + o0 + oo] : 0.f;
-    }
-    __syncthreads();
-    for (int r = 0; r < nb; ++r) {                                  // (dys rows >= nb are zero; x rows are only read below nb)
-      const float4 xv = on ? reinterpret_cast<const float4*>(x + (long long)(b0 + r) * in_dim)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+  for (int b = 0; b < B; ++b) {
+    const float4 xv = on ? reinterpret_cast<const float4*>(x + (long long)b * in_dim)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int oo = 0; oo < OT; ++oo) {
-        const float g = dys[r][oo];
-        sb[oo] += g;
-        acc[oo].x = fmaf(g, xv.x, acc[oo].x); acc[oo].y = fmaf(g, xv.y, acc[oo].y);
-        acc[oo].z = fmaf(g, xv.z, acc[oo].z); acc[oo].w = fmaf(g, xv.w, acc[oo].w);
-      }
+    for (int oo = 0; oo < OT; ++oo) {
+      const float g = (o0 + oo < out_dim) ? dy[(long long)b * out_dim + oo] : 0.f;
+      sb[oo] += g;
+      acc[oo].x = fmaf(g, xv.x, acc[oo].x); acc[oo].y = fmaf(g, xv.y, acc[oo].y);
+      acc[oo].z = fmaf(g, xv.z, acc[oo].z); acc[oo].w = fmaf(g, xv.w, acc[oo].w);
     }
   }
 #pragma unroll
@@ -155,50 +147,38 @@ __global__ __launch_bounds__(128) void glin_bwd_w_kernel(GLJobs J, int B) {
   }
 }
 
-// dx partials: part[chunk][b][i] = sum over the chunk's (job, o) pairs of dy[b][o] w[o][i]; chunk = 64 outputs of one
-// job; thread = 4 consecutive i, 32 batch rows in registers, the chunk's dy tile (32 x 64) in LDS (broadcast reads of 4
-// outputs at a time).  All jobs of a launch share x (same in_dim).
+// dx partials: part[chunk][b][i] = sum over the chunk's (job, o) pairs of dy[b][o] w[o][i]; chunk = OC outputs of one job.
+// Workgroup = (chunk, group of 4 batch rows): thread = 4 consecutive i, 4 rows in registers, dy through scalar loads, the chunk's
+// weight rows streamed once per row group (L2).  All jobs of a launch share x (same in_dim).  No LDS (see glin_bwd_w_kernel).
+constexpr int GLX_ROWS = 4;
 template <int OC>      // outputs per chunk: 64, or 16 for launches of few chunks
 __global__ __launch_bounds__(128) void glin_bwd_x_kernel(GLJobs J, int B, int in_dim, float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float dys[GL_ROWS][OC];
   const int job = find_job(J, blockIdx.x);
   const int out_dim = J.out_dim[job];
   const int o0 = (blockIdx.x - J.tile0[job]) * OC;
-  const float* __restrict__ w = J.w[job];
-  const float* __restrict__ dy = J.dy[job];
+  const int b0 = blockIdx.y * GLX_ROWS;
+  const float* __restrict__ w = J.w[job] + (long long)o0 * in_dim;
+  const float* __restrict__ dy = J.dy[job] + o0;
   const int i4 = threadIdx.x;
   const bool on = i4 < in_dim / 4;
-  for (int b0 = 0; b0 < B; b0 += GL_ROWS) {
-    const int nb = min(GL_ROWS, B - b0);
-    __syncthreads();
-    for (int e = threadIdx.x; e < GL_ROWS * OC; e += 128) {
-      const int r = e / OC, oo = e % OC;
-      dys[r][oo] = (r < nb && o0 + oo < out_dim) ? dy[(long long)(b0 + r) * out_dim + o0 + oo] : 0.f;
+  float4 acc[GLX_ROWS];
+#pragma unroll
+  for (int r = 0; r < GLX_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int oend = min(OC, out_dim - o0);
+#pragma unroll 2
+  for (int oo = 0; oo < oend; ++oo) {
+    const float4 wv = on ? reinterpret_cast<const float4*>(w + (long long)oo * in_dim)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < GLX_ROWS; ++r) {
+      const float g = (b0 + r < B) ? dy[(long long)(b0 + r) * out_dim + oo] : 0.f;
+      acc[r].x = fmaf(g, wv.x, acc[r].x); acc[r].y = fmaf(g, wv.y, acc[r].y);
+      acc[r].z = fmaf(g, wv.z, acc[r].z); acc[r].w = fmaf(g, wv.w, acc[r].w);
     }
-    __syncthreads();
-    float4 acc[GL_ROWS];
+  }
+  if (on) {
 #pragma unroll
-    for (int r = 0; r < GL_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int oend = min(OC, out_dim - o0);
-    for (int oo = 0; oo < oend; oo += 4) {
-      float4 wv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        wv[q] = (on && oo + q < oend) ? reinterpret_cast<const float4*>(w + (long long)(o0 + oo + q) * in_dim)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int r = 0; r < GL_ROWS; ++r) {
-        const float4 g = *reinterpret_cast<const float4*>(&dys[r][oo]);
-        acc[r].x = fmaf(g.x, wv[0].x, fmaf(g.y, wv[1].x, fmaf(g.z, wv[2].x, fmaf(g.w, wv[3].x, acc[r].x))));
-        acc[r].y = fmaf(g.x, wv[0].y, fmaf(g.y, wv[1].y, fmaf(g.z, wv[2].y, fmaf(g.w, wv[3].y, acc[r].y))));
-        acc[r].z = fmaf(g.x, wv[0].z, fmaf(g.y, wv[1].z, fmaf(g.z, wv[2].z, fmaf(g.w, wv[3].z, acc[r].z))));
-        acc[r].w = fmaf(g.x, wv[0].w, fmaf(g.y, wv[1].w, fmaf(g.z, wv[2].w, fmaf(g.w, wv[3].w, acc[r].w))));
-      }
-    }
-    if (on) {
-#pragma unroll
-      for (int r = 0; r < GL_ROWS; ++r)                             // (constant indices: acc stays in registers)
-        if (r < nb) reinterpret_cast<float4*>(part + ((long long)blockIdx.x * B + b0 + r) * in_dim)[i4] = acc[r];
-    }
+    for (int r = 0; r < GLX_ROWS; ++r)
+      if (b0 + r < B) reinterpret_cast<float4*>(part + ((long long)blockIdx.x * B + b0 + r) * in_dim)[i4] = acc[r];
   }
 }
 
@@ -293,58 +273,47 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restric
     if (t + 256 * q < cols) y[(long long)row * cols + t + 256 * q] = out[q];
 }
 
-// dx for one row; dyhat (rows, cols) = dL/d(gamma * xhat + beta) is written for the column reductions of d gamma / d beta
-__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ yout,
-                                                          const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                          const float* __restrict__ dy, float* __restrict__ dx,
-                                                          float* __restrict__ dyhat, int cols, int mode, float slope) {
-  __shared__ float red[256];
+// dx for one row; dyhat (rows, cols) = dL/d(gamma * xhat + beta) is written for the column reductions of d gamma / d beta.
+// One WAVE per row, two passes over the row (the second one re-reads it from L2), reductions by DPP: no LDS, ~20 registers
+// (see glin_bwd_w_kernel for why).
+__global__ __launch_bounds__(64) void rownorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ yout,
+                                                         const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                         const float* __restrict__ dy, float* __restrict__ dx,
+                                                         float* __restrict__ dyhat, int cols, int mode, float slope) {
   const int row = blockIdx.x, t = threadIdx.x;
   const long long base = (long long)row * cols;
-  float xv[RN_MAXC / 256], g[RN_MAXC / 256];
-#pragma unroll
-  for (int q = 0; q < RN_MAXC / 256; ++q) {
-    const int c = t + 256 * q;
-    const bool ok = c < cols;
-    xv[q] = ok ? x[base + c] : 0.f;
-    float gg = ok ? dy[base + c] : 0.f;
-    if ((mode & 2) && ok) gg *= (yout[base + c] > 0.f) ? 1.f : slope;      // gate from the stored output (same sign)
-    g[q] = gg;
-  }
+  auto gate = [&](int c) {                      // upstream gradient through the activation (gate from the stored output: same sign)
+    float gg = dy[base + c];
+    if (mode & 2) gg *= (yout[base + c] > 0.f) ? 1.f : slope;
+    return gg;
+  };
   if (mode & 4) {                     // y = x r: dx = r (dy - y mean(dy y))
     const float r = stats[2 * row + 1];
     float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < RN_MAXC / 256; ++q) s = fmaf(g[q], xv[q] * r, s);
-    const float m = rn_block_sum(s, red) / (float)cols;
-#pragma unroll
-    for (int q = 0; q < RN_MAXC / 256; ++q)
-      if (t + 256 * q < cols) dx[base + t + 256 * q] = r * (g[q] - xv[q] * r * m);
+    for (int c = t; c < cols; c += 64) s = fmaf(gate(c), x[base + c] * r, s);
+    const float m = wave_sum_dpp(s) / (float)cols;
+    for (int c = t; c < cols; c += 64) dx[base + c] = r * (gate(c) - x[base + c] * r * m);
     return;
   }
   if (!(mode & 1)) {                  // activation only
-#pragma unroll
-    for (int q = 0; q < RN_MAXC / 256; ++q)
-      if (t + 256 * q < cols) dx[base + t + 256 * q] = g[q];
+    for (int c = t; c < cols; c += 64) dx[base + c] = gate(c);
     return;
   }
   const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-  float xh[RN_MAXC / 256], gx[RN_MAXC / 256], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int q = 0; q < RN_MAXC / 256; ++q) {
-    const int c = t + 256 * q;
-    const bool ok = c < cols;
-    xh[q] = ok ? (xv[q] - mean) * rstd : 0.f;
-    gx[q] = ok ? g[q] * gamma[c] : 0.f;
-    if (ok) dyhat[base + c] = g[q];
-    s1 += gx[q];
-    s2 = fmaf(gx[q], xh[q], s2);
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = t; c < cols; c += 64) {
+    const float g = gate(c);
+    const float gx = g * gamma[c];
+    dyhat[base + c] = g;
+    s1 += gx;
+    s2 = fmaf(gx, (x[base + c] - mean) * rstd, s2);
   }
-  const float m1 = rn_block_sum(s1, red) / (float)cols;
-  const float m2 = rn_block_sum(s2, red) / (float)cols;
-#pragma unroll
-  for (int q = 0; q < RN_MAXC / 256; ++q)
-    if (t + 256 * q < cols) dx[base + t + 256 * q] = rstd * (gx[q] - m1 - xh[q] * m2);
+  const float m1 = wave_sum_dpp(s1) / (float)cols;
+  const float m2 = wave_sum_dpp(s2) / (float)cols;
+  for (int c = t; c < cols; c += 64) {
+    const float gx = dyhat[base + c] * gamma[c];
+    dx[base + c] = rstd * (gx - m1 - (x[base + c] - mean) * rstd * m2);
+  }
 }
 
 // d gamma[c] = sum_rows dyhat * xhat, d beta[c] = sum_rows dyhat  (fixed order)
@@ -439,13 +408,9 @@ extern "C" int cips_grouped_linear_bwd(const cips_glin_job* jobs, int njobs, int
   if (rc) return rc;
   if (B <= 0) return (int)hipErrorInvalidValue;
   for (int j = 0; j < njobs; ++j) if (!jobs[j].dy || !jobs[j].dw) return (int)hipErrorInvalidValue;
-  if (J.tile0[njobs] < 128) {
-    rc = fill(J, jobs, njobs, 4);
-    if (rc) return rc;
-    hipLaunchKernelGGL(glin_bwd_w_kernel<4>, dim3(J.tile0[njobs]), dim3(128), 0, (hipStream_t)stream, J, B);
-  } else {
-    hipLaunchKernelGGL(glin_bwd_w_kernel<16>, dim3(J.tile0[njobs]), dim3(128), 0, (hipStream_t)stream, J, B);
-  }
+  rc = fill(J, jobs, njobs, 4);
+  if (rc) return rc;
+  hipLaunchKernelGGL(glin_bwd_w_kernel<4>, dim3(J.tile0[njobs]), dim3(128), 0, (hipStream_t)stream, J, B);
   if (dx) {
     const int in_dim = jobs[0].in_dim;
     for (int j = 1; j < njobs; ++j) if (jobs[j].in_dim != in_dim || jobs[j].x != jobs[0].x) return (int)hipErrorInvalidValue;
@@ -456,8 +421,9 @@ extern "C" int cips_grouped_linear_bwd(const cips_glin_job* jobs, int njobs, int
     if (fine) { rc = fill(K, jobs, njobs, 16); if (rc) return rc; }
     const int nchunks = K.tile0[njobs];
     if (!scratch || scratch_floats < (long long)nchunks * B * in_dim) return (int)hipErrorInvalidValue;
-    if (fine) hipLaunchKernelGGL(glin_bwd_x_kernel<16>, dim3(nchunks), dim3(128), 0, (hipStream_t)stream, K, B, in_dim, scratch);
-    else hipLaunchKernelGGL(glin_bwd_x_kernel<64>, dim3(nchunks), dim3(128), 0, (hipStream_t)stream, K, B, in_dim, scratch);
+    const dim3 gx(nchunks, (B + GLX_ROWS - 1) / GLX_ROWS);
+    if (fine) hipLaunchKernelGGL(glin_bwd_x_kernel<16>, gx, dim3(128), 0, (hipStream_t)stream, K, B, in_dim, scratch);
+    else hipLaunchKernelGGL(glin_bwd_x_kernel<64>, gx, dim3(128), 0, (hipStream_t)stream, K, B, in_dim, scratch);
     const long long n = (long long)B * in_dim;
     hipLaunchKernelGGL(glin_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch, dx, nchunks, n);
   }
@@ -489,7 +455,7 @@ extern "C" int cips_rownorm_bwd(const float* x, const float* y, const float* gam
   if (!x || !y || !stats || !dy || !dx || rows <= 0 || cols <= 0 || cols > RN_MAXC || ((mode & 4) && (mode & 3))) return (int)hipErrorInvalidValue;
   if ((mode & 1) && (!gamma || !dyhat || !dgamma || !dbeta)) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(rows), dim3(256), 0, st, x, y, gamma, stats, dy, dx, dyhat, cols, mode, slope);
+  hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(rows), dim3(64), 0, st, x, y, gamma, stats, dy, dx, dyhat, cols, mode, slope);
   if (mode & 1)
     hipLaunchKernelGGL(rownorm_bwd_affine_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, x, stats, dyhat, dgamma, dbeta, rows, cols);
   return CIPS_CHECK_LAUNCH();

@@ -343,17 +343,20 @@ class CIPSNet(nn.Module):
         self.tanh = nn.Sequential(nn.Tanh())
         self.module_name_list.append('tanh')
 
-    def forward(self, input, style_dict, img_size=1024, **kwargs):
+    def _names(self, img_size):
         img_size = str(2 ** int(np.log2(img_size)))
         names = []
         for name in self.network.keys():
             names.append(name)
             if name == img_size:
                 break
-        params = []
+        return names
+
+    def _build_params(self, names, style_dict):
         # s = SinStyleMod.modulation(style) of all 18 layers (mod_conv_fc.py:474) in one grouped launch
         mods = ops.grouped_linear([(style_dict[f'{self.network[name].name_prefix}_{j}'], m.modulation)
                                    for name in names for j, m in enumerate((self.network[name].mod1, self.network[name].mod2))])
+        params = []
         for k, name in enumerate(names):
             blk = self.network[name]
             # (1, in, out) -> (in, out) as a VIEW: indexing with [0] makes autograd materialise a zero-filled (1, in, out)
@@ -363,7 +366,49 @@ class CIPSNet(nn.Module):
         for idx, name in enumerate(names):
             if idx >= 3:
                 params += [self.to_rgbs[name].linear.weight, self.to_rgbs[name].linear.bias]
-        rgb = ops.inr_head(len(names), input, *params)
+        return mods, params
+
+    def open_tail_ports(self, style_dict, B, n, in0, img_size=1024, join=True):
+        """The head's weight-gradient tail behind gradient ports on the side stream (ops.INR_TAIL), opened for the NEXT forward()
+        with these styles and (B, n, in0) inputs.  Every autograd node between the ports and the parameters — the modulation
+        Linears, the weight views — is created under that stream as well (a node on the caller's stream that consumed a port's
+        output would make the caller's stream wait for the whole tail).  GeneratorNerfINR._render calls this BEFORE the ray march:
+        nodes created earlier run later in the backward pass, so the NeRF backward is issued first and the tail starts behind
+        its compositing kernel (ops._TAIL_GATE).  Returns True when ports are pending."""
+        self._tail = None
+        dev = next(self.parameters()).device
+        names = self._names(img_size)
+        if not (dev.type == "cuda" and B <= 64 and torch.is_grad_enabled() and ops.INR_TAIL == "side" and len(names) > 3):
+            return False
+        side = _side_stream(dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            mods, params = self._build_params(names, style_dict)
+        for t in mods:
+            t.record_stream(main)
+        ok = ops.inr_head_ports_ok(len(names), B, n, in0, params, dev)
+        ports = ops.inr_head_open_ports(len(names), B, n, params, side) if ok else None
+        if join:
+            main.wait_stream(side)
+        # (not ok: the modulation Linears are kept all the same — forward() takes its parameters from here)
+        self._tail = dict(key=(B, n, in0, len(names), id(style_dict)), params=params, ports=ports)
+        return True
+
+    def forward(self, input, style_dict, img_size=1024, **kwargs):
+        names = self._names(img_size)
+        tail, self._tail = getattr(self, "_tail", None), None
+        key = (input.shape[0], input.shape[1], input.shape[2], len(names), id(style_dict))
+        if tail is None and torch.is_grad_enabled() and input.is_cuda and self.open_tail_ports(style_dict, *key[:3], img_size=img_size):
+            tail, self._tail = self._tail, None          # not opened ahead (a direct call): open them now
+        if tail is not None and tail["key"] == key and torch.is_grad_enabled():
+            if tail["ports"] is not None:
+                rgb = ops.inr_head_with_ports(len(names), input, tail["params"], tail["ports"])
+            else:
+                rgb = ops.inr_head(len(names), input, *tail["params"])
+        else:
+            _, params = self._build_params(names, style_dict)
+            rgb = ops.inr_head(len(names), input, *params)
         return self.tanh(rgb)
 
 
@@ -607,6 +652,11 @@ class GeneratorNerfINR(nn.Module):
         part = grad_points is not None and grad_points < n
         if part:
             staged = False          # generator.py:1325-1347: part_grad_forward is not handed forward_points
+        if not part and not staged and torch.is_grad_enabled():
+            # the INR head's gradient ports, opened before the NeRF path so that its backward is issued first
+            # (CIPSNet.open_tail_ports); they sit on the INR mapping network's side stream, joined right before the head
+            if self.inr_net.open_tail_ports(style_dict, b, n, 32, join=False):
+                self._pending_side = _side_stream(device)
 
         # ---------------- random draws in reference order ----------------
         def draw(kind, fn, shape, override=True):

@@ -403,6 +403,7 @@ class CompositeFunction(torch.autograd.Function):
         check(lib.cips_composite_bwd(_p(feat_c), _p(sig_c), _p(z_c), _p(feat_f), _p(sig_f), _p(z_f), _p(noise),
                                      noise_std, _p(order), _p(dfea), _p(dfeat_c), _p(dsig_c), _p(dfeat_f),
                                      _p(dsig_f), R, S, clamp_mode, flags, _p(ctx.clamp_mask), _stream()), "cips_composite_bwd")
+        _tail_gate_publish(dfea.device)
         return dfeat_c, dsig_c, None, dfeat_f, dsig_f, None, None, None, None, None
 
 
@@ -660,6 +661,7 @@ class RayMarchFunction(torch.autograd.Function):
         check(lib.cips_composite_bwd(_p(feat), _p(sigma), _p(z), None, None, None, _p(noise), float(noise_std), None,
                                      _p(dfea), _p(dfeat), _p(dsig), None, None, R, S, clamp_mode, flags, _p(ctx.clamp_mask),
                                      _stream()), "cips_composite_bwd")
+        _tail_gate_publish(dfea.device)
         rp = _ray_params(xg, yg, zg, zc, cam2world, jitter, H, W, S)
         grads = _siren_backward(t, dfeat, dsig, B, n * S, rays=rp)
         return (None,) * 7 + grads
@@ -970,6 +972,11 @@ import os as _os
 INR_MODE = _os.environ.get("CIPS_INR_MODE", "bf16x3")   # "bf16x3" (default, ~1e-5 rel. per layer) or "f32" (exact fp32 MFMA)
 BF = torch.bfloat16
 INR_W_KMAJOR = True   # dW GEMMs read the row-major planes through LDS transpose reads (no transposed copies in HBM)
+# The head's weight-gradient tail (style / modulated-weight gradients of all layers, ToRGB weight gradients: ~0.75 ms of streaming
+# kernels at C2) depends on nothing that follows the head in the backward pass.  "side": it hangs off the head through two
+# gradient ports whose autograd nodes live on the generator's side stream, so it runs next to the compositing / SIREN backward
+# instead of in front of it (CIPSNet.forward; profiles/r6_cores_tail_probe.txt).  "main": everything inside InrHeadX3Function.
+INR_TAIL = _os.environ.get("CIPS_INR_TAIL", "side")
                                                                  # transpose reads: no transposed planes in HBM
 
 
@@ -1336,12 +1343,15 @@ def modfc_prep_x3_batch(layers, eps=1e-8):
     return out
 
 
-def modfc_prep_bwd_batch(layers):
-    """layers: list of (W, s, demod, gwb) -> list of (dW, ds), all layers in three launches."""
+def modfc_prep_bwd_batch(layers, cores=False):
+    """layers: list of (W, s, demod, gwb) -> list of (dW, ds), all layers in three launches.  cores=True: the co-resident
+    form (no LDS, <= 40 VGPRs: runs beside the fused SIREN backward when issued on a side stream; B <= 64, out % 4 == 0)."""
     lib = _lib.load()
     from ._lib import ModfcBwdJob
     mx = lib.cips_modfc_max_jobs()
     out = []
+    cores = bool(cores) and layers[0][1].shape[0] <= 64 and all(W.shape[1] % 4 == 0 for W, _, _, _ in layers)
+    parts = lib.cips_cores_colsum_parts() if cores else 1
     for c0 in range(0, len(layers), mx):
         chunk = layers[c0:c0 + mx]
         jobs = (ModfcBwdJob * len(chunk))()
@@ -1350,7 +1360,7 @@ def modfc_prep_bwd_batch(layers):
         for j, (W, s, demod, gwb) in zip(jobs, chunk):
             in_dim, out_dim = W.shape
             dev = W.device
-            cbuf = torch.empty(B, out_dim, device=dev)
+            cbuf = torch.empty(parts, B, out_dim, device=dev)
             dW = torch.empty(in_dim, out_dim, device=dev)
             ds = torch.empty(B, in_dim, device=dev)
             j.weight, j.s, j.demod, j.gwb = _p(W), _p(s), _p(demod), _p(gwb)
@@ -1358,7 +1368,10 @@ def modfc_prep_bwd_batch(layers):
             j.in_dim, j.out_dim = in_dim, out_dim
             keep.append(cbuf)
             out.append((dW, ds))
-        check(lib.cips_modfc_prep_bwd_batch(jobs, len(chunk), B, _stream()), "cips_modfc_prep_bwd_batch")
+        if cores:
+            check(lib.cips_modfc_prep_bwd_batch_cores(jobs, len(chunk), B, _stream()), "cips_modfc_prep_bwd_batch_cores")
+        else:
+            check(lib.cips_modfc_prep_bwd_batch(jobs, len(chunk), B, _stream()), "cips_modfc_prep_bwd_batch")
     return out
 
 
@@ -1383,9 +1396,10 @@ def torgb_bwd_w_x3(xp, drgb2d):
     return dw, db
 
 
-def torgb_bwd_w_x3_batch(xps, drgb2d):
+def torgb_bwd_w_x3_batch(xps, drgb2d, cores=False):
     """the ToRGB weight / bias gradients of several taps (Planes of one shape) against one drgb: list of (dw (3, K), db (3,)).
-    Two launches for all of them when K = 512 (<= 8 taps), else one pair per tap."""
+    Two launches for all of them when K = 512 (<= 8 taps), else one pair per tap.  cores=True: the co-resident form of the
+    batched launch (see modfc_prep_bwd_batch)."""
     lib = _lib.load()
     K = xps[0].hi.shape[-1]
     M = xps[0].hi.numel() // K
@@ -1399,7 +1413,8 @@ def torgb_bwd_w_x3_batch(xps, drgb2d):
     db = torch.empty(n, 3, device=dev)
     hi = (_ct.c_void_p * n)(*[_p(xp.hi) for xp in xps])
     lo = (_ct.c_void_p * n)(*[_p(xp.lo) for xp in xps])
-    check(lib.cips_torgb_bwd_w_x3_batch(hi, lo, n, _p(drgb2d), _p(part), _p(dw), _p(db), M, K, _stream()), "cips_torgb_bwd_w_x3_batch")
+    fn = lib.cips_torgb_bwd_w_x3_batch_cores if cores else lib.cips_torgb_bwd_w_x3_batch
+    check(fn(hi, lo, n, _p(drgb2d), _p(part), _p(dw), _p(db), M, K, _stream()), "cips_torgb_bwd_w_x3_batch")
     return [(dw[i], db[i]) for i in range(n)]
 
 
@@ -1441,7 +1456,14 @@ class InrHeadX3Function(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, nblocks, x0, *params):
-        nblocks, grad_mode = nblocks if isinstance(nblocks, tuple) else (nblocks, True)
+        ports = None
+        if isinstance(nblocks, tuple) and len(nblocks) == 3:
+            # (nblocks, grad mode, state of the two gradient ports): params carries, after the usual tensors (passed detached),
+            # one handle per modulated layer and the ToRGB handle; their "gradients" are dL/dWb and drgb (see _ModPrepGradPort)
+            nblocks, grad_mode, ports = nblocks
+            params = params[:len(params) - 2 * nblocks - 1]
+        else:
+            nblocks, grad_mode = nblocks if isinstance(nblocks, tuple) else (nblocks, True)
         x0 = _c(x0.detach())
         B, n, in0 = x0.shape
         if n % 32 or in0 % 32:
@@ -1547,6 +1569,10 @@ class InrHeadX3Function(torch.autograd.Function):
         ctx.nblocks, ctx.blocks, ctx.rgbp, ctx.saved = nblocks, blocks, rgbp, saved
         ctx.dims = (B, n)
         ctx.kmajor = INR_W_KMAJOR
+        ctx.ports = ports if train else None
+        if ports is not None and train:
+            ports["demod"] = [d for k in range(nblocks) for d in (saved[k]["d1"], saved[k]["d2"])]
+            ports["taps"] = [saved[k]["oP"] for k in range(3, nblocks)]
         return rgb
 
     @staticmethod
@@ -1603,7 +1629,7 @@ class InrHeadX3Function(torch.autograd.Function):
                     gT.hi.zero_(); gT.lo.zero_()
                 Dout = torch.zeros(nb, n, width, device=dev) if saved[k]["skip"] and not addp else None
             # ToRGB weight / bias gradients of all taps: they need only the saved block outputs and drgb
-            taps = list(range(3, nblocks))
+            taps = list(range(3, nblocks)) if ctx.ports is None else []
             if taps:
                 for k_, res_ in zip(taps, torgb_bwd_w_x3_batch([_bsl(saved[k_]["oP"], b0, b1) for k_ in taps], drgb2)):
                     rgb_parts[k_][ci] = res_
@@ -1678,6 +1704,10 @@ class InrHeadX3Function(torch.autograd.Function):
                     Dout = newD
 
         _run_chunks(ranges, run, dev)
+        if ctx.ports is not None:
+            _tail_gate_clear(dev)
+            # the tail runs in the ports' backward nodes (side stream): hand them dL/dWb of every layer and drgb
+            return (None, dx0) + (None,) * (4 * nblocks + len(rgbp)) + tuple(g for k in range(nblocks) for g in gwb[k]) + (drgb,)
         grads_blocks = [None] * nblocks
         grads_rgb = [None] * len(rgbp)
         for k in range(3, nblocks):
@@ -1701,6 +1731,112 @@ class InrHeadX3Function(torch.autograd.Function):
             flat.extend(gb)
         flat.extend(grads_rgb)
         return tuple(flat)
+
+
+class _ModPrepGradPort(torch.autograd.Function):
+    """Gradient port of the head's modulated weights.  forward: no launch — one handle per layer, a stride-0 zero shaped like
+    the per-image weights (B, in, out), which InrHeadX3Function takes as an input and answers with dL/dWb; backward: the
+    modulation / demodulation backward of all layers (mod_conv_fc.py:392-496) -> (dW, ds) per layer.  The node lives on the
+    stream that is current when apply() is called: CIPSNet.forward calls it under the generator's side stream."""
+
+    @staticmethod
+    def forward(ctx, state, B, *ws):
+        ctx.state = state
+        ctx.ws = tuple(_c(t.detach()) for t in ws)
+        z = _zero_handle(ws[0].device)
+        return tuple(z.expand(B, ws[2 * i].shape[0], ws[2 * i].shape[1]) for i in range(len(ws) // 2))
+
+    @staticmethod
+    def backward(ctx, *gwb):
+        _tail_gate_wait(gwb[0].device)
+        demod = ctx.state["demod"]
+        layers = [(ctx.ws[2 * i], ctx.ws[2 * i + 1], demod[i], _c(gwb[i])) for i in range(len(gwb))]
+        res = modfc_prep_bwd_batch(layers, cores=True)
+        return (None, None) + tuple(t for pair in res for t in pair)
+
+
+class _ToRGBGradPort(torch.autograd.Function):
+    """Gradient port of the ToRGB taps: forward returns a stride-0 zero shaped like the head's output (its gradient IS drgb),
+    backward computes every tap's weight / bias gradient from the block outputs the head kept (state["taps"])."""
+
+    @staticmethod
+    def forward(ctx, state, shape, *rgbp):
+        ctx.state, ctx.n = state, len(rgbp)
+        return _zero_handle(rgbp[0].device).expand(shape)
+
+    @staticmethod
+    def backward(ctx, drgb):
+        _tail_gate_wait(drgb.device)
+        taps = ctx.state["taps"]
+        drgb2 = _c(drgb).reshape(-1, 3)
+        out = []
+        for dT, dtau in torgb_bwd_w_x3_batch(taps, drgb2, cores=True):
+            out += [dT, dtau]
+        return (None, None) + tuple(out)
+
+
+_ZERO_HANDLE = {}
+
+
+def _zero_handle(dev):
+    """one cached zero element per device (never written): the storage behind every port handle.  Not cached under a graph
+    capture (a tensor made inside a capture lives in the graph's pool)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(1, device=dev)
+    z = _ZERO_HANDLE.get(dev)
+    if z is None:
+        z = _ZERO_HANDLE[dev] = torch.zeros(1, device=dev)
+    return z
+
+
+# The ports' tail must not start while the compositing backward (HBM-bound, on the critical path) is running: it would share the
+# bandwidth and delay it by as much as the tail gains.  The NeRF path's backward publishes an event right after that launch; the
+# ports' backward nodes — which the engine runs AFTER it when the ports were opened before the ray march in the forward pass
+# (lower sequence numbers; GeneratorNerfINR._render does that) — make their stream wait for it.  No event (frozen NeRF, ports
+# opened late): the tail starts as soon as the head's backward is done.
+_TAIL_GATE = {}
+
+
+def _tail_gate_clear(dev):
+    _TAIL_GATE.pop(torch.device(dev).index, None)
+
+
+def _tail_gate_publish(dev):
+    if INR_TAIL == "side" and torch.device(dev).type == "cuda":
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        _TAIL_GATE[torch.device(dev).index] = ev
+
+
+def _tail_gate_wait(dev):
+    ev = _TAIL_GATE.get(torch.device(dev).index)
+    if ev is not None:
+        torch.cuda.current_stream(dev).wait_event(ev)
+
+
+def inr_head_ports_ok(nblocks, B, n, in0, params, dev):
+    """the gradient-port form applies: split-bf16 head in training, batch within the co-resident kernels' limit, ToRGB taps present"""
+    return (INR_TAIL == "side" and INR_MODE == "bf16x3" and torch.device(dev).type == "cuda" and torch.is_grad_enabled()
+            and nblocks > 3 and n % 32 == 0 and in0 % 32 == 0 and B <= 64 and any(t.requires_grad for t in params))
+
+
+def inr_head_open_ports(nblocks, B, n, params, side):
+    """the two gradient ports of one head evaluation (see INR_TAIL), their autograd nodes on `side` -> (state, handles, H)"""
+    state = {}
+    ws, rgbp = params[:4 * nblocks], params[4 * nblocks:]
+    dev = params[0].device
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        handles = _ModPrepGradPort.apply(state, B, *ws)
+        H = _ToRGBGradPort.apply(state, (B, n, 3), *rgbp)
+    return state, handles, H
+
+
+def inr_head_with_ports(nblocks, x0, params, ports):
+    """inr_head with the weight-gradient tail behind the gradient ports `ports` = inr_head_open_ports(...)"""
+    state, handles, H = ports
+    det = [t.detach() for t in params]
+    return InrHeadX3Function.apply((nblocks, True, state), x0, *det, *handles, H)
 
 
 def inr_head(nblocks, x0, *params):

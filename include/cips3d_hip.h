@@ -453,6 +453,12 @@ typedef struct cips_modfc_bwd_job {
 int cips_modfc_max_jobs(void);
 int cips_modfc_prep_x3_batch(const cips_modfc_prep_job* jobs, int njobs, int B, float eps, cips_stream_t stream);
 int cips_modfc_prep_bwd_batch(const cips_modfc_bwd_job* jobs, int njobs, int B, cips_stream_t stream);
+/* Co-resident form of cips_modfc_prep_bwd_batch (same results up to the summation order): kernels without LDS and with
+ * <= 40 VGPRs, which get wave slots BESIDE a kernel that owns the whole LDS (the fused SIREN backward) instead of waiting
+ * for it — for a caller that runs this tail on a side stream.  cbuf must hold cips_cores_colsum_parts() planes of (B, out).
+ * B <= 64, out_dim % 4 == 0, else hipErrorNotSupported. */
+int cips_cores_colsum_parts(void);
+int cips_modfc_prep_bwd_batch_cores(const cips_modfc_bwd_job* jobs, int njobs, int B, cips_stream_t stream);
 
 /* Grouped small Linear layers: every per-image vector of the hot path is a Linear of a style vector — the 18
  * SinStyleMod.modulation layers of the CIPS head (exp/comm/models/mod_conv_fc.py:433-436, 474) and the gain_fc / bias_fc
@@ -501,6 +507,9 @@ int cips_torgb_bwd_w_x3(const void* x_hi, const void* x_lo, const float* drgb, f
  * x_hi / x_lo: host arrays of njobs device plane pointers; partials (njobs, chunks, 4, K); dw (njobs, 3, K); dbias (njobs, 3) */
 int cips_torgb_bwd_w_x3_batch(const void* const* x_hi, const void* const* x_lo, int njobs, const float* drgb,
                               float* partials, float* dw, float* dbias, long long M, int K, cips_stream_t stream);
+/* co-resident form (see cips_modfc_prep_bwd_batch_cores): same arguments, layouts and scratch */
+int cips_torgb_bwd_w_x3_batch_cores(const void* const* x_hi, const void* const* x_lo, int njobs, const float* drgb,
+                                    float* partials, float* dw, float* dbias, long long M, int K, cips_stream_t stream);
 /* dx (M,K) = drgb (M,3) @ w (3,K) [+ add]; optional copy before masking; out = dx * (mask>0 ? 1 : slope)
  * (the LeakyReLU gate of the layer below, fused).  mask / add / out_unmasked may be NULL. */
 int cips_torgb_bwd_x(const float* drgb, const float* w, const float* add, const float* mask, float slope,
