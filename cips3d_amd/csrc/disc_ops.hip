@@ -884,7 +884,7 @@ extern "C" int cips_image_to_u8(const float* x, unsigned char* out, int B, int C
   return CIPS_CHECK_LAUNCH();
 }
 
-extern "C" int cips_version(void) { return 6; }     // 6: + cips_conv2d_x3_dgrad_s2, cips_upfirdn2d_parity, cips_lrelu_bwd_bias_finish / _nhwc, cips_conv_weight_prep_batch (additive)
+extern "C" int cips_version(void) { return 7; }     // 7: + cips_modfc_prep_bwd_batch_cores, cips_torgb_bwd_w_x3_batch_cores, cips_cores_colsum_parts (additive); 6: + cips_conv2d_x3_dgrad_s2, cips_upfirdn2d_parity, cips_lrelu_bwd_bias_finish / _nhwc, cips_conv_weight_prep_batch (additive)
 extern "C" const char* cips_arch(void) { return "gfx950"; }
 
 extern "C" int cips_fused_bias_act(const float* x, const float* bias, const float* refer, float* y,

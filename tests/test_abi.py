@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     lib = _lib.load()
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.cips_version() == 6
+    assert lib.cips_version() == 7
     assert lib.cips_arch() == b"gfx950"
 
 

@@ -471,3 +471,46 @@ def test_nerf_network_of_other_width_or_depth_runs_unfused_and_matches_the_oracl
         gs = [p.grad for p in G.siren.parameters()]
         assert all(g_ is not None and bool(torch.isfinite(g_).all()) for g_ in gs) and any(float(g_.abs().max()) > 0 for g_ in gs)
         G.zero_grad()
+
+
+@pytest.mark.parametrize("tag", ["g_r8_flat_noise", "g_r16_hier", "g_r8_freeze"])
+def test_weight_gradient_tail_on_the_side_stream_gives_the_same_gradients(tag):
+    """ops.INR_TAIL: the head's weight-gradient tail behind two gradient ports on the side stream (opened before the ray march,
+    gated behind the compositing backward, co-resident kernel forms) against everything inside InrHeadX3Function on the caller's
+    stream: the same images bit for bit, every parameter gradient present in both and equal up to the tail kernels' summation
+    order; the ported form is the one that ran."""
+    from cips3d_amd import ops
+    if ops.INR_MODE != "bf16x3":
+        pytest.skip("the ports belong to the split-bf16 head")
+    fix = load_golden(tag)
+    d = torch.device("cuda:0")
+    G = seeded_generator(fix["seed"], freeze=fix["freeze"], device=d)
+    zs = {k: v.to(d) for k, v in fix["zs"].items()}
+    rand = {k: v.to(d) for k, v in fix["rand"].items()}
+    calls = []
+    orig = ops.inr_head_with_ports
+    ops.inr_head_with_ports = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    out = {}
+    keep = ops.INR_TAIL
+    try:
+        for mode in ("main", "side", "side"):
+            ops.INR_TAIL = mode
+            for p in G.parameters():
+                p.grad = None
+            n0 = len(calls)
+            imgs, _ = G(zs, img_size=fix["img_size"], nerf_noise=fix["nerf_noise"], return_aux_img=fix["aux"],
+                        grad_points=None, forward_points=None, rand_override=rand, **fix["G_kwargs"])
+            (imgs * fix["G0"].to(d)).sum().backward()
+            torch.cuda.synchronize()
+            assert (len(calls) - n0 == 1) == (mode == "side")
+            out.setdefault(mode, []).append((imgs.detach().clone(), {n: p.grad.clone() for n, p in G.named_parameters() if p.grad is not None}))
+    finally:
+        ops.INR_TAIL = keep
+        ops.inr_head_with_ports = orig
+    (im_m, g_m), (im_s, g_s), (im_s2, g_s2) = out["main"][0], out["side"][0], out["side"][1]
+    assert torch.equal(im_m, im_s) and torch.equal(im_s, im_s2)
+    assert g_m.keys() == g_s.keys() == g_s2.keys()
+    for k in g_m:
+        assert torch.equal(g_s[k], g_s2[k]), k                                  # the side-stream form is reproducible
+        scale = float(g_m[k].abs().max()) + 1e-30
+        assert float((g_m[k] - g_s[k]).abs().max()) <= 5e-6 * scale, (k, float((g_m[k] - g_s[k]).abs().max()) / scale)

@@ -451,9 +451,18 @@ def test_modfc_prep_batch_forward_backward(shapes, B_):
         assert rel_err(wbP.float(), wb.float()) < 2e-5
         if wbtP is not None and wbtP.hi is not None:
             assert rel_err(wbtP.float(), wb.float().transpose(1, 2)) < 2e-5
-    res = ops.modfc_prep_bwd_batch([(W.detach().to(d), s.detach().to(d), p[2], up.to(d)) for W, s, p, up in zip(Ws, ss, prep, ups)])
+    layers = [(W.detach().to(d), s.detach().to(d), p[2], up.to(d)) for W, s, p, up in zip(Ws, ss, prep, ups)]
+    res = ops.modfc_prep_bwd_batch(layers)
     for (dW, ds), W, s in zip(res, Ws, ss):
         assert rel_err(dW, W.grad) < 1e-4 and rel_err(ds, s.grad) < 1e-4
+    # the co-resident form (no LDS, <= 40 VGPRs: cips_modfc_prep_bwd_batch_cores; the wrapper falls back to the form above
+    # outside its limits, B <= 64 and out_dim % 4 == 0): the same gradients up to the summation order, and reproducible
+    res_c = ops.modfc_prep_bwd_batch(layers, cores=True)
+    for (dW, ds), (dWc, dsc), W, s in zip(res, res_c, Ws, ss):
+        assert rel_err(dWc, W.grad) < 1e-4 and rel_err(dsc, s.grad) < 1e-4
+        assert rel_err(dWc, dW) < 2e-6 and rel_err(dsc, ds) < 2e-6
+    res_c2 = ops.modfc_prep_bwd_batch(layers, cores=True)
+    assert all(torch.equal(a, b) and torch.equal(c, e) for (a, c), (b, e) in zip(res_c, res_c2))
 
 
 def _planes(x):
@@ -955,6 +964,14 @@ def test_torgb_x3_forward_and_weight_gradient(M, K):
     torch.cuda.synchronize()
     assert torch.equal(res[0][0], dw) and torch.equal(res[0][1], db) and torch.equal(res[2][0], dw)
     assert torch.equal(res[1][0], dwy) and torch.equal(res[1][1], dby)
+    # the co-resident form of the batched launch (cips_torgb_bwd_w_x3_batch_cores): rows in order inside a wave, the same sums
+    # up to that order, reproducible
+    resc = ops.torgb_bwd_w_x3_batch([xP, yP, xP], drgb.to(d), cores=True)
+    resc2 = ops.torgb_bwd_w_x3_batch([xP, yP, xP], drgb.to(d), cores=True)
+    for (a, b_), (c, e), (f, h) in zip(res, resc, resc2):
+        assert rel_err(c, a) < 2e-6 and rel_err(e, b_) < 2e-6
+        assert torch.equal(c, f) and torch.equal(e, h)
+    assert rel_err(resc[0][0], drgb.double().t() @ x[0].double()) < 1e-5
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float64, torch.float32])
