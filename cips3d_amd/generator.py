@@ -399,7 +399,8 @@ class CIPSNet(nn.Module):
         names = self._names(img_size)
         tail, self._tail = getattr(self, "_tail", None), None
         key = (input.shape[0], input.shape[1], input.shape[2], len(names), id(style_dict))
-        if tail is None and torch.is_grad_enabled() and input.is_cuda and self.open_tail_ports(style_dict, *key[:3], img_size=img_size):
+        if (tail is None and torch.is_grad_enabled() and input.is_cuda and input.requires_grad
+                and self.open_tail_ports(style_dict, *key[:3], img_size=img_size)):
             tail, self._tail = self._tail, None          # not opened ahead (a direct call): open them now
         if tail is not None and tail["key"] == key and torch.is_grad_enabled():
             if tail["ports"] is not None:
@@ -652,9 +653,11 @@ class GeneratorNerfINR(nn.Module):
         part = grad_points is not None and grad_points < n
         if part:
             staged = False          # generator.py:1325-1347: part_grad_forward is not handed forward_points
-        if not part and not staged and torch.is_grad_enabled():
+        if not part and not staged and nerf_grad and torch.is_grad_enabled():
             # the INR head's gradient ports, opened before the NeRF path so that its backward is issued first
-            # (CIPSNet.open_tail_ports); they sit on the INR mapping network's side stream, joined right before the head
+            # (CIPSNet.open_tail_ports); they sit on the INR mapping network's side stream, joined right before the head.
+            # Only where a NeRF backward follows the head's: with a frozen NeRF there is nothing to run beside, and the
+            # side-stream form measured 0.4 ms slower than the plain one at the r256 stages (profiles/r6_tail_ab.txt)
             if self.inr_net.open_tail_ports(style_dict, b, n, 32, join=False):
                 self._pending_side = _side_stream(device)
 

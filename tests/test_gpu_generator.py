@@ -478,7 +478,7 @@ def test_weight_gradient_tail_on_the_side_stream_gives_the_same_gradients(tag):
     """ops.INR_TAIL: the head's weight-gradient tail behind two gradient ports on the side stream (opened before the ray march,
     gated behind the compositing backward, co-resident kernel forms) against everything inside InrHeadX3Function on the caller's
     stream: the same images bit for bit, every parameter gradient present in both and equal up to the tail kernels' summation
-    order; the ported form is the one that ran."""
+    order; the ported form is the one that ran (except with a frozen NeRF, where nothing follows the head's backward)."""
     from cips3d_amd import ops
     if ops.INR_MODE != "bf16x3":
         pytest.skip("the ports belong to the split-bf16 head")
@@ -502,7 +502,8 @@ def test_weight_gradient_tail_on_the_side_stream_gives_the_same_gradients(tag):
                         grad_points=None, forward_points=None, rand_override=rand, **fix["G_kwargs"])
             (imgs * fix["G0"].to(d)).sum().backward()
             torch.cuda.synchronize()
-            assert (len(calls) - n0 == 1) == (mode == "side")
+            # (a frozen NeRF has no backward to run beside: the generator keeps the plain form there)
+            assert (len(calls) - n0 == 1) == (mode == "side" and not fix["freeze"])
             out.setdefault(mode, []).append((imgs.detach().clone(), {n: p.grad.clone() for n, p in G.named_parameters() if p.grad is not None}))
     finally:
         ops.INR_TAIL = keep
